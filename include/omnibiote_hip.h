@@ -1,0 +1,154 @@
+/* omnibiote_hip.h — C ABI of libomnibiote_hip.so: the MI355X (gfx950) implementation of the OmniBioTE
+ * encoder-training hot path.
+ *
+ * The reference (nyuolab/OmniBioTE) is pure Python and defines no FFI of its own; each entry point below
+ * names the reference code it replaces (paths relative to the reference tree).  Conventions:
+ *   - every function returns 0 on success or a negative OBTE_E* code; obte_last_error() gives the text
+ *     (thread-local).  Nothing here allocates, frees or synchronises: all buffers (incl. workspaces) are
+ *     caller-owned device memory, borrowed for the duration of the call, and kernels are enqueued on the
+ *     caller's stream (a hipStream_t passed as void*; NULL = the null stream).
+ *   - bf16 tensors are passed as uint16_t* (bit pattern of bfloat16), dense row-major unless a stride
+ *     argument says otherwise.  "rows" always means tokens (B*T).
+ *   - re-entrant: no global mutable state besides the thread-local error string.
+ */
+#ifndef OMNIBIOTE_HIP_H
+#define OMNIBIOTE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t obte_bf16;
+typedef void* obte_stream;
+
+enum {
+    OBTE_OK = 0,
+    OBTE_EINVAL = -1,   /* bad shape / alignment / null pointer */
+    OBTE_ELAUNCH = -2,  /* hipLaunch failure */
+    OBTE_EUNSUPPORTED = -3
+};
+
+int obte_abi_version(void);
+const char* obte_last_error(void);
+
+/* ---- LayerNorm, weight only, eps inside (training/model.py:63-72; F.layer_norm) ------------------------- */
+/* y = (x-mean)*rstd*w ; saves mean,rstd (fp32, one per row) for backward.  cols % 8 == 0, cols <= 4096. */
+int obte_layernorm_fwd(const obte_bf16* x, const obte_bf16* w, obte_bf16* y, float* mean, float* rstd,
+                       int64_t rows, int cols, float eps, obte_stream s);
+/* dx = LN'(dy) (+ dresid if non-null); dw = sum_rows dy*xhat.  ws: fp32 [obte_layernorm_bwd_ws_rows()*cols]. */
+int obte_layernorm_bwd_ws_rows(void);
+int obte_layernorm_bwd(const obte_bf16* dy, const obte_bf16* x, const obte_bf16* w, const float* mean,
+                       const float* rstd, const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dw, float* ws,
+                       int64_t rows, int cols, obte_stream s);
+
+/* ---- bf16 GEMM on MFMA, fp32 accumulate (nn.Linear fwd/dgrad/wgrad: training/model.py:102,151,163,166,253)
+ * D[M,N] = epilogue(alpha * sum_k A(m,k) * B(n,k)).
+ *   a_kmajor=1: A(m,k) = a[m*lda + k]   (k contiguous)      a_kmajor=0: A(m,k) = a[k*lda + m]
+ *   b_kmajor=1: B(n,k) = b[n*ldb + k]                        b_kmajor=0: B(n,k) = b[k*ldb + n]
+ * forward  y = x W^T      : A=x (kmajor), B=W (kmajor)
+ * dgrad    dx = dy W      : A=dy (kmajor), B=W (k = out-feature rows: b_kmajor=0)
+ * wgrad    dW = dy^T x    : A=dy (a_kmajor=0, k = tokens), B=x (b_kmajor=0)
+ * Requirements: lda, ldb, ldd % 8 == 0; a k-major operand needs K % 64 == 0 (a k-strided one may have any K:
+ * the tail is zero-filled by the buffer bounds check); operands are dense (total size rows*ld).
+ */
+enum {
+    OBTE_EPI_NONE = 0,      /* d = bf16(alpha*acc) */
+    OBTE_EPI_GELU = 1,      /* d = bf16(acc) ; d2 = bf16(gelu_erf_1.41421(d))   (model.py:23-25,163-165) */
+    OBTE_EPI_ADD = 2,       /* d = bf16(aux + bf16(acc))    residual add (model.py:179-180) */
+    OBTE_EPI_GELU_BWD = 3   /* d = bf16(bf16(acc) * gelu'(aux))  aux = pre-activation */
+};
+typedef struct {
+    const obte_bf16* a; const obte_bf16* b; obte_bf16* d;
+    const obte_bf16* aux;   /* [M,N] ld = ldd, for EPI_ADD / EPI_GELU_BWD */
+    obte_bf16* d2;          /* [M,N] ld = ldd, for EPI_GELU */
+    int64_t M, N, K;
+    int64_t lda, ldb, ldd;
+    int32_t a_kmajor, b_kmajor;
+    int32_t epilogue;
+    float alpha;
+} obte_gemm_args;
+int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s);
+
+/* ---- RoPE on the q and k thirds of a packed qkv activation, in place (training/model.py:39-50,108) ------
+ * qkv: [rows = B*T, 3*C]; pairs (2j,2j+1) of each head; position = row % T.  cos/sin: fp32 [T, hs/2].
+ * sin all-zero reproduces the reference's degenerate bf16 mode.  inverse=1 applies the
+ * transpose (backward). */
+int obte_rope_qk_inplace(obte_bf16* qkv, const float* cos_t, const float* sin_t, int64_t B, int64_t T,
+                         int n_head, int head_dim, int inverse, obte_stream s);
+
+/* ---- fused attention (training/model.py:115-148): softmax(q k^T * scale + mask) v, non-causal -------------
+ * q,k,v are read from the packed [B*T, 3C] qkv buffer (row stride 3C; head h at column h*hs, k at +C, v at
+ * +2C) and o is written as [B*T, C] (heads side by side: the "merge heads" copy of model.py:148 is free).
+ * Mask, one of:  none;  key ranges int32 [B,T,2] = [k_start,k_end) per query (the block-diagonal masks of
+ * train_encoder.py:25-57);  dense additive bf16 with element strides (mask_sb, mask_sh, mask_sq; key stride 1;
+ * mask_sh = 0 for the reference's expand() view).  lse: fp32 [B,H,T] (natural log, of the scaled scores).
+ * head_dim in {64,128}.  */
+typedef struct {
+    const obte_bf16* qkv; obte_bf16* o; float* lse;
+    const int32_t* key_ranges; const obte_bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
+    int64_t B, T; int32_t n_head, head_dim; float scale;
+} obte_attn_fwd_args;
+int obte_attn_fwd(const obte_attn_fwd_args* a, obte_stream s);
+
+typedef struct {
+    const obte_bf16* qkv; const obte_bf16* o; const obte_bf16* d_o; const float* lse;
+    float* delta;          /* workspace fp32 [B,H,T] */
+    obte_bf16* dqkv;       /* out, packed like qkv (all three thirds written) */
+    const float* rope_cos; const float* rope_sin;  /* nullable pair, fp32 [T, hs/2]: if given, dq and dk are
+                                                      returned already multiplied by the transpose of the RoPE
+                                                      map (i.e. gradients w.r.t. the un-rotated c_attn output) */
+    const int32_t* key_ranges; const obte_bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
+    int64_t B, T; int32_t n_head, head_dim; float scale;
+} obte_attn_bwd_args;
+int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s);
+
+/* ---- token embedding (training/model.py:203,241) ------------------------------------------------------------
+ * fwd: out[r,:] = wte[idx[r],:].  bwd: dwte (dense [V,C], fully written) = scatter-add of dout rows, summed in
+ * fp32 in a fixed order (deterministic).  order = a stable argsort of idx (int32 [rows]); ws: fp32
+ * [2*ceil(rows/32)*C + ...] see obte_embedding_bwd_ws_bytes. */
+int obte_embedding_fwd(const int64_t* idx, const obte_bf16* wte, obte_bf16* out, int64_t rows, int cols,
+                       int64_t vocab, obte_stream s);
+int64_t obte_embedding_bwd_ws_bytes(int64_t rows, int cols);
+int obte_embedding_bwd(const int64_t* idx, const int32_t* order, const obte_bf16* dout, obte_bf16* dwte,
+                       void* ws, int64_t rows, int cols, int64_t vocab, obte_stream s);
+
+/* ---- masked-LM cross entropy, forward + backward in one pass (training/train_encoder.py:301-305) -------------
+ * loss_sum[0] += sum over rows with mlm_mask!=0 of (logsumexp(logits[r]) - logits[r,target[r]]) * row_scale
+ * dlogits[r,:] = (softmax(logits[r]) - onehot(target[r])) * row_scale * grad_scale[0]  for masked rows, else 0,
+ * where row_scale = 1/n_accum and grad_scale points at a device fp32 (1/mask_count), so no host sync is needed.
+ * vocab % 8 == 0, vocab <= 65536*2. */
+int obte_masked_ce_fwd_bwd(const obte_bf16* logits, const int64_t* target, const uint8_t* mlm_mask,
+                           const float* grad_scale, float row_scale, float* loss_sum, float* row_loss,
+                           obte_bf16* dlogits, int64_t rows, int64_t vocab, obte_stream s);
+
+/* ---- fused AdamW step, bf16 params/grads/moments as the reference trains (train_encoder.py:170,199,316-317) ---
+ * One launch per tensor: p -= lr*(m_hat/(sqrt(v_hat)+eps) + wd*p), grads pre-multiplied by clip_coef[0]
+ * (device fp32, 1.0 if no clipping).  step is 1-based.  */
+int obte_adamw_bf16(obte_bf16* p, const obte_bf16* g, obte_bf16* m, obte_bf16* v, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                    const float* clip_coef, obte_stream s);
+/* sum of squares of a bf16 tensor accumulated into out[0] (fp32, atomics) — for clip_grad_norm_. */
+int obte_sumsq_bf16(const obte_bf16* g, int64_t n, float* out, obte_stream s);
+
+/* ---- whole transformer block (training/model.py:170-181), forward and backward, dropout 0 --------------------
+ * One host call enqueues every kernel of the block, so Python crosses the boundary once per block and pass.
+ * Activations saved for backward live in one caller-allocated buffer of obte_block_act_bytes() bytes. */
+typedef struct {
+    int64_t B, T; int32_t n_embd, n_head;
+    const obte_bf16 *ln1_w, *attn_w, *proj_w, *ln2_w, *fc_w, *mlp_w;   /* parameters */
+    const float *rope_cos, *rope_sin;                                   /* [T, hs/2] */
+    const int32_t* key_ranges; const obte_bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
+} obte_block_desc;
+int64_t obte_block_act_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head);
+int64_t obte_block_bwd_ws_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head);
+int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte_bf16* y, void* act, obte_stream s);
+/* grads of the six parameters are written (not accumulated) to d*_w; dx to dx. */
+int obte_block_bwd(const obte_block_desc* d, const obte_bf16* x, const obte_bf16* dy, const void* act, void* ws,
+                   obte_bf16* dx, obte_bf16* dln1_w, obte_bf16* dattn_w, obte_bf16* dproj_w, obte_bf16* dln2_w,
+                   obte_bf16* dfc_w, obte_bf16* dmlp_w, obte_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

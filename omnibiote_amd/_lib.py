@@ -1,0 +1,112 @@
+"""ctypes binding of libomnibiote_hip.so (C ABI: include/omnibiote_hip.h).
+
+Loaded lazily and exactly once; a missing or unloadable library is a hard error (there is no fallback path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libomnibiote_hip.so")
+
+c_bf16_p = C.c_void_p
+c_f32_p = C.c_void_p
+c_stream = C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("d", C.c_void_p), ("aux", C.c_void_p), ("d2", C.c_void_p),
+                ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("ldd", C.c_int64),
+                ("a_kmajor", C.c_int32), ("b_kmajor", C.c_int32), ("epilogue", C.c_int32), ("alpha", C.c_float)]
+
+
+class AttnFwdArgs(C.Structure):
+    _fields_ = [("qkv", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
+                ("key_ranges", C.c_void_p), ("mask", C.c_void_p),
+                ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
+                ("B", C.c_int64), ("T", C.c_int64), ("n_head", C.c_int32), ("head_dim", C.c_int32), ("scale", C.c_float)]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("qkv", C.c_void_p), ("o", C.c_void_p), ("d_o", C.c_void_p), ("lse", C.c_void_p),
+                ("delta", C.c_void_p), ("dqkv", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+                ("key_ranges", C.c_void_p), ("mask", C.c_void_p),
+                ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
+                ("B", C.c_int64), ("T", C.c_int64), ("n_head", C.c_int32), ("head_dim", C.c_int32), ("scale", C.c_float)]
+
+
+class BlockDesc(C.Structure):
+    _fields_ = [("B", C.c_int64), ("T", C.c_int64), ("n_embd", C.c_int32), ("n_head", C.c_int32),
+                ("ln1_w", C.c_void_p), ("attn_w", C.c_void_p), ("proj_w", C.c_void_p),
+                ("ln2_w", C.c_void_p), ("fc_w", C.c_void_p), ("mlp_w", C.c_void_p),
+                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+                ("key_ranges", C.c_void_p), ("mask", C.c_void_p),
+                ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64)]
+
+
+EPI_NONE, EPI_GELU, EPI_ADD, EPI_GELU_BWD = 0, 1, 2, 3
+
+# name -> (restype, argtypes); every symbol include/omnibiote_hip.h declares
+SYMBOLS = {
+    "obte_abi_version": (C.c_int, []),
+    "obte_last_error": (C.c_char_p, []),
+    "obte_layernorm_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_float, c_stream]),
+    "obte_layernorm_bwd_ws_rows": (C.c_int, []),
+    "obte_layernorm_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, c_stream]),
+    "obte_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), c_stream]),
+    "obte_rope_qk_inplace": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, c_stream]),
+    "obte_attn_fwd": (C.c_int, [C.POINTER(AttnFwdArgs), c_stream]),
+    "obte_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), c_stream]),
+    "obte_embedding_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int64, c_stream]),
+    "obte_embedding_bwd_ws_bytes": (C.c_int64, [C.c_int64, C.c_int]),
+    "obte_embedding_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int64, c_stream]),
+    "obte_masked_ce_fwd_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int64, C.c_int64, c_stream]),
+    "obte_adamw_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int32, C.c_void_p, c_stream]),
+    "obte_sumsq_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, c_stream]),
+    "obte_block_act_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "obte_block_bwd_ws_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "obte_block_fwd": (C.c_int, [C.POINTER(BlockDesc), C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
+    "obte_block_bwd": (C.c_int, [C.POINTER(BlockDesc)] + [C.c_void_p] * 11 + [c_stream]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library.  Raises HipLibraryError if it is missing: build it with
+    ``python -c 'import __graft_entry__ as g; g.build()'`` (or ``make -C omnibiote_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise HipLibraryError(f"{LIB_PATH} not found: the HIP library has not been built "
+                                      "(make -C omnibiote_amd/csrc). There is no CPU fallback.")
+            try:
+                l = C.CDLL(LIB_PATH)
+            except OSError as e:
+                raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+            for name, (res, args) in SYMBOLS.items():
+                try:
+                    fn = getattr(l, name)
+                except AttributeError as e:
+                    raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+                fn.restype = res
+                fn.argtypes = args
+            _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().obte_last_error()
+        raise RuntimeError(f"{what or 'libomnibiote_hip'} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,693 @@
+// Fused attention for the OmniBioTE block (training/model.py:115-148), forward and backward, on CDNA4 MFMA
+// (v_mfma_f32_32x32x16_bf16).  softmax(q k^T * scale + mask) v, non-causal, scale = 8/n_embd passed in.
+//
+// Data layout: q, k, v are read in place from the packed c_attn output [B*T, 3C] (row stride 3C, head h at
+// column h*D); o is written as [B*T, C], so the reference's transpose(1,2).contiguous() copy never exists.
+//
+// Common structure of the three kernels: the operand that belongs to the workgroup's own rows stays in
+// registers as MFMA B fragments (16 B per lane straight from global memory); the other side streams through
+// LDS in 64-row (or 32-row) tiles, XOR-swizzled so that both row reads (ds_read_b128) and hardware-transposed
+// reads (ds_read_b64_tr_b16) are bank-conflict free.  Scores are produced TRANSPOSED with the workgroup's own
+// row index on the MFMA lane (S^T = K Q^T in forward/dQ, S = Q K^T with the key on the lane in dK/dV), so that
+//   - softmax statistics are per lane (one cross-lane exchange with lane^32 per tile), and
+//   - the f32 score accumulator, converted to bf16 in registers, already IS the B operand of the next MFMA
+//     (O^T += V^T P^T, dQ^T += K^T dS^T, dV^T += dO^T P, dK^T += Q^T dS): no LDS round trip for P or dS.
+// Masks: none | per-query key ranges [k_start,k_end) (block-diagonal document masks; KV tiles outside the
+// workgroup's union range are skipped) | dense additive bf16 (any strides, stride-0 heads allowed).
+// Backward is two kernels without atomics (bitwise reproducible): dQ per query block, dK/dV per key block,
+// each recomputing P from the saved log-sum-exp.  The dK/dV kernel, in range mode, uses the symmetry of the
+// reference's masks (query t may see key u  <=>  query u may see key t).
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+enum { MASK_NONE = 0, MASK_RANGES = 1, MASK_DENSE = 2 };
+
+struct AttnParams {
+    const bf16* qkv; bf16* o; float* lse;                       // forward
+    const bf16* o_in; const bf16* d_o; const float* lse_in; float* delta; bf16* dqkv;   // backward
+    const float* rope_cos; const float* rope_sin;               // backward: inverse RoPE on dq, dk (nullable)
+    const int32_t* key_ranges; const bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
+    int64_t B, T; int H; float scale;
+};
+
+template <int D>
+__device__ __forceinline__ int swz(int row, int ch) {
+    if (D == 128) return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+    return row * 128 + ((ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+// A/B fragment of v_mfma_f32_32x32x16_bf16 read by rows: lane l -> tile row row0 + (l&31), k = 16s + 8(l>>5) + j.
+template <int D>
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int row0, int s, int lane) {
+    return *reinterpret_cast<const bf16x8*>(tile + swz<D>(row0 + (lane & 31), 2 * s + (lane >> 5)));
+}
+
+// A fragment of the TRANSPOSED tile: MFMA row = tile column 32*dt + (l&31), MFMA k element j = tile row
+// krow0 + 8(j>>2) + 4(l>>5) + (j&3)  — the row order in which a 32x32 f32 accumulator, converted in place,
+// serves as the other operand (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand").
+template <int D>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int krow0, int dt, int lane) {
+    const int li = lane & 15;
+    const int row = krow0 + 4 * (lane >> 5) + (li >> 2);
+    const int ch = 4 * dt + 2 * ((lane >> 4) & 1) + ((li & 3) >> 1);
+    const int sub = (li & 1) * 8;
+    const bf16x4 lo = lds_read_tr16(tile + swz<D>(row, ch) + sub);
+    const bf16x4 hi = lds_read_tr16(tile + swz<D>(row + 8, ch) + sub);
+    return join8(lo, hi);
+}
+
+// Global -> registers -> LDS staging of a ROWS x D tile by 256 threads (rows >= nvalid read as zero).
+template <int D, int ROWS>
+struct TileStage {
+    static constexpr int CPR = D / 8;                 // 16-B chunks per row
+    static constexpr int N = ROWS * CPR / 256;        // chunks per thread
+    bf16x8 r[N];
+    __device__ __forceinline__ void load(const bf16* g, int64_t row_stride, int nvalid, int tid) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int cid = tid + 256 * i;
+            const int row = cid / CPR, ch = cid % CPR;
+            bf16x8 v = {};
+            if (row < nvalid) v = *reinterpret_cast<const bf16x8*>(g + (int64_t)row * row_stride + ch * 8);
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(char* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int cid = tid + 256 * i;
+            *reinterpret_cast<bf16x8*>(tile + swz<D>(cid / CPR, cid % CPR)) = r[i];
+        }
+    }
+};
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// accumulator register -> row index inside the 32x32 tile, for lane half h
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int base) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = f2bf(v[base + j]);
+    return r;
+}
+
+// min/max over the workgroup (256 threads) through a small LDS scratch of 8 ints
+__device__ __forceinline__ void block_minmax(int& lo, int& hi, int* scratch, int wave, int lane) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o, 64));
+        hi = max(hi, __shfl_xor(hi, o, 64));
+    }
+    if (lane == 0) { scratch[wave] = lo; scratch[4 + wave] = hi; }
+    __syncthreads();
+    lo = min(min(scratch[0], scratch[1]), min(scratch[2], scratch[3]));
+    hi = max(max(scratch[4], scratch[5]), max(scratch[6], scratch[7]));
+    __syncthreads();
+}
+
+// ==========================================================================================================
+// forward
+// ==========================================================================================================
+template <int D, int MODE>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 64 * 2 * D;  // bytes of one 64-row tile
+    constexpr int NS = D / 16;      // k-steps over the head dim
+    constexpr int ND = D / 32;      // 32-wide d tiles of the output
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int hd = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int T = (int)p.T;
+    const int C = p.H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const int q_row = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool q_ok = q_row < T;
+    const int q_c = q_ok ? q_row : T - 1;
+
+    const bf16* qptr = p.qkv + (b * T + q_c) * ld + hd * D;
+    bf16x8 qf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qptr + 16 * s + 8 * h);
+
+    int ks = 0, ke = T;
+    if (MODE == MASK_RANGES) {
+        ks = p.key_ranges[(b * T + q_c) * 2];
+        ke = min(p.key_ranges[(b * T + q_c) * 2 + 1], T);
+        ks = max(ks, 0);
+    }
+    int lo = ks, hi = ke;
+    if (MODE == MASK_RANGES) block_minmax(lo, hi, reinterpret_cast<int*>(smem + 4 * TB), wave, lane);
+    const int t_begin = lo / 64;
+    const int t_end = hi > lo ? (hi + 63) / 64 : t_begin;
+
+    const bf16* kbase = p.qkv + b * T * ld + C + hd * D;
+    const bf16* vbase = kbase + C;
+    const bf16* mrow = nullptr;
+    if (MODE == MASK_DENSE) mrow = p.mask + b * p.mask_sb + hd * p.mask_sh + (int64_t)q_c * p.mask_sq;
+
+    float m = -INFINITY, l = 0.f;
+    f32x16 o[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    const float scale2 = p.scale * LOG2E;
+
+    TileStage<D, 64> sk, sv;
+    if (t_begin < t_end) {
+        sk.load(kbase + (int64_t)t_begin * 64 * ld, ld, T - t_begin * 64, tid);
+        sv.load(vbase + (int64_t)t_begin * 64 * ld, ld, T - t_begin * 64, tid);
+        sk.store(smem, tid);
+        sv.store(smem + TB, tid);
+    }
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int cur = (t - t_begin) & 1;
+        const bool more = t + 1 < t_end;
+        if (more) {
+            sk.load(kbase + (int64_t)(t + 1) * 64 * ld, ld, T - (t + 1) * 64, tid);
+            sv.load(vbase + (int64_t)(t + 1) * 64 * ld, ld, T - (t + 1) * 64, tid);
+        }
+        const char* Kt = smem + cur * 2 * TB;
+        const char* Vt = Kt + TB;
+        const int key0 = t * 64;
+
+        f32x16 sc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[0][r] = 0.f; sc[1][r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 0, s, lane), qf[s], sc[0], 0, 0, 0);
+            sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 32, s, lane), qf[s], sc[1], 0, 0, 0);
+        }
+        // scores in the log2 domain, plus mask
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = sc[mt][r] * scale2;
+                if (MODE == MASK_DENSE) {
+                    const int key = key0 + 32 * mt + acc_row(r, h);
+                    if (key < T) x += bf2f(mrow[key]) * LOG2E;
+                }
+                sc[mt][r] = x;
+            }
+        const bool inside = key0 >= ks && key0 + 64 <= ke;
+        if (!__all(inside)) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + 32 * mt + acc_row(r, h);
+                    if (key < ks || key >= ke) sc[mt][r] = -INFINITY;
+                }
+        }
+        float mx = sc[0][0];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[mt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = fast_exp2(m - m_safe);
+        float rs = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = fast_exp2(sc[mt][r] - m_safe);
+                sc[mt][r] = pv;
+                rs += pv;
+            }
+        l = l * alpha + rs;
+        m = m_new;
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        // O^T += V^T P^T : P^T accumulators are the B operand as they stand
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 pf = pack8(sc[kk >> 1], 8 * (kk & 1));
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Vt, 16 * kk, dt, lane), pf, o[dt], 0, 0, 0);
+        }
+        if (more) {
+            sk.store(smem + (cur ^ 1) * 2 * TB, tid);
+            sv.store(smem + (cur ^ 1) * 2 * TB + TB, tid);
+        }
+        __syncthreads();
+    }
+
+    const float l_tot = l + __shfl_xor(l, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (q_ok) {
+        if (h == 0) p.lse[(b * p.H + hd) * T + q_row] = l_tot > 0.f ? (m + __log2f(l_tot)) * LN2 : INFINITY;
+        bf16* orow = p.o + (b * T + q_row) * C + hd * D;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bf16x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = f2bf(o[dt][4 * i + j] * inv);
+                *reinterpret_cast<bf16x4*>(orow + 32 * dt + 8 * i + 4 * h) = v;
+            }
+    }
+}
+
+// ==========================================================================================================
+// backward, part 0: delta[b,h,t] = sum_d dO * O   (one 8-element chunk per lane, D/8 lanes per (row, head))
+// ==========================================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ d_o,
+                                                          float* __restrict__ delta, int64_t B, int64_t T, int H) {
+    constexpr int LPR = D / 8;
+    const int C = H * D;
+    const int64_t total = B * T * H * LPR;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f;
+    int64_t bt = 0; int hd = 0;
+    if (i < total) {
+        const int64_t item = i / LPR;
+        const int c8 = (int)(i % LPR);
+        bt = item / H; hd = (int)(item % H);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(o + bt * C + hd * D + c8 * 8);
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(d_o + bt * C + hd * D + c8 * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += bf2f(a[j]) * bf2f(g[j]);
+    }
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (i < total && (i % LPR) == 0) {
+        const int64_t bb = bt / T, t = bt % T;
+        delta[(bb * H + hd) * T + t] = s;
+    }
+}
+
+// inverse RoPE on 4 consecutive head-dim elements (d0 multiple of 4) of a gradient row at position t
+__device__ __forceinline__ void rope_inv4(float (&g)[4], const float* cos_t, const float* sin_t, int64_t t, int D, int d0) {
+    if (!cos_t) return;
+    const float c0 = cos_t[t * (D / 2) + d0 / 2], c1 = cos_t[t * (D / 2) + d0 / 2 + 1];
+    const float s0 = sin_t[t * (D / 2) + d0 / 2], s1 = sin_t[t * (D / 2) + d0 / 2 + 1];
+    const float e0 = g[0] * c0 + g[1] * s0, o0 = -g[0] * s0 + g[1] * c0;
+    const float e1 = g[2] * c1 + g[3] * s1, o1 = -g[2] * s1 + g[3] * c1;
+    g[0] = e0; g[1] = o0; g[2] = e1; g[3] = o1;
+}
+
+// ==========================================================================================================
+// backward, part 1: dQ.  Same shape as forward: 128 queries per workgroup, query on the lane.
+//   S^T = K Q^T ; P^T = exp(S^T*scale + mask - lse) ; dP^T = V dO^T ; dS^T = P^T (dP^T - delta) ; dQ^T += K^T dS^T
+// ==========================================================================================================
+template <int D, int MODE>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 64 * 2 * D;
+    constexpr int NS = D / 16, ND = D / 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int hd = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int T = (int)p.T;
+    const int C = p.H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const int q_row = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool q_ok = q_row < T;
+    const int q_c = q_ok ? q_row : T - 1;
+
+    const bf16* qptr = p.qkv + (b * T + q_c) * ld + hd * D;
+    const bf16* doptr = p.d_o + (b * T + q_c) * C + hd * D;
+    bf16x8 qf[NS], dof[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        qf[s] = *reinterpret_cast<const bf16x8*>(qptr + 16 * s + 8 * h);
+        dof[s] = *reinterpret_cast<const bf16x8*>(doptr + 16 * s + 8 * h);
+    }
+    const float lse2 = p.lse_in[(b * p.H + hd) * T + q_c] * LOG2E;
+    const float dl = p.delta[(b * p.H + hd) * T + q_c];
+
+    int ks = 0, ke = T;
+    if (MODE == MASK_RANGES) {
+        ks = max(p.key_ranges[(b * T + q_c) * 2], 0);
+        ke = min(p.key_ranges[(b * T + q_c) * 2 + 1], T);
+    }
+    int lo = ks, hi = ke;
+    if (MODE == MASK_RANGES) block_minmax(lo, hi, reinterpret_cast<int*>(smem + 4 * TB), wave, lane);
+    const int t_begin = lo / 64;
+    const int t_end = hi > lo ? (hi + 63) / 64 : t_begin;
+
+    const bf16* kbase = p.qkv + b * T * ld + C + hd * D;
+    const bf16* vbase = kbase + C;
+    const bf16* mrow = nullptr;
+    if (MODE == MASK_DENSE) mrow = p.mask + b * p.mask_sb + hd * p.mask_sh + (int64_t)q_c * p.mask_sq;
+
+    f32x16 dq[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+    const float scale2 = p.scale * LOG2E;
+
+    TileStage<D, 64> sk, sv;
+    if (t_begin < t_end) {
+        sk.load(kbase + (int64_t)t_begin * 64 * ld, ld, T - t_begin * 64, tid);
+        sv.load(vbase + (int64_t)t_begin * 64 * ld, ld, T - t_begin * 64, tid);
+        sk.store(smem, tid);
+        sv.store(smem + TB, tid);
+    }
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int cur = (t - t_begin) & 1;
+        const bool more = t + 1 < t_end;
+        if (more) {
+            sk.load(kbase + (int64_t)(t + 1) * 64 * ld, ld, T - (t + 1) * 64, tid);
+            sv.load(vbase + (int64_t)(t + 1) * 64 * ld, ld, T - (t + 1) * 64, tid);
+        }
+        const char* Kt = smem + cur * 2 * TB;
+        const char* Vt = Kt + TB;
+        const int key0 = t * 64;
+
+        f32x16 sc[2], dp[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[0][r] = 0.f; sc[1][r] = 0.f; dp[0][r] = 0.f; dp[1][r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 0, s, lane), qf[s], sc[0], 0, 0, 0);
+            sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 32, s, lane), qf[s], sc[1], 0, 0, 0);
+            dp[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vt, 0, s, lane), dof[s], dp[0], 0, 0, 0);
+            dp[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vt, 32, s, lane), dof[s], dp[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + 32 * mt + acc_row(r, h);
+                float x = sc[mt][r] * scale2 - lse2;
+                if (MODE == MASK_DENSE) { if (key < T) x += bf2f(mrow[key]) * LOG2E; }
+                float pv = fast_exp2(x);
+                if (key < ks || key >= ke) pv = 0.f;
+                sc[mt][r] = pv * (dp[mt][r] - dl);   // dS^T (without the scale factor)
+            }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 dsf = pack8(sc[kk >> 1], 8 * (kk & 1));
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Kt, 16 * kk, dt, lane), dsf, dq[dt], 0, 0, 0);
+        }
+        if (more) {
+            sk.store(smem + (cur ^ 1) * 2 * TB, tid);
+            sv.store(smem + (cur ^ 1) * 2 * TB + TB, tid);
+        }
+        __syncthreads();
+    }
+
+    if (q_ok) {
+        bf16* drow = p.dqkv + (b * T + q_row) * ld + hd * D;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float g[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = dq[dt][4 * i + j] * p.scale;
+                const int d0 = 32 * dt + 8 * i + 4 * h;
+                rope_inv4(g, p.rope_cos, p.rope_sin, q_row, D, d0);
+                bf16x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = f2bf(g[j]);
+                *reinterpret_cast<bf16x4*>(drow + d0) = v;
+            }
+    }
+}
+
+// ==========================================================================================================
+// backward, part 2: dK and dV.  128 keys per workgroup (32 per wave), key on the lane; queries stream through
+// LDS in 32-row tiles (Q and dO, plus their lse/delta).
+//   S = Q K^T ; P = exp(S*scale + mask - lse) ; dP = dO V^T ; dS = P (dP - delta)
+//   dV^T += dO^T P ; dK^T += Q^T dS
+// ==========================================================================================================
+template <int D, int MODE>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int QB = 32 * 2 * D;  // bytes of one 32-row tile
+    constexpr int NS = D / 16, ND = D / 32;
+    constexpr int STAGE = 2 * QB + 256;  // Q tile, dO tile, 32 lse2 + 32 delta floats
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int hd = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int T = (int)p.T;
+    const int C = p.H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const int key = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool k_ok = key < T;
+    const int key_c = k_ok ? key : T - 1;
+
+    const bf16* kptr = p.qkv + (b * T + key_c) * ld + C + hd * D;
+    const bf16* vptr = kptr + C;
+    bf16x8 kf[NS], vf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        kf[s] = *reinterpret_cast<const bf16x8*>(kptr + 16 * s + 8 * h);
+        vf[s] = *reinterpret_cast<const bf16x8*>(vptr + 16 * s + 8 * h);
+    }
+    // by symmetry of the mask, the queries that see this key are the keys this position sees as a query
+    int qs = 0, qe = T;
+    if (MODE == MASK_RANGES) {
+        qs = max(p.key_ranges[(b * T + key_c) * 2], 0);
+        qe = min(p.key_ranges[(b * T + key_c) * 2 + 1], T);
+    }
+    if (!k_ok) { qs = 0; qe = 0; }
+    int lo = k_ok ? qs : T, hi = k_ok ? qe : 0;
+    if (MODE == MASK_RANGES) block_minmax(lo, hi, reinterpret_cast<int*>(smem + 2 * STAGE), wave, lane);
+    else { lo = 0; hi = T; }
+    const int t_begin = lo / 32;
+    const int t_end = hi > lo ? (hi + 31) / 32 : t_begin;
+
+    const bf16* qbase = p.qkv + b * T * ld + hd * D;
+    const bf16* dobase = p.d_o + b * T * C + hd * D;
+    const float* lse_b = p.lse_in + (b * p.H + hd) * T;
+    const float* del_b = p.delta + (b * p.H + hd) * T;
+    const bf16* mcol = nullptr;
+    if (MODE == MASK_DENSE) mcol = p.mask + b * p.mask_sb + hd * p.mask_sh + key_c;
+
+    f32x16 dk[ND], dv[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+    const float scale2 = p.scale * LOG2E;
+
+    TileStage<D, 32> sq, sd;
+    float st_l = 0.f;  // threads 0..31: lse2 of row tid ; 32..63: delta of row tid-32
+    auto load_stats = [&](int q0) {
+        if (tid < 64) {
+            const int q = q0 + (tid & 31);
+            float v = 0.f;
+            if (q < T) v = tid < 32 ? lse_b[q] * LOG2E : del_b[q];
+            else if (tid < 32) v = INFINITY;   // rows past T: p = exp2(x - inf) = 0
+            st_l = v;
+        }
+    };
+    auto store_stats = [&](char* stage) {
+        if (tid < 64) reinterpret_cast<float*>(stage + 2 * QB)[tid] = st_l;
+    };
+    if (t_begin < t_end) {
+        sq.load(qbase + (int64_t)t_begin * 32 * ld, ld, T - t_begin * 32, tid);
+        sd.load(dobase + (int64_t)t_begin * 32 * C, C, T - t_begin * 32, tid);
+        load_stats(t_begin * 32);
+        sq.store(smem, tid);
+        sd.store(smem + QB, tid);
+        store_stats(smem);
+    }
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int cur = (t - t_begin) & 1;
+        const bool more = t + 1 < t_end;
+        if (more) {
+            sq.load(qbase + (int64_t)(t + 1) * 32 * ld, ld, T - (t + 1) * 32, tid);
+            sd.load(dobase + (int64_t)(t + 1) * 32 * C, C, T - (t + 1) * 32, tid);
+            load_stats((t + 1) * 32);
+        }
+        const char* Qt = smem + cur * STAGE;
+        const char* Dt = Qt + QB;
+        const float* stats = reinterpret_cast<const float*>(Qt + 2 * QB);
+        const int q0 = t * 32;
+
+        f32x16 sc, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Qt, 0, s, lane), kf[s], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Dt, 0, s, lane), vf[s], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(stats + 8 * i + 4 * h);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(stats + 32 + 8 * i + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * i + j;
+                const int q = q0 + 8 * i + 4 * h + j;
+                float x = sc[r] * scale2 - l4[j];
+                if (MODE == MASK_DENSE) { if (q < T) x += bf2f(mcol[(int64_t)q * p.mask_sq]) * LOG2E; }
+                float pv = fast_exp2(x);
+                if (q < qs || q >= qe) pv = 0.f;
+                sc[r] = pv;
+                dp[r] = pv * (dp[r] - d4[j]);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 pf = pack8(sc, 8 * kk);
+            const bf16x8 dsf = pack8(dp, 8 * kk);
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Dt, 16 * kk, dt, lane), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Qt, 16 * kk, dt, lane), dsf, dk[dt], 0, 0, 0);
+            }
+        }
+        if (more) {
+            char* nxt = smem + (cur ^ 1) * STAGE;
+            sq.store(nxt, tid);
+            sd.store(nxt + QB, tid);
+            store_stats(nxt);
+        }
+        __syncthreads();
+    }
+
+    if (k_ok) {
+        bf16* dkrow = p.dqkv + (b * T + key) * ld + C + hd * D;
+        bf16* dvrow = dkrow + C;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d0 = 32 * dt + 8 * i + 4 * h;
+                float g[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = dk[dt][4 * i + j] * p.scale;
+                rope_inv4(g, p.rope_cos, p.rope_sin, key, D, d0);
+                bf16x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = f2bf(g[j]);
+                *reinterpret_cast<bf16x4*>(dkrow + d0) = v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = f2bf(dv[dt][4 * i + j]);
+                *reinterpret_cast<bf16x4*>(dvrow + d0) = v;
+            }
+    }
+}
+
+template <typename K>
+void set_smem(K kern, int bytes) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+int mask_mode(const int32_t* ranges, const obte_bf16* mask) { return ranges ? MASK_RANGES : (mask ? MASK_DENSE : MASK_NONE); }
+
+template <int D>
+int launch_fwd(const AttnParams& p, int mode, hipStream_t st) {
+    const int smem = 4 * 64 * 2 * D + 64;
+    const dim3 grid((unsigned)cdiv64(p.T, 128), p.H, (unsigned)p.B), block(256);
+#define GO(M)                                                                        \
+    do {                                                                             \
+        set_smem(attn_fwd_kernel<D, M>, smem);                                       \
+        hipLaunchKernelGGL((attn_fwd_kernel<D, M>), grid, block, smem, st, p);       \
+    } while (0)
+    if (mode == MASK_NONE) GO(MASK_NONE); else if (mode == MASK_RANGES) GO(MASK_RANGES); else GO(MASK_DENSE);
+#undef GO
+    OBTE_CHECK_LAUNCH("obte_attn_fwd");
+    return OBTE_OK;
+}
+
+template <int D>
+int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
+    {
+        const int64_t total = p.B * p.T * p.H * (D / 8);
+        hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, p.o_in, p.d_o, p.delta, p.B, p.T, p.H);
+        OBTE_CHECK_LAUNCH("obte_attn_bwd(delta)");
+    }
+    {
+        const int smem = 4 * 64 * 2 * D + 64;
+        const dim3 grid((unsigned)cdiv64(p.T, 128), p.H, (unsigned)p.B), block(256);
+#define GO(M)                                                                         \
+    do {                                                                              \
+        set_smem(attn_bwd_dq_kernel<D, M>, smem);                                     \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<D, M>), grid, block, smem, st, p);     \
+    } while (0)
+        if (mode == MASK_NONE) GO(MASK_NONE); else if (mode == MASK_RANGES) GO(MASK_RANGES); else GO(MASK_DENSE);
+#undef GO
+        OBTE_CHECK_LAUNCH("obte_attn_bwd(dq)");
+    }
+    {
+        const int smem = 2 * (2 * 32 * 2 * D + 256) + 64;
+        const dim3 grid((unsigned)cdiv64(p.T, 128), p.H, (unsigned)p.B), block(256);
+#define GO(M)                                                                          \
+    do {                                                                               \
+        set_smem(attn_bwd_dkdv_kernel<D, M>, smem);                                    \
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, M>), grid, block, smem, st, p);    \
+    } while (0)
+        if (mode == MASK_NONE) GO(MASK_NONE); else if (mode == MASK_RANGES) GO(MASK_RANGES); else GO(MASK_DENSE);
+#undef GO
+        OBTE_CHECK_LAUNCH("obte_attn_bwd(dkdv)");
+    }
+    return OBTE_OK;
+}
+
+}  // namespace
+
+static int check_common(const char* who, const void* qkv, int64_t B, int64_t T, int H, int D, const int32_t* ranges,
+                        const obte_bf16* mask) {
+    OBTE_REQUIRE(qkv, "%s: null qkv", who);
+    OBTE_REQUIRE(B > 0 && T > 0 && H > 0 && B < 65536 && H < 65536, "%s: bad B/T/H", who);
+    OBTE_REQUIRE(D == 64 || D == 128, "%s: head_dim must be 64 or 128 (got %d)", who, D);
+    OBTE_REQUIRE(T < (1 << 24), "%s: T too large", who);
+    OBTE_REQUIRE(!(ranges && mask), "%s: pass key_ranges or a dense mask, not both", who);
+    return OBTE_OK;
+}
+
+extern "C" int obte_attn_fwd(const obte_attn_fwd_args* a, obte_stream s) {
+    OBTE_REQUIRE(a, "obte_attn_fwd: null args");
+    int rc = check_common("obte_attn_fwd", a->qkv, a->B, a->T, a->n_head, a->head_dim, a->key_ranges, a->mask);
+    if (rc) return rc;
+    OBTE_REQUIRE(a->o && a->lse, "obte_attn_fwd: null output");
+    AttnParams p = {};
+    p.qkv = (const bf16*)a->qkv; p.o = (bf16*)a->o; p.lse = a->lse;
+    p.key_ranges = a->key_ranges; p.mask = (const bf16*)a->mask; p.mask_sb = a->mask_sb; p.mask_sh = a->mask_sh; p.mask_sq = a->mask_sq;
+    p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
+    const int mode = mask_mode(a->key_ranges, a->mask);
+    return a->head_dim == 128 ? launch_fwd<128>(p, mode, (hipStream_t)s) : launch_fwd<64>(p, mode, (hipStream_t)s);
+}
+
+extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
+    OBTE_REQUIRE(a, "obte_attn_bwd: null args");
+    int rc = check_common("obte_attn_bwd", a->qkv, a->B, a->T, a->n_head, a->head_dim, a->key_ranges, a->mask);
+    if (rc) return rc;
+    OBTE_REQUIRE(a->o && a->d_o && a->lse && a->delta && a->dqkv, "obte_attn_bwd: null pointer");
+    OBTE_REQUIRE((a->rope_cos == nullptr) == (a->rope_sin == nullptr), "obte_attn_bwd: pass both RoPE tables or neither");
+    AttnParams p = {};
+    p.qkv = (const bf16*)a->qkv; p.o_in = (const bf16*)a->o; p.d_o = (const bf16*)a->d_o; p.lse_in = a->lse; p.delta = a->delta;
+    p.dqkv = (bf16*)a->dqkv; p.rope_cos = a->rope_cos; p.rope_sin = a->rope_sin;
+    p.key_ranges = a->key_ranges; p.mask = (const bf16*)a->mask; p.mask_sb = a->mask_sb; p.mask_sh = a->mask_sh; p.mask_sq = a->mask_sq;
+    p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
+    const int mode = mask_mode(a->key_ranges, a->mask);
+    return a->head_dim == 128 ? launch_bwd<128>(p, mode, (hipStream_t)s) : launch_bwd<64>(p, mode, (hipStream_t)s);
+}

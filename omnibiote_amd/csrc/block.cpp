@@ -1,0 +1,148 @@
+// Host-side sequencing of one transformer block (training/model.py:170-181): a single C call enqueues every
+// kernel of the block's forward (or backward) on the caller's stream, so the Python layer crosses the
+// boundary once per block and pass.  Pre-LN residual wiring:
+//     x1 = x  + c_proj(attn(rope(c_attn(ln_1(x)))))        out = x1 + mlp.c_proj(gelu(c_fc(ln_2(x1))))
+// The residual adds live in the GEMM epilogues, GELU in c_fc's epilogue, GELU' in the mlp.c_proj dgrad epilogue,
+// the residual-gradient adds in the LayerNorm backward kernels, inverse RoPE in the attention backward epilogue.
+#include "common.h"
+
+namespace {
+
+inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
+
+struct ActLayout {
+    int64_t mean1, rstd1, h1, qkv, lse, y, x1, mean2, rstd2, h2, hpre, hact, total;
+    ActLayout(int64_t B, int64_t T, int C, int H) {
+        const int64_t M = B * T;
+        int64_t o = 0;
+        auto take = [&](int64_t bytes) { int64_t r = o; o += align256(bytes); return r; };
+        mean1 = take(M * 4); rstd1 = take(M * 4);
+        h1 = take(M * C * 2);
+        qkv = take(M * 3 * C * 2);
+        lse = take(B * H * T * 4);
+        y = take(M * C * 2);
+        x1 = take(M * C * 2);
+        mean2 = take(M * 4); rstd2 = take(M * 4);
+        h2 = take(M * C * 2);
+        hpre = take(M * 4 * C * 2);
+        hact = take(M * 4 * C * 2);
+        total = o;
+    }
+};
+
+struct WsLayout {
+    int64_t dhpre, dh, dx1, dyattn, dqkv, delta, lnws, total;
+    WsLayout(int64_t B, int64_t T, int C, int H) {
+        const int64_t M = B * T;
+        int64_t o = 0;
+        auto take = [&](int64_t bytes) { int64_t r = o; o += align256(bytes); return r; };
+        dhpre = take(M * 4 * C * 2);
+        dh = take(M * C * 2);       // dh2, later dh1
+        dx1 = take(M * C * 2);
+        dyattn = take(M * C * 2);
+        dqkv = take(M * 3 * C * 2);
+        delta = take(B * H * T * 4);
+        lnws = take((int64_t)obte_layernorm_bwd_ws_rows() * C * 4);
+        total = o;
+    }
+};
+
+int gemm(const obte_bf16* a, const obte_bf16* b, obte_bf16* d, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+         int ak, int bk, int epi, const obte_bf16* aux, obte_bf16* d2, obte_stream s) {
+    obte_gemm_args g = {};
+    g.a = a; g.b = b; g.d = d; g.aux = aux; g.d2 = d2;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldd = N;
+    g.a_kmajor = ak; g.b_kmajor = bk; g.epilogue = epi; g.alpha = 1.0f;
+    return obte_gemm_bf16(&g, s);
+}
+
+int check_desc(const char* who, const obte_block_desc* d) {
+    OBTE_REQUIRE(d, "%s: null descriptor", who);
+    OBTE_REQUIRE(d->B > 0 && d->T > 0 && d->n_head > 0 && d->n_embd > 0, "%s: bad shape", who);
+    OBTE_REQUIRE(d->n_embd % d->n_head == 0, "%s: n_embd %% n_head != 0", who);
+    const int hs = d->n_embd / d->n_head;
+    OBTE_REQUIRE(hs == 64 || hs == 128, "%s: head size %d unsupported by the HIP path (64 or 128)", who, hs);
+    OBTE_REQUIRE(d->n_embd % 64 == 0 && d->n_embd <= 4096, "%s: n_embd must be a multiple of 64 and <= 4096", who);
+    OBTE_REQUIRE(d->ln1_w && d->attn_w && d->proj_w && d->ln2_w && d->fc_w && d->mlp_w && d->rope_cos && d->rope_sin,
+                 "%s: null parameter", who);
+    return OBTE_OK;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_ != OBTE_OK) return rc_; } while (0)
+
+}  // namespace
+
+extern "C" int64_t obte_block_act_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head) {
+    return ActLayout(B, T, n_embd, n_head).total;
+}
+extern "C" int64_t obte_block_bwd_ws_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head) {
+    return WsLayout(B, T, n_embd, n_head).total;
+}
+
+extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte_bf16* y_out, void* act, obte_stream s) {
+    TRY(check_desc("obte_block_fwd", d));
+    OBTE_REQUIRE(x && y_out && act, "obte_block_fwd: null pointer");
+    const int C = d->n_embd, H = d->n_head, hs = C / H;
+    const int64_t M = d->B * d->T;
+    const ActLayout L(d->B, d->T, C, H);
+    char* A = (char*)act;
+    float *mean1 = (float*)(A + L.mean1), *rstd1 = (float*)(A + L.rstd1), *mean2 = (float*)(A + L.mean2), *rstd2 = (float*)(A + L.rstd2);
+    obte_bf16 *h1 = (obte_bf16*)(A + L.h1), *qkv = (obte_bf16*)(A + L.qkv), *yat = (obte_bf16*)(A + L.y), *x1 = (obte_bf16*)(A + L.x1),
+              *h2 = (obte_bf16*)(A + L.h2), *hpre = (obte_bf16*)(A + L.hpre), *hact = (obte_bf16*)(A + L.hact);
+    float* lse = (float*)(A + L.lse);
+
+    TRY(obte_layernorm_fwd(x, d->ln1_w, h1, mean1, rstd1, M, C, 1e-5f, s));
+    TRY(gemm(h1, d->attn_w, qkv, M, 3 * C, C, C, C, 1, 1, OBTE_EPI_NONE, nullptr, nullptr, s));
+    TRY(obte_rope_qk_inplace(qkv, d->rope_cos, d->rope_sin, d->B, d->T, H, hs, 0, s));
+    obte_attn_fwd_args af = {};
+    af.qkv = qkv; af.o = yat; af.lse = lse; af.key_ranges = d->key_ranges; af.mask = d->mask;
+    af.mask_sb = d->mask_sb; af.mask_sh = d->mask_sh; af.mask_sq = d->mask_sq;
+    af.B = d->B; af.T = d->T; af.n_head = H; af.head_dim = hs; af.scale = 8.0f / (float)C;  // model.py:119
+    TRY(obte_attn_fwd(&af, s));
+    TRY(gemm(yat, d->proj_w, x1, M, C, C, C, C, 1, 1, OBTE_EPI_ADD, x, nullptr, s));
+    TRY(obte_layernorm_fwd(x1, d->ln2_w, h2, mean2, rstd2, M, C, 1e-5f, s));
+    TRY(gemm(h2, d->fc_w, hpre, M, 4 * C, C, C, C, 1, 1, OBTE_EPI_GELU, nullptr, hact, s));
+    TRY(gemm(hact, d->mlp_w, y_out, M, C, 4 * C, 4 * C, 4 * C, 1, 1, OBTE_EPI_ADD, x1, nullptr, s));
+    return OBTE_OK;
+}
+
+extern "C" int obte_block_bwd(const obte_block_desc* d, const obte_bf16* x, const obte_bf16* dy, const void* act, void* ws,
+                              obte_bf16* dx, obte_bf16* dln1_w, obte_bf16* dattn_w, obte_bf16* dproj_w, obte_bf16* dln2_w,
+                              obte_bf16* dfc_w, obte_bf16* dmlp_w, obte_stream s) {
+    TRY(check_desc("obte_block_bwd", d));
+    OBTE_REQUIRE(x && dy && act && ws && dx && dln1_w && dattn_w && dproj_w && dln2_w && dfc_w && dmlp_w, "obte_block_bwd: null pointer");
+    const int C = d->n_embd, H = d->n_head, hs = C / H;
+    const int64_t M = d->B * d->T;
+    const ActLayout L(d->B, d->T, C, H);
+    const WsLayout W(d->B, d->T, C, H);
+    const char* A = (const char*)act;
+    char* S = (char*)ws;
+    const float *mean1 = (const float*)(A + L.mean1), *rstd1 = (const float*)(A + L.rstd1), *mean2 = (const float*)(A + L.mean2),
+                *rstd2 = (const float*)(A + L.rstd2), *lse = (const float*)(A + L.lse);
+    const obte_bf16 *h1 = (const obte_bf16*)(A + L.h1), *qkv = (const obte_bf16*)(A + L.qkv), *yat = (const obte_bf16*)(A + L.y),
+                    *x1 = (const obte_bf16*)(A + L.x1), *h2 = (const obte_bf16*)(A + L.h2), *hpre = (const obte_bf16*)(A + L.hpre),
+                    *hact = (const obte_bf16*)(A + L.hact);
+    obte_bf16 *dhpre = (obte_bf16*)(S + W.dhpre), *dh = (obte_bf16*)(S + W.dh), *dx1 = (obte_bf16*)(S + W.dx1),
+              *dyattn = (obte_bf16*)(S + W.dyattn), *dqkv = (obte_bf16*)(S + W.dqkv);
+    float *delta = (float*)(S + W.delta), *lnws = (float*)(S + W.lnws);
+
+    // MLP: out = x1 + hact W_mlp^T
+    TRY(gemm(dy, d->mlp_w, dhpre, M, 4 * C, C, C, 4 * C, 1, 0, OBTE_EPI_GELU_BWD, hpre, nullptr, s));          // dhpre = (dy W_mlp) * gelu'(hpre)
+    TRY(gemm(dy, hact, dmlp_w, C, 4 * C, M, C, 4 * C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s));               // dW_mlp = dy^T hact
+    TRY(gemm(dhpre, d->fc_w, dh, M, C, 4 * C, 4 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh2 = dhpre W_fc
+    TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, M, 4 * C, C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s));               // dW_fc = dhpre^T h2
+    TRY(obte_layernorm_bwd(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, lnws, M, C, s));                     // dx1 = dy + LN2'(dh2)
+    // attention: x1 = x + y W_proj^T
+    TRY(gemm(dx1, d->proj_w, dyattn, M, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));                  // dy_attn = dx1 W_proj
+    TRY(gemm(dx1, yat, dproj_w, C, C, M, C, C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s));                       // dW_proj = dx1^T y
+    obte_attn_bwd_args ab = {};
+    ab.qkv = qkv; ab.o = yat; ab.d_o = dyattn; ab.lse = lse; ab.delta = delta; ab.dqkv = dqkv;
+    ab.rope_cos = d->rope_cos; ab.rope_sin = d->rope_sin;
+    ab.key_ranges = d->key_ranges; ab.mask = d->mask; ab.mask_sb = d->mask_sb; ab.mask_sh = d->mask_sh; ab.mask_sq = d->mask_sq;
+    ab.B = d->B; ab.T = d->T; ab.n_head = H; ab.head_dim = hs; ab.scale = 8.0f / (float)C;
+    TRY(obte_attn_bwd(&ab, s));
+    TRY(gemm(dqkv, d->attn_w, dh, M, C, 3 * C, 3 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh1 = dqkv W_attn
+    TRY(gemm(dqkv, h1, dattn_w, 3 * C, C, M, 3 * C, C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s));               // dW_attn = dqkv^T h1
+    TRY(obte_layernorm_bwd(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, lnws, M, C, s));                      // dx = dx1 + LN1'(dh1)
+    return OBTE_OK;
+}

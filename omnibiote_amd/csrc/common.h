@@ -1,0 +1,85 @@
+// Shared device/host helpers for the gfx950 kernels of libomnibiote_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/omnibiote_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define WAVE 64
+
+// ---- error plumbing ------------------------------------------------------------------------------------
+void obte_set_error(const char* fmt, ...);
+#define OBTE_REQUIRE(cond, ...)                     \
+    do {                                            \
+        if (!(cond)) {                              \
+            obte_set_error(__VA_ARGS__);            \
+            return OBTE_EINVAL;                     \
+        }                                           \
+    } while (0)
+#define OBTE_CHECK_LAUNCH(name)                                                           \
+    do {                                                                                  \
+        hipError_t e_ = hipGetLastError();                                                \
+        if (e_ != hipSuccess) {                                                           \
+            obte_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));         \
+            return OBTE_ELAUNCH;                                                          \
+        }                                                                                 \
+    } while (0)
+
+// ---- bf16 <-> f32 -----------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+
+// ---- wave reductions (64 lanes) ----------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- buffer resources --------------------------------------------------------------------------------------
+// Raw buffer descriptor over [base, base+bytes): out-of-range lanes of a buffer load return 0 (and write 0 to
+// LDS for the LDS-DMA form).  bytes is clipped to 32 bits; callers keep per-tile offsets far below 4 GiB by
+// re-basing the descriptor at the tile origin.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int64_t bytes) {
+    uint32_t n = bytes <= 0 ? 0u : (bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+}
+
+// ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a
+// 4 x 16 block of 16-bit elements; lane i receives column i of the 4 rows (row q in element q).
+__device__ __forceinline__ bf16x4 lds_read_tr16(const void* lds_addr) {
+    s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_addr));
+    return __builtin_bit_cast(bf16x4, t);
+}
+
+__device__ __forceinline__ bf16x8 join8(bf16x4 a, bf16x4 b) {
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// gelu_erf with the reference's constant 1.41421 (training/model.py:25) and its derivative.
+#define OBTE_GELU_C 1.41421f
+__device__ __forceinline__ float gelu_ref(float x) { return x * 0.5f * (1.0f + erff(x / OBTE_GELU_C)); }
+__device__ __forceinline__ float gelu_ref_grad(float x) {
+    const float u = x / OBTE_GELU_C;
+    // d/dx [0.5 x (1 + erf(x/c))] = 0.5 (1 + erf(u)) + x * (1/(c*sqrt(pi))) * exp(-u^2)
+    return 0.5f * (1.0f + erff(u)) + x * (0.5641895835477563f / OBTE_GELU_C) * __expf(-u * u);
+}
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

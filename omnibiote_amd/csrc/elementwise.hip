@@ -1,0 +1,331 @@
+// HBM-bound pieces of the path: RoPE on packed qkv, token-embedding gather / deterministic scatter-add,
+// masked-LM cross entropy (forward + backward in one kernel), bf16 AdamW, sum of squares.
+// All use 16-byte accesses per lane and grid sizes that fill 256 CUs.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// RoPE (training/model.py:39-50).  qkv [rows, 3C]; the q and k thirds are rotated in place.
+// One thread = 8 consecutive elements = 4 (even, odd) pairs of one head.
+// ---------------------------------------------------------------------------------------------------------
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ qkv, const float* __restrict__ cos_t,
+                                                    const float* __restrict__ sin_t, int64_t rows, int64_t T, int C, int hs) {
+    const int chunks_per_row = 2 * C / 8;  // q and k thirds
+    const int64_t total = rows * chunks_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / chunks_per_row;
+        const int col = (int)(i % chunks_per_row) * 8;  // 0 .. 2C-8: q then k, contiguous in the packed row
+        const int d = col % hs;                         // C % hs == 0, so head boundaries align in both thirds
+        const int64_t t = row % T;
+        bf16* ptr = qkv + row * 3 * C + col;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(ptr);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(cos_t + t * (hs / 2) + d / 2);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(sin_t + t * (hs / 2) + d / 2);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xe = bf2f(v[2 * j]), xo = bf2f(v[2 * j + 1]);
+            const float sj = INVERSE ? -s[j] : s[j];
+            o[2 * j] = f2bf(xe * c[j] - xo * sj);
+            o[2 * j + 1] = f2bf(xe * sj + xo * c[j]);
+        }
+        *reinterpret_cast<bf16x8*>(ptr) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Embedding gather (training/model.py:241).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ idx, const bf16* __restrict__ wte,
+                                                         bf16* __restrict__ out, int64_t rows, int cols, int64_t vocab) {
+    const int cpr = cols / 8;
+    const int64_t total = rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cpr;
+        const int c = (int)(i % cpr) * 8;
+        int64_t tok = idx[r];
+        tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);  // memory safety; the host wrapper validates ids
+        *reinterpret_cast<bf16x8*>(out + r * cols + c) = *reinterpret_cast<const bf16x8*>(wte + tok * cols + c);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Embedding backward: dwte[tok] = sum of dout rows with that token, fp32, fixed order (bitwise reproducible).
+// The rows are visited in sorted-token order (order = stable argsort(idx)), cut into chunks of 32 positions.
+// Pass A (one workgroup per chunk) sums each run of equal tokens inside its chunk; runs that touch a chunk
+// edge shared with a neighbour holding the same token go to an fp32 slab (slot 0: the chunk's first run,
+// slot 1: its last run), all others are written to dwte directly.  Pass B: the chunk where a spanning run
+// starts adds the slabs of the following chunks in chunk order and writes the row.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int EMB_CHUNK = 32;
+
+__global__ __launch_bounds__(128) void embed_bwd_chunk_kernel(const int64_t* __restrict__ idx, const int32_t* __restrict__ order,
+                                                               const bf16* __restrict__ dout, bf16* __restrict__ dwte,
+                                                               float* __restrict__ slab, int64_t rows, int cols) {
+    __shared__ int32_t s_row[EMB_CHUNK];
+    __shared__ int64_t s_tok[EMB_CHUNK + 2];  // [0] = token before the chunk (or -1), [1..n] chunk, [n+1] = token after (or -1)
+    const int64_t c = blockIdx.x;
+    const int64_t p0 = c * EMB_CHUNK;
+    const int n = (int)((rows - p0) < EMB_CHUNK ? (rows - p0) : EMB_CHUNK);
+    if (threadIdx.x < n) {
+        const int32_t r = order[p0 + threadIdx.x];
+        s_row[threadIdx.x] = r;
+        s_tok[threadIdx.x + 1] = idx[r];
+    }
+    if (threadIdx.x == 64) s_tok[0] = p0 > 0 ? idx[order[p0 - 1]] : -1;
+    if (threadIdx.x == 65) s_tok[n + 1] = (p0 + n < rows) ? idx[order[p0 + n]] : -1;
+    __syncthreads();
+    const bool left_open = s_tok[0] == s_tok[1];
+    const bool right_open = s_tok[n + 1] == s_tok[n];
+    for (int col = threadIdx.x * 8; col < cols; col += 128 * 8) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        int seg_start = 0;
+        for (int i = 0; i < n; ++i) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(dout + (int64_t)s_row[i] * cols + col);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+            const bool seg_end = (i == n - 1) || (s_tok[i + 2] != s_tok[i + 1]);
+            if (seg_end) {
+                const bool is_first = seg_start == 0, is_last = i == n - 1;
+                if ((is_first && left_open) || (is_last && right_open)) {
+                    float* dst = slab + ((c * 2 + (is_first ? 0 : 1)) * cols + col);
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+                    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+                } else {
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
+                    *reinterpret_cast<bf16x8*>(dwte + s_tok[i + 1] * cols + col) = o;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+                seg_start = i + 1;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(128) void embed_bwd_span_kernel(const int64_t* __restrict__ idx, const int32_t* __restrict__ order,
+                                                              bf16* __restrict__ dwte, const float* __restrict__ slab,
+                                                              int64_t rows, int cols, int64_t nchunks) {
+    const int64_t c = blockIdx.x;
+    const int64_t p0 = c * EMB_CHUNK;
+    const int64_t p1 = (p0 + EMB_CHUNK < rows) ? p0 + EMB_CHUNK : rows;
+    const int64_t first = idx[order[p0]], last = idx[order[p1 - 1]];
+    const bool single = first == last;
+    const bool left_open = p0 > 0 && idx[order[p0 - 1]] == first;
+    const bool right_open = p1 < rows && idx[order[p1]] == last;
+    if (!right_open || (single && left_open)) return;  // no spanning run starts in this chunk
+    const int slot0 = single ? 0 : 1;
+    for (int col = threadIdx.x * 8; col < cols; col += 128 * 8) {
+        float acc[8];
+        const float* src = slab + ((c * 2 + slot0) * cols + col);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = src[j];
+        for (int64_t cc = c + 1; cc < nchunks; ++cc) {
+            const int64_t q0 = cc * EMB_CHUNK;
+            const int64_t q1 = (q0 + EMB_CHUNK < rows) ? q0 + EMB_CHUNK : rows;
+            if (idx[order[q0]] != last) break;
+            const float* s2 = slab + ((cc * 2) * cols + col);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += s2[j];
+            if (idx[order[q1 - 1]] != last) break;  // the run ended inside chunk cc
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
+        *reinterpret_cast<bf16x8*>(dwte + last * cols + col) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Masked-LM cross entropy, forward + backward (training/train_encoder.py:301-305).  One workgroup per row.
+// Rows outside the MLM mask contribute exactly zero loss and zero gradient in the reference (loss *= mask),
+// so their logits are not read; their dlogits row is written as zeros.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void masked_ce_kernel(const bf16* __restrict__ logits, const int64_t* __restrict__ target,
+                                                         const uint8_t* __restrict__ mlm_mask, const float* __restrict__ grad_scale,
+                                                         float row_scale, float* __restrict__ row_loss, bf16* __restrict__ dlogits,
+                                                         int64_t vocab) {
+    __shared__ float red[8];
+    const int64_t r = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bf16* drow = dlogits + r * vocab;
+    if (!mlm_mask[r]) {
+        const bf16x8 z = {};
+        for (int64_t c = (int64_t)threadIdx.x * 8; c < vocab; c += 256 * 8) *reinterpret_cast<bf16x8*>(drow + c) = z;
+        if (threadIdx.x == 0 && row_loss) row_loss[r] = 0.f;
+        return;
+    }
+    const bf16* lrow = logits + r * vocab;
+    // pass 1: online max / sum-exp (per thread), then combine
+    float m = -INFINITY, l = 0.f;
+    for (int64_t c = (int64_t)threadIdx.x * 8; c < vocab; c += 256 * 8) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(lrow + c);
+        float mx = bf2f(v[0]);
+#pragma unroll
+        for (int j = 1; j < 8; ++j) mx = fmaxf(mx, bf2f(v[j]));
+        const float mn = fmaxf(m, mx);
+        float add = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) add += __expf(bf2f(v[j]) - mn);
+        l = l * __expf(m - mn) + add;
+        m = mn;
+    }
+    const float wm = wave_max(m);
+    l = wave_sum(l * __expf(m - wm));
+    if (lane == 0) { red[wave] = wm; red[4 + wave] = l; }
+    __syncthreads();
+    const float bm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float bl = red[4] * __expf(red[0] - bm) + red[5] * __expf(red[1] - bm) + red[6] * __expf(red[2] - bm) + red[7] * __expf(red[3] - bm);
+    const float lse = bm + __logf(bl);
+    int64_t tgt = target[r];
+    tgt = tgt < 0 ? 0 : (tgt >= vocab ? vocab - 1 : tgt);
+    if (threadIdx.x == 0 && row_loss) row_loss[r] = (lse - bf2f(lrow[tgt])) * row_scale;
+    // pass 2 (row is L2-resident): gradient
+    const float gs = row_scale * grad_scale[0];
+    for (int64_t c = (int64_t)threadIdx.x * 8; c < vocab; c += 256 * 8) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(lrow + c);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float p = __expf(bf2f(v[j]) - lse);
+            if (c + j == tgt) p -= 1.0f;
+            o[j] = f2bf(p * gs);
+        }
+        *reinterpret_cast<bf16x8*>(drow + c) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// AdamW in the reference's pure-bf16 regime (train_encoder.py:170,199): p, g, m, v all bf16; the update is
+// evaluated in fp32 per element and each state is rounded once.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(bf16* __restrict__ p, const bf16* __restrict__ g, bf16* __restrict__ m,
+                                                     bf16* __restrict__ v, int64_t n8, float lr, float b1, float b2, float eps,
+                                                     float wd, float bc1, float bc2_sqrt, const float* __restrict__ clip) {
+    const float cc = clip ? clip[0] : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        bf16x8 pp = reinterpret_cast<bf16x8*>(p)[i], mm = reinterpret_cast<bf16x8*>(m)[i], vv = reinterpret_cast<bf16x8*>(v)[i];
+        const bf16x8 gg = reinterpret_cast<const bf16x8*>(g)[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gj = bf2f(gg[j]) * cc;
+            float pj = bf2f(pp[j]) * (1.0f - lr * wd);
+            const float mj = bf2f(mm[j]) + (gj - bf2f(mm[j])) * (1.0f - b1);
+            const float vj = bf2f(vv[j]) * b2 + gj * gj * (1.0f - b2);
+            const float denom = sqrtf(vj) / bc2_sqrt + eps;
+            pj -= (lr / bc1) * (mj / denom);
+            pp[j] = f2bf(pj); mm[j] = f2bf(mj); vv[j] = f2bf(vj);
+        }
+        reinterpret_cast<bf16x8*>(p)[i] = pp; reinterpret_cast<bf16x8*>(m)[i] = mm; reinterpret_cast<bf16x8*>(v)[i] = vv;
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const bf16* __restrict__ g, int64_t n8, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const bf16x8 v = reinterpret_cast<const bf16x8*>(g)[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = bf2f(v[j]); s += f * f; }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+inline unsigned stream_grid(int64_t work_items, int per_block) {
+    int64_t b = cdiv64(work_items, per_block);
+    return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace
+
+extern "C" int obte_rope_qk_inplace(obte_bf16* qkv, const float* cos_t, const float* sin_t, int64_t B, int64_t T,
+                                    int n_head, int head_dim, int inverse, obte_stream s) {
+    OBTE_REQUIRE(qkv && cos_t && sin_t, "obte_rope_qk_inplace: null pointer");
+    OBTE_REQUIRE(B > 0 && T > 0 && n_head > 0 && head_dim % 8 == 0, "obte_rope_qk_inplace: head_dim must be a multiple of 8");
+    const int C = n_head * head_dim;
+    const int64_t rows = B * T, total = rows * (2 * C / 8);
+    hipStream_t st = (hipStream_t)s;
+    if (inverse)
+        hipLaunchKernelGGL((rope_kernel<true>), dim3(stream_grid(total, 256)), dim3(256), 0, st, (bf16*)qkv, cos_t, sin_t, rows, T, C, head_dim);
+    else
+        hipLaunchKernelGGL((rope_kernel<false>), dim3(stream_grid(total, 256)), dim3(256), 0, st, (bf16*)qkv, cos_t, sin_t, rows, T, C, head_dim);
+    OBTE_CHECK_LAUNCH("obte_rope_qk_inplace");
+    return OBTE_OK;
+}
+
+extern "C" int obte_embedding_fwd(const int64_t* idx, const obte_bf16* wte, obte_bf16* out, int64_t rows, int cols,
+                                  int64_t vocab, obte_stream s) {
+    OBTE_REQUIRE(idx && wte && out, "obte_embedding_fwd: null pointer");
+    OBTE_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && vocab > 0, "obte_embedding_fwd: cols must be a multiple of 8");
+    if (rows == 0) return OBTE_OK;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(stream_grid(rows * (cols / 8), 256)), dim3(256), 0, (hipStream_t)s, idx,
+                       (const bf16*)wte, (bf16*)out, rows, cols, vocab);
+    OBTE_CHECK_LAUNCH("obte_embedding_fwd");
+    return OBTE_OK;
+}
+
+extern "C" int64_t obte_embedding_bwd_ws_bytes(int64_t rows, int cols) {
+    return cdiv64(rows, EMB_CHUNK) * 2 * (int64_t)cols * (int64_t)sizeof(float);
+}
+
+extern "C" int obte_embedding_bwd(const int64_t* idx, const int32_t* order, const obte_bf16* dout, obte_bf16* dwte,
+                                  void* ws, int64_t rows, int cols, int64_t vocab, obte_stream s) {
+    OBTE_REQUIRE(idx && order && dout && dwte && ws, "obte_embedding_bwd: null pointer");
+    OBTE_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && vocab > 0, "obte_embedding_bwd: bad shape");
+    OBTE_REQUIRE(rows < (1ll << 31), "obte_embedding_bwd: too many rows");
+    hipStream_t st = (hipStream_t)s;
+    if (hipMemsetAsync(dwte, 0, (size_t)vocab * cols * sizeof(obte_bf16), st) != hipSuccess) {
+        obte_set_error("obte_embedding_bwd: memset failed");
+        return OBTE_ELAUNCH;
+    }
+    const int64_t nchunks = cdiv64(rows, EMB_CHUNK);
+    hipLaunchKernelGGL(embed_bwd_chunk_kernel, dim3((unsigned)nchunks), dim3(128), 0, st, idx, order, (const bf16*)dout,
+                       (bf16*)dwte, (float*)ws, rows, cols);
+    OBTE_CHECK_LAUNCH("obte_embedding_bwd(chunk)");
+    hipLaunchKernelGGL(embed_bwd_span_kernel, dim3((unsigned)nchunks), dim3(128), 0, st, idx, order, (bf16*)dwte,
+                       (const float*)ws, rows, cols, nchunks);
+    OBTE_CHECK_LAUNCH("obte_embedding_bwd(span)");
+    return OBTE_OK;
+}
+
+extern "C" int obte_masked_ce_fwd_bwd(const obte_bf16* logits, const int64_t* target, const uint8_t* mlm_mask,
+                                      const float* grad_scale, float row_scale, float* loss_sum, float* row_loss,
+                                      obte_bf16* dlogits, int64_t rows, int64_t vocab, obte_stream s) {
+    (void)loss_sum;
+    OBTE_REQUIRE(logits && target && mlm_mask && grad_scale && dlogits, "obte_masked_ce_fwd_bwd: null pointer");
+    OBTE_REQUIRE(rows > 0 && rows < (1ll << 31) && vocab > 0 && vocab % 8 == 0, "obte_masked_ce_fwd_bwd: vocab must be a multiple of 8");
+    hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)s, (const bf16*)logits, target, mlm_mask,
+                       grad_scale, row_scale, row_loss, (bf16*)dlogits, vocab);
+    OBTE_CHECK_LAUNCH("obte_masked_ce_fwd_bwd");
+    return OBTE_OK;
+}
+
+extern "C" int obte_adamw_bf16(obte_bf16* p, const obte_bf16* g, obte_bf16* m, obte_bf16* v, int64_t n, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                               const float* clip_coef, obte_stream s) {
+    OBTE_REQUIRE(p && g && m && v, "obte_adamw_bf16: null pointer");
+    OBTE_REQUIRE(n > 0 && n % 8 == 0 && step >= 1, "obte_adamw_bf16: n must be a positive multiple of 8, step >= 1");
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(stream_grid(n / 8, 256)), dim3(256), 0, (hipStream_t)s, (bf16*)p, (const bf16*)g,
+                       (bf16*)m, (bf16*)v, n / 8, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, clip_coef);
+    OBTE_CHECK_LAUNCH("obte_adamw_bf16");
+    return OBTE_OK;
+}
+
+extern "C" int obte_sumsq_bf16(const obte_bf16* g, int64_t n, float* out, obte_stream s) {
+    OBTE_REQUIRE(g && out, "obte_sumsq_bf16: null pointer");
+    OBTE_REQUIRE(n > 0 && n % 8 == 0, "obte_sumsq_bf16: n must be a positive multiple of 8");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(stream_grid(n / 8, 256)), dim3(256), 0, (hipStream_t)s, (const bf16*)g, n / 8, out);
+    OBTE_CHECK_LAUNCH("obte_sumsq_bf16");
+    return OBTE_OK;
+}

@@ -1,0 +1,209 @@
+// Weight-only LayerNorm forward/backward (training/model.py:63-72 -> F.layer_norm(x, (C,), w, None, 1e-5)).
+// HBM-bound: one wave per row, 16-B loads/stores, the row is held in registers between the statistics passes
+// so each element is read once and written once.  Algorithmic bytes per row: fwd 4*C (2 read + 2 written),
+// bwd 8*C (dy, x, [dresid] read; dx written) + the dw partials.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_BWD_MAX_BLOCKS = 1024;
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
+                                                      bf16* __restrict__ y, float* __restrict__ mean,
+                                                      float* __restrict__ rstd, int64_t rows, int cols, float eps) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const bf16* xr = x + row * cols;
+    float v[NCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < cols) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(xr + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] = bf2f(t[j]); sum += v[i][j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+    }
+    const float mu = wave_sum(sum) / (float)cols;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < cols) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mu; sq += d * d; }
+        }
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(sq) / (float)cols + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    bf16* yr = y + row * cols;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < cols) {
+            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2bf((v[i][j] - mu) * rs * bf2f(wv[j]));
+            *reinterpret_cast<bf16x8*>(yr + c) = o;
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*w ; partial dw per workgroup into ws[block][cols].
+template <int NCH, bool HAS_RESID>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                      const bf16* __restrict__ w, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const bf16* __restrict__ dresid,
+                                                      bf16* __restrict__ dx, float* __restrict__ ws, int64_t rows, int cols) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = reinterpret_cast<float*>(smem_raw);  // [4][cols]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float wv[NCH][8], dwacc[NCH][8];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        bf16x8 t = {};
+        if (c < cols) t = *reinterpret_cast<const bf16x8*>(w + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { wv[i][j] = bf2f(t[j]); dwacc[i][j] = 0.f; }
+    }
+    const float inv_c = 1.0f / (float)cols;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[NCH][8], g[NCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 8;
+            if (c < cols) {
+                const bf16x8 tx = *reinterpret_cast<const bf16x8*>(x + row * cols + c);
+                const bf16x8 td = *reinterpret_cast<const bf16x8*>(dy + row * cols + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = bf2f(td[j]);
+                    xh[i][j] = (bf2f(tx[j]) - mu) * rs;
+                    g[i][j] = d * wv[i][j];
+                    dwacc[i][j] += d * xh[i][j];
+                    s1 += g[i][j];
+                    s2 += g[i][j] * xh[i][j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { xh[i][j] = 0.f; g[i][j] = 0.f; }
+            }
+        }
+        s1 = wave_sum(s1) * inv_c;
+        s2 = wave_sum(s2) * inv_c;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 8;
+            if (c < cols) {
+                bf16x8 o;
+                bf16x8 r = {};
+                if (HAS_RESID) r = *reinterpret_cast<const bf16x8*>(dresid + row * cols + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float d = rs * (g[i][j] - s1 - xh[i][j] * s2);
+                    if (HAS_RESID) d += bf2f(r[j]);
+                    o[j] = f2bf(d);
+                }
+                *reinterpret_cast<bf16x8*>(dx + row * cols + c) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < cols) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wave * cols + c + j] = dwacc[i][j];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += 256)
+        ws[(int64_t)blockIdx.x * cols + c] = red[c] + red[cols + c] + red[2 * cols + c] + red[3 * cols + c];
+}
+
+__global__ __launch_bounds__(256) void ln_dw_reduce_kernel(const float* __restrict__ ws, bf16* __restrict__ dw, int nblk, int cols) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (c < cols)
+        for (int b = part; b < nblk; b += 4) s += ws[(int64_t)b * cols + c];
+    red[part][cl] = s;
+    __syncthreads();
+    if (part == 0 && c < cols) dw[c] = f2bf(red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+int nch_for(int cols) {
+    const int chunks = (cols / 8 + 63) / 64;
+    if (chunks <= 1) return 1;
+    if (chunks <= 2) return 2;
+    if (chunks <= 4) return 4;
+    if (chunks <= 8) return 8;
+    return 16;
+}
+
+}  // namespace
+
+extern "C" int obte_layernorm_bwd_ws_rows(void) { return LN_BWD_MAX_BLOCKS; }
+
+extern "C" int obte_layernorm_fwd(const obte_bf16* x, const obte_bf16* w, obte_bf16* y, float* mean, float* rstd,
+                                  int64_t rows, int cols, float eps, obte_stream s) {
+    OBTE_REQUIRE(x && w && y && mean && rstd, "obte_layernorm_fwd: null pointer");
+    OBTE_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 4096, "obte_layernorm_fwd: cols must be a multiple of 8 and <= 4096 (got %d)", cols);
+    if (rows == 0) return OBTE_OK;
+    const dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
+    hipStream_t st = (hipStream_t)s;
+#define LN_FWD(N) hipLaunchKernelGGL((ln_fwd_kernel<N>), grid, block, 0, st, (const bf16*)x, (const bf16*)w, (bf16*)y, mean, rstd, rows, cols, eps)
+    switch (nch_for(cols)) {
+        case 1: LN_FWD(1); break;
+        case 2: LN_FWD(2); break;
+        case 4: LN_FWD(4); break;
+        case 8: LN_FWD(8); break;
+        default: LN_FWD(16); break;
+    }
+#undef LN_FWD
+    OBTE_CHECK_LAUNCH("obte_layernorm_fwd");
+    return OBTE_OK;
+}
+
+extern "C" int obte_layernorm_bwd(const obte_bf16* dy, const obte_bf16* x, const obte_bf16* w, const float* mean,
+                                  const float* rstd, const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dw, float* ws,
+                                  int64_t rows, int cols, obte_stream s) {
+    OBTE_REQUIRE(dy && x && w && mean && rstd && dx && dw && ws, "obte_layernorm_bwd: null pointer");
+    OBTE_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 4096, "obte_layernorm_bwd: bad shape rows=%lld cols=%d", (long long)rows, cols);
+    const int nblk = (int)(cdiv64(rows, 4) < LN_BWD_MAX_BLOCKS ? cdiv64(rows, 4) : LN_BWD_MAX_BLOCKS);
+    const dim3 grid(nblk), block(256);
+    const size_t smem = (size_t)4 * cols * sizeof(float);
+    hipStream_t st = (hipStream_t)s;
+#define LN_BWD(N)                                                                                                           \
+    do {                                                                                                                    \
+        if (dresid)                                                                                                         \
+            hipLaunchKernelGGL((ln_bwd_kernel<N, true>), grid, block, smem, st, (const bf16*)dy, (const bf16*)x, (const bf16*)w, \
+                               mean, rstd, (const bf16*)dresid, (bf16*)dx, ws, rows, cols);                                 \
+        else                                                                                                                \
+            hipLaunchKernelGGL((ln_bwd_kernel<N, false>), grid, block, smem, st, (const bf16*)dy, (const bf16*)x, (const bf16*)w, \
+                               mean, rstd, (const bf16*)nullptr, (bf16*)dx, ws, rows, cols);                                \
+    } while (0)
+    switch (nch_for(cols)) {
+        case 1: LN_BWD(1); break;
+        case 2: LN_BWD(2); break;
+        case 4: LN_BWD(4); break;
+        case 8: LN_BWD(8); break;
+        default: LN_BWD(16); break;
+    }
+#undef LN_BWD
+    OBTE_CHECK_LAUNCH("obte_layernorm_bwd");
+    hipLaunchKernelGGL(ln_dw_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, (const float*)ws, (bf16*)dw, nblk, cols);
+    OBTE_CHECK_LAUNCH("obte_layernorm_bwd(dw reduce)");
+    return OBTE_OK;
+}

@@ -1,0 +1,375 @@
+"""Drop-in replacement for the reference's ``training/model.py`` class surface, computed by hand-written HIP.
+
+Same names, constructor RNG order, attribute tree and state_dict keys as the reference
+(training/model.py:63-277), so ``train_encoder.py`` and the eval scripts can ``from model import OmniBioTA,
+OmniBioTAConfig`` unchanged (``training/model.py`` in this repo re-exports this module).  What differs is what
+runs underneath: every block forward/backward is one call into ``libomnibiote_hip.so``.
+
+Contract notes (each mirrors a reference behaviour):
+  * ``OmniBioTAConfig`` has no ``flash`` field; callers assign it ad hoc (train_encoder.py:152).  Reading it
+    when absent raises AttributeError exactly like the reference.
+  * ``freqs_cis`` is a persistent complex64 buffer.  ``module.to(torch.bfloat16)`` turns it into a real bf16
+    tensor holding cos only (PyTorch semantics), and the reference then *scales* pairs instead of rotating
+    them.  This module reproduces both modes from the buffer's dtype: complex -> rotation, real -> cos-only.
+  * softmax scale is 8 / n_embd (model.py:119), GELU uses erf(x / 1.41421) (model.py:25), LayerNorm eps 1e-5.
+  * The HIP path computes in bf16 with fp32 accumulation — the regime the reference trains and evaluates in
+    (train_encoder.py:21,170).  Parameters must be bf16 on a GPU at forward time; anything else raises.
+  * dropout: only p == 0 (or eval mode) is implemented in this round; p > 0 in training raises
+    NotImplementedError rather than silently training without dropout.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch.utils.checkpoint import checkpoint
+
+from . import _lib as L
+from . import ops
+
+try:  # the real package, if the environment has it (README.md:16 pins mup==1.0.0)
+    from mup import MuReadout as _MuReadoutBase  # type: ignore
+    _HAVE_MUP = True
+except Exception:  # not installed here: restated semantics, see mup_compat.py
+    from .mup_compat import MuReadout as _MuReadoutBase
+    _HAVE_MUP = False
+
+
+# ------------------------------------------------------------------------------------------------ helper functions
+def fused_gelu(x: torch.Tensor) -> torch.Tensor:
+    """x * 0.5 * (1 + erf(x / 1.41421))  (model.py:23-25).  Tensor-level helper kept for API parity; inside the
+    block the same formula runs in the c_fc GEMM epilogue."""
+    return x * 0.5 * (1.0 + torch.erf(x / 1.41421))
+
+
+def precompute_freqs_cis(dim: int, end: int, theta: float = 10000.0) -> torch.Tensor:
+    """complex64 (end, dim/2) table of unit phasors exp(i t theta^(-2j/dim))  (model.py:53-61)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim))
+    angles = torch.outer(torch.arange(end), inv_freq).float()
+    return torch.polar(torch.ones_like(angles), angles)
+
+
+def reshape_for_broadcast(freqs_cis: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """(model.py:28-35) view the first x.shape[1] rows of the table as (1, T, 1, hs/2)."""
+    assert freqs_cis.shape[-1] == x.shape[-1]
+    f = freqs_cis[: x.shape[1]]
+    return f.view(*[d if i in (1, x.ndim - 1) else 1 for i, d in enumerate(x.shape)])
+
+
+def rope_tables(freqs_cis: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """fp32 (cos, sin) tables the kernels consume.  A real-valued buffer (after ``.to(bfloat16)``) yields
+    sin = 0: the reference's degenerate cos-only scaling, including the bf16 rounding of cos."""
+    if freqs_cis.is_complex():
+        return freqs_cis.real.float().contiguous(), freqs_cis.imag.float().contiguous()
+    c = freqs_cis.float().contiguous()
+    return c, torch.zeros_like(c)
+
+
+def apply_rotary_emb(xq: torch.Tensor, xk: torch.Tensor, freqs_cis: torch.Tensor):
+    """(model.py:39-50) on (B, T, H, hs) tensors; runs the HIP RoPE kernel on a packed copy."""
+    B, T, H, hs = xq.shape
+    cos, sin = rope_tables(freqs_cis.to(xq.device))
+    packed = torch.cat([xq.reshape(B, T, H * hs), xk.reshape(B, T, H * hs), torch.zeros_like(xq).reshape(B, T, H * hs)], dim=2)
+    packed = packed.to(torch.bfloat16).contiguous()
+    ops.rope_qk_(packed, cos, sin, B, T, H, hs)
+    q, k, _ = packed.split(H * hs, dim=2)
+    return q.reshape(B, T, H, hs).type_as(xq), k.reshape(B, T, H, hs).type_as(xk)
+
+
+def _require_hip(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: the OmniBioTE MI355X path needs GPU tensors (got {t.device}); there is no CPU "
+                           "fallback in this package. Move the model and inputs to the GPU, e.g. m.to(torch.bfloat16).to('cuda').")
+    if t.dtype != torch.bfloat16:
+        raise RuntimeError(f"{what}: parameters/activations must be torch.bfloat16 (the reference trains and evaluates "
+                           f"in bf16: train_encoder.py:21,170); got {t.dtype}. Call model.to(torch.bfloat16).")
+    L.lib()  # raises HipLibraryError if the shared library is missing
+
+
+# ------------------------------------------------------------------------------------------------- autograd glue
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        y, mean, rstd = ops.layernorm_fwd(x.contiguous(), w)
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dx, dw = ops.layernorm_bwd(dy.contiguous(), x.contiguous(), w, mean, rstd)
+        return dx, dw
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = alpha * x W^T (bias-free nn.Linear; alpha = 1/width_mult for the muP readout)."""
+
+    @staticmethod
+    def forward(ctx, x, w, alpha):
+        ctx.save_for_backward(x, w)
+        ctx.alpha = alpha
+        x2 = x.reshape(-1, x.shape[-1])
+        y = ops.linear_fwd(x2.contiguous(), w, alpha=alpha)
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_dgrad(dy2, w, alpha=ctx.alpha).view_as(x)
+        if ctx.needs_input_grad[1]:
+            dw = ops.linear_wgrad(dy2, x2, alpha=ctx.alpha)
+        return dx, dw, None
+
+
+class _EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, idx, wte):
+        ctx.save_for_backward(idx)
+        ctx.vocab = wte.shape[0]
+        return ops.embedding_fwd(idx.contiguous(), wte)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        return None, ops.embedding_bwd(idx.contiguous(), dout.contiguous(), ctx.vocab)
+
+
+class _BlockFn(torch.autograd.Function):
+    """One pre-LN transformer block (model.py:170-181): a single C call per pass."""
+
+    @staticmethod
+    def forward(ctx, x, ln1, attn_w, proj_w, ln2, fc_w, mlp_w, rope_cos, rope_sin, n_head, mask):
+        x = x.contiguous()
+        params = (ln1, attn_w, proj_w, ln2, fc_w, mlp_w)
+        y, act = ops.block_fwd(x, params, (rope_cos, rope_sin), n_head, mask)
+        ctx.save_for_backward(x, act, rope_cos, rope_sin, *params)
+        ctx.n_head, ctx.mask = n_head, mask
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, act, rope_cos, rope_sin, *params = ctx.saved_tensors
+        dx, grads = ops.block_bwd(x, dy.contiguous(), act, tuple(params), (rope_cos, rope_sin), ctx.n_head, ctx.mask)
+        return (dx, *grads, None, None, None, None)
+
+
+class _AttnCoreFn(torch.autograd.Function):
+    """rope + fused attention on a packed qkv activation (used by the standalone SelfAttention module)."""
+
+    @staticmethod
+    def forward(ctx, qkv, rope_cos, rope_sin, n_head, scale, mask):
+        B, T, C3 = qkv.shape
+        hs = C3 // 3 // n_head
+        qkv = qkv.contiguous().clone()
+        ops.rope_qk_(qkv, rope_cos, rope_sin, B, T, n_head, hs)
+        o, lse = ops.attn_fwd(qkv, B, T, n_head, hs, scale, mask)
+        ctx.save_for_backward(qkv, o, lse, rope_cos, rope_sin)
+        ctx.meta = (B, T, n_head, hs, scale, mask)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qkv, o, lse, rope_cos, rope_sin = ctx.saved_tensors
+        B, T, H, hs, scale, mask = ctx.meta
+        dqkv = ops.attn_bwd(qkv, o, d_o.contiguous(), lse, B, T, H, hs, scale, mask, rope=(rope_cos, rope_sin))
+        return dqkv, None, None, None, None, None
+
+
+def _check_dropout(module: nn.Module, p: float) -> None:
+    if module.training and p > 0.0:
+        raise NotImplementedError(
+            f"dropout={p} in training mode is not implemented by the HIP path yet (round 1 covers the reference's "
+            "--dropout 0 regime). Set config.dropout = 0 or call model.eval().")
+
+
+# ------------------------------------------------------------------------------------------------------- modules
+class LayerNorm(nn.Module):
+    """LayerNorm with optional bias (model.py:63-72).  The reference always builds it with bias=False."""
+
+    def __init__(self, ndim, bias):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(ndim))
+        self.bias = nn.Parameter(torch.zeros(ndim)) if bias else None
+
+    def forward(self, input):
+        if self.bias is not None:
+            raise NotImplementedError("bias=True is not used by the reference (model.py:191) and not implemented")
+        _require_hip(input, "LayerNorm")
+        return _LayerNormFn.apply(input, self.weight)
+
+
+class SelfAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        assert config.n_embd % config.n_head == 0
+        self.c_attn = nn.Linear(config.n_embd, 3 * config.n_embd, bias=config.bias)
+        self.c_proj = nn.Linear(config.n_embd, config.n_embd, bias=config.bias)
+        self.attn_dropout = nn.Dropout(config.dropout, inplace=True)
+        self.resid_dropout = nn.Dropout(config.dropout, inplace=True)
+        self.n_head = config.n_head
+        self.n_embd = config.n_embd
+        self.dropout = config.dropout
+        self.autoregressive = config.autoregressive
+        self.flash = config.flash  # AttributeError if the caller never set it, as in the reference (model.py:89)
+        self.register_buffer("freqs_cis", precompute_freqs_cis(self.n_embd // self.n_head, config.block_size))
+        if not self.flash:
+            # state_dict parity with the reference's non-flash modules (model.py:92-96); the buffer is unused here:
+            # both settings run the same fused kernel, which is exact attention either way.
+            self.register_buffer("bias", torch.tril(torch.ones(config.block_size, config.block_size))
+                                 .view(1, 1, config.block_size, config.block_size))
+        self._rope_key = None
+        self._rope_val = None
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_rope_key"] = None
+        state["_rope_val"] = None
+        return state
+
+    def rope(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """fp32 cos/sin tables derived from the (possibly dtype-cast) ``freqs_cis`` buffer, cached."""
+        f = self.freqs_cis
+        key = (f.data_ptr(), f.dtype, f.device, f._version)
+        if self._rope_key != key:
+            self._rope_val = rope_tables(f)
+            self._rope_key = key
+        return self._rope_val
+
+    def forward(self, x, attn_mask=None):
+        _require_hip(x, "SelfAttention")
+        _check_dropout(self, self.dropout)
+        if self.autoregressive:
+            raise NotImplementedError("autoregressive=True is not used by the encoder (model.py:192) and not implemented")
+        B, T, C = x.size()
+        mask = ops.MaskSpec.from_user(attn_mask, B, T, self.n_head, x.device)
+        cos, sin = self.rope()
+        qkv = _LinearFn.apply(x, self.c_attn.weight, 1.0)
+        y = _AttnCoreFn.apply(qkv, cos, sin, self.n_head, 8.0 / self.n_embd, mask)
+        return _LinearFn.apply(y, self.c_proj.weight, 1.0)
+
+
+class MLP(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.c_fc = nn.Linear(config.n_embd, 4 * config.n_embd, bias=config.bias)
+        self.c_proj = nn.Linear(4 * config.n_embd, config.n_embd, bias=config.bias)
+        self.dropout = nn.Dropout(config.dropout, inplace=True)
+
+    def forward(self, x):
+        _require_hip(x, "MLP")
+        _check_dropout(self, self.dropout.p)
+        h = _LinearFn.apply(x, self.c_fc.weight, 1.0)
+        return _LinearFn.apply(fused_gelu(h.float()).to(h.dtype), self.c_proj.weight, 1.0)
+
+
+class Block(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.ln_1 = LayerNorm(config.n_embd, bias=config.bias)
+        self.attn = SelfAttention(config)
+        self.ln_2 = LayerNorm(config.n_embd, bias=config.bias)
+        self.mlp = MLP(config)
+        if config.bias:
+            raise NotImplementedError("bias=True is not used by the reference (model.py:191) and not implemented")
+
+    def forward(self, x, attn_mask=None):
+        _require_hip(x, "Block")
+        _require_hip(self.attn.c_attn.weight, "Block parameters")
+        _check_dropout(self, self.attn.dropout)
+        if self.attn.autoregressive:
+            raise NotImplementedError("autoregressive=True is not used by the encoder and not implemented")
+        B, T, C = x.shape
+        mask = ops.MaskSpec.from_user(attn_mask, B, T, self.attn.n_head, x.device)
+        cos, sin = self.attn.rope()
+        return _BlockFn.apply(x, self.ln_1.weight, self.attn.c_attn.weight, self.attn.c_proj.weight, self.ln_2.weight,
+                              self.mlp.c_fc.weight, self.mlp.c_proj.weight, cos, sin, self.attn.n_head, mask)
+
+
+@dataclass
+class OmniBioTAConfig:
+    block_size: int = 2048
+    vocab_size: int = 2 ** 16
+    n_layer: int = 12
+    n_head: int = 12
+    n_embd: int = 1024
+    dropout: float = 0.1
+    bias: bool = False
+    autoregressive: bool = False
+    checkpoint_freq: int = 0
+
+
+class MuReadout(_MuReadoutBase):
+    """The readout layer (model.py:208).  With the real ``mup`` package this is its MuReadout with the matmul
+    swapped for the HIP GEMM; without it, the restated class from mup_compat."""
+
+    def forward(self, x):
+        _require_hip(x, "MuReadout")
+        wm = self.width_mult()
+        return _LinearFn.apply(x, self.weight, float(self.output_mult) / float(wm))
+
+
+class OmniBioTA(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        assert config.vocab_size is not None
+        assert config.block_size is not None
+        self.config = config
+        self.transformer = nn.ModuleDict(dict(
+            wte=nn.Embedding(config.vocab_size, config.n_embd),
+            drop=nn.Dropout(config.dropout, inplace=True),
+            h=nn.ModuleList([Block(config) for _ in range(config.n_layer)]),
+            ln_f=LayerNorm(config.n_embd, bias=config.bias),
+        ))
+        self.lm_head = MuReadout(config.n_embd, config.vocab_size, bias=False)
+        print("number of parameters: %.2fM" % (self.get_num_params() / 1e6,))
+
+    def get_num_params(self, non_embedding=True):
+        """All parameters, minus the token embedding when non_embedding (model.py:213-223; lm_head is counted)."""
+        n_params = sum(p.numel() for p in self.parameters())
+        if non_embedding:
+            n_params -= self.transformer.wte.weight.numel()
+        return n_params
+
+    def forward(self, idx, attn_mask=None, return_embeddings=False):
+        """idx (b, t) int64 -> logits (b, t, vocab) or, with return_embeddings, emb (b, t, n_embd)
+        (model.py:225-254).  ``attn_mask``: None, the reference's additive (b, n_head, t, t) tensor (any strides,
+        expand() views included), or a ``masks.RangeMask`` (per-query key ranges; the fast path)."""
+        _, t = idx.size()
+        assert t <= self.config.block_size, f"Cannot forward sequence of length {t}, block size is only {self.config.block_size}"
+        wte = self.transformer.wte.weight
+        _require_hip(wte, "OmniBioTA")
+        if not idx.is_cuda:
+            raise RuntimeError("OmniBioTA.forward: idx must be on the GPU")
+        _check_dropout(self, self.transformer.drop.p)
+        b = idx.shape[0]
+        mask = ops.MaskSpec.from_user(attn_mask, b, t, self.config.n_head, idx.device)
+        x = _EmbeddingFn.apply(idx, wte)
+        for i, block in enumerate(self.transformer.h):
+            if self.config.checkpoint_freq > 0 and i % self.config.checkpoint_freq == 0:
+                x = checkpoint(block, x, mask, use_reentrant=False)
+            else:
+                x = block(x, attn_mask=mask)
+        emb = self.transformer.ln_f(x)
+        if return_embeddings:
+            return emb
+        return self.lm_head(emb)
+
+    def encode(self, idx, method="mean"):
+        """Pooled sequence embedding (model.py:256-277)."""
+        assert method in ["mean", "first", "last", "max", "all"], f"Unknown pooling method {method}"
+        emb = self.forward(idx, return_embeddings=True)
+        if method == "mean":
+            return emb.mean(dim=1)
+        elif method == "first":
+            return emb[:, 0]
+        elif method == "last":
+            return emb[:, -1]
+        elif method == "max":
+            return emb.max(dim=1)[0]
+        return emb

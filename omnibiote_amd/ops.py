@@ -1,0 +1,280 @@
+"""Tensor-level wrappers over the C ABI (include/omnibiote_hip.h).
+
+Each function validates shapes/dtypes/devices on the host (the kernels assume them), borrows raw device
+pointers from PyTorch-owned tensors for the duration of the call, and enqueues on PyTorch's *current* HIP
+stream.  Nothing here synchronises the host.  PyTorch is plumbing only: allocation, streams, autograd glue.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+bf16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(t: torch.Tensor, name: str, dtype=bf16, contiguous: bool = True) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the OmniBioTE HIP path runs on MI355X only; got a {t.device} tensor "
+                           "(there is no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float = 1e-5):
+    _need(x, "x"); _need(w, "weight")
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    assert w.numel() == cols
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    L.check(L.lib().obte_layernorm_fwd(_ptr(x), _ptr(w), _ptr(y), _ptr(mean), _ptr(rstd), rows, cols, eps, _stream()),
+            "obte_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dresid=None):
+    _need(dy, "dy"); _need(x, "x"); _need(w, "weight")
+    _need(mean, "mean", torch.float32); _need(rstd, "rstd", torch.float32)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    assert dy.shape == x.shape and mean.numel() == rows and rstd.numel() == rows
+    if dresid is not None:
+        _need(dresid, "dresid"); assert dresid.shape == x.shape
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    ws = torch.empty(L.lib().obte_layernorm_bwd_ws_rows() * cols, dtype=torch.float32, device=x.device)
+    L.check(L.lib().obte_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dresid), _ptr(dx),
+                                        _ptr(dw), _ptr(ws), rows, cols, _stream()), "obte_layernorm_bwd")
+    return dx, dw
+
+
+# --------------------------------------------------------------------------------------------------------- GEMM
+def gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True, epilogue=L.EPI_NONE, aux=None, alpha=1.0, out=None):
+    """D[M,N] = epilogue(alpha * sum_k A(m,k) B(n,k)); see include/omnibiote_hip.h.  Returns d, or (d, d2) for
+    the GELU epilogue."""
+    _need(a, "a"); _need(b, "b")
+    lda = K if a_kmajor else M
+    ldb = K if b_kmajor else N
+    assert a.numel() == M * K, (a.shape, M, K)
+    assert b.numel() == N * K, (b.shape, N, K)
+    d = out if out is not None else torch.empty((M, N), dtype=bf16, device=a.device)
+    _need(d, "d"); assert d.numel() == M * N
+    d2 = None
+    if epilogue == L.EPI_GELU:
+        d2 = torch.empty((M, N), dtype=bf16, device=a.device)
+    if epilogue in (L.EPI_ADD, L.EPI_GELU_BWD):
+        _need(aux, "aux"); assert aux.numel() == M * N
+    g = L.GemmArgs(_ptr(a), _ptr(b), _ptr(d), _ptr(aux), _ptr(d2), M, N, K, lda, ldb, N,
+                   int(a_kmajor), int(b_kmajor), epilogue, float(alpha))
+    L.check(L.lib().obte_gemm_bf16(C.byref(g), _stream()), "obte_gemm_bf16")
+    return (d, d2) if d2 is not None else d
+
+
+def linear_fwd(x2d, w, epilogue=L.EPI_NONE, aux=None, alpha=1.0):
+    """y = x W^T for x [M,K], W [N,K] (nn.Linear forward)."""
+    M, K = x2d.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    return gemm(x2d, w, M, N, K, True, True, epilogue, aux, alpha)
+
+
+def linear_dgrad(dy2d, w, epilogue=L.EPI_NONE, aux=None, alpha=1.0):
+    """dx = dy W for dy [M,N], W [N,K]."""
+    M, N = dy2d.shape
+    K = w.shape[1]
+    assert w.shape[0] == N
+    return gemm(dy2d, w, M, K, N, True, False, epilogue, aux, alpha)
+
+
+def linear_wgrad(dy2d, x2d, alpha=1.0):
+    """dW = dy^T x for dy [M,N], x [M,K] -> [N,K]."""
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    assert x2d.shape[0] == M
+    return gemm(dy2d, x2d, N, K, M, False, False, L.EPI_NONE, None, alpha)
+
+
+# --------------------------------------------------------------------------------------------------------- RoPE
+def rope_qk_(qkv, cos, sin, B, T, H, hs, inverse=False):
+    _need(qkv, "qkv"); _need(cos, "cos", torch.float32); _need(sin, "sin", torch.float32)
+    assert qkv.numel() == B * T * 3 * H * hs
+    assert cos.shape[-1] == hs // 2 and cos.shape[0] >= T and cos.shape == sin.shape
+    L.check(L.lib().obte_rope_qk_inplace(_ptr(qkv), _ptr(cos), _ptr(sin), B, T, H, hs, int(inverse), _stream()),
+            "obte_rope_qk_inplace")
+    return qkv
+
+
+# ---------------------------------------------------------------------------------------------------- attention
+class MaskSpec:
+    """How a mask reaches the kernels: per-query key ranges (int32 [B,T,2]) or a dense additive bf16 tensor
+    (B, H|1, T, T), possibly an expand() view with stride-0 heads, last dim contiguous."""
+
+    __slots__ = ("ranges", "dense", "sb", "sh", "sq")
+
+    def __init__(self, ranges=None, dense=None):
+        self.ranges, self.dense = ranges, dense
+        self.sb = self.sh = self.sq = 0
+        if dense is not None:
+            self.sb, self.sh, self.sq = dense.stride(0), dense.stride(1), dense.stride(2)
+
+    @staticmethod
+    def from_user(attn_mask, B, T, H, device):
+        if attn_mask is None:
+            return MaskSpec()
+        if isinstance(attn_mask, MaskSpec):
+            return attn_mask
+        if hasattr(attn_mask, "key_ranges"):  # masks.RangeMask
+            r = attn_mask.key_ranges
+            _need(r, "key_ranges", torch.int32)
+            if tuple(r.shape) != (B, T, 2):
+                raise RuntimeError(f"key_ranges must be (B,T,2)=({B},{T},2), got {tuple(r.shape)}")
+            return MaskSpec(ranges=r)
+        m = attn_mask
+        if not isinstance(m, torch.Tensor):
+            raise TypeError("attn_mask must be None, a tensor or a RangeMask")
+        if m.dim() == 3:
+            m = m.unsqueeze(1)
+        if m.dim() != 4 or m.shape[0] != B or m.shape[2] != T or m.shape[3] != T or m.shape[1] not in (1, H):
+            raise RuntimeError(f"attn_mask must be (B, n_head, T, T)=({B},{H},{T},{T}), got {tuple(attn_mask.shape)}")
+        if not m.is_cuda:
+            raise RuntimeError("attn_mask must be on the GPU")
+        if m.dtype == torch.bool:
+            raise RuntimeError("boolean masks are not part of the reference's contract; pass an additive float mask")
+        if m.shape[1] == H and m.stride(1) != 0 and H > 1:
+            pass
+        if m.dtype != bf16 or m.stride(3) != 1:
+            # convert without materialising H copies of an expand()ed mask
+            if m.shape[1] == 1 or m.stride(1) == 0:
+                m = m[:, :1].to(bf16).contiguous()
+            else:
+                m = m.to(bf16).contiguous()
+        if m.shape[1] == 1:
+            m = m.expand(B, H, T, T)
+        return MaskSpec(dense=m)
+
+
+def attn_fwd(qkv, B, T, H, hs, scale, mask: Optional[MaskSpec] = None):
+    _need(qkv, "qkv"); assert qkv.numel() == B * T * 3 * H * hs
+    mask = mask or MaskSpec()
+    o = torch.empty((B, T, H * hs), dtype=bf16, device=qkv.device)
+    lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
+    a = L.AttnFwdArgs(_ptr(qkv), _ptr(o), _ptr(lse), _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq,
+                      B, T, H, hs, float(scale))
+    L.check(L.lib().obte_attn_fwd(C.byref(a), _stream()), "obte_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(qkv, o, d_o, lse, B, T, H, hs, scale, mask: Optional[MaskSpec] = None, rope=None):
+    _need(qkv, "qkv"); _need(o, "o"); _need(d_o, "d_o"); _need(lse, "lse", torch.float32)
+    mask = mask or MaskSpec()
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
+    cos, sin = rope if rope is not None else (None, None)
+    a = L.AttnBwdArgs(_ptr(qkv), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(delta), _ptr(dqkv), _ptr(cos), _ptr(sin),
+                      _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq, B, T, H, hs, float(scale))
+    L.check(L.lib().obte_attn_bwd(C.byref(a), _stream()), "obte_attn_bwd")
+    return dqkv
+
+
+# ---------------------------------------------------------------------------------------------------- embedding
+def embedding_fwd(idx, wte):
+    _need(idx, "idx", torch.int64); _need(wte, "wte")
+    V, Cc = wte.shape
+    out = torch.empty(tuple(idx.shape) + (Cc,), dtype=bf16, device=wte.device)
+    L.check(L.lib().obte_embedding_fwd(_ptr(idx), _ptr(wte), _ptr(out), idx.numel(), Cc, V, _stream()), "obte_embedding_fwd")
+    return out
+
+
+def embedding_bwd(idx, dout, vocab):
+    _need(idx, "idx", torch.int64); _need(dout, "dout")
+    rows, Cc = idx.numel(), dout.shape[-1]
+    # the order is plumbing (a stable sort of <= a few 10k token ids); the summation itself is ours
+    order = torch.sort(idx.reshape(-1), stable=True).indices.to(torch.int32)
+    dwte = torch.empty((vocab, Cc), dtype=bf16, device=dout.device)
+    ws = torch.empty(max(int(L.lib().obte_embedding_bwd_ws_bytes(rows, Cc)), 16), dtype=torch.uint8, device=dout.device)
+    L.check(L.lib().obte_embedding_bwd(_ptr(idx), _ptr(order), _ptr(dout), _ptr(dwte), _ptr(ws), rows, Cc, vocab, _stream()),
+            "obte_embedding_bwd")
+    return dwte
+
+
+# ---------------------------------------------------------------------------------------------- loss, optimizer
+def masked_ce(logits, targets, mlm_mask, n_accum: int):
+    """Returns (loss scalar fp32 tensor, dlogits bf16) with the reference's micro-batch normalisation
+    (train_encoder.py:301-305): loss = sum_masked(CE)/n_accum / count."""
+    _need(logits, "logits"); _need(targets, "targets", torch.int64)
+    V = logits.shape[-1]
+    rows = logits.numel() // V
+    assert targets.numel() == rows and mlm_mask.numel() == rows
+    m8 = mlm_mask.reshape(-1).to(torch.uint8).contiguous()
+    inv_count = (1.0 / m8.sum(dtype=torch.float32)).reshape(1)
+    row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    L.check(L.lib().obte_masked_ce_fwd_bwd(_ptr(logits), _ptr(targets), _ptr(m8), _ptr(inv_count), 1.0 / n_accum, None,
+                                            _ptr(row_loss), _ptr(dlogits), rows, V, _stream()), "obte_masked_ce_fwd_bwd")
+    loss = row_loss.sum() * inv_count[0]
+    return loss, dlogits
+
+
+def adamw_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, clip_coef=None):
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _need(t, n)
+    assert p.numel() == g.numel() == m.numel() == v.numel()
+    L.check(L.lib().obte_adamw_bf16(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay,
+                                     int(step), _ptr(clip_coef), _stream()), "obte_adamw_bf16")
+
+
+def sumsq_(g, out):
+    _need(g, "g"); _need(out, "out", torch.float32)
+    L.check(L.lib().obte_sumsq_bf16(_ptr(g), g.numel(), _ptr(out), _stream()), "obte_sumsq_bf16")
+
+
+# -------------------------------------------------------------------------------------------------------- block
+def _block_desc(B, T, Cc, H, params, rope, mask: MaskSpec):
+    ln1, attn_w, proj_w, ln2, fc_w, mlp_w = params
+    return L.BlockDesc(B, T, Cc, H, _ptr(ln1), _ptr(attn_w), _ptr(proj_w), _ptr(ln2), _ptr(fc_w), _ptr(mlp_w),
+                       _ptr(rope[0]), _ptr(rope[1]), _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq)
+
+
+def block_fwd(x, params, rope, H, mask: MaskSpec):
+    """One transformer block forward.  Returns (y, act) where act is the opaque saved-activation buffer."""
+    _need(x, "x")
+    B, T, Cc = x.shape
+    for i, w in enumerate(params):
+        _need(w, f"param{i}")
+    _need(rope[0], "rope_cos", torch.float32); _need(rope[1], "rope_sin", torch.float32)
+    assert rope[0].shape[0] >= T
+    y = torch.empty_like(x)
+    act = torch.empty(int(L.lib().obte_block_act_bytes(B, T, Cc, H)), dtype=torch.uint8, device=x.device)
+    d = _block_desc(B, T, Cc, H, params, rope, mask)
+    L.check(L.lib().obte_block_fwd(C.byref(d), _ptr(x), _ptr(y), _ptr(act), _stream()), "obte_block_fwd")
+    return y, act
+
+
+def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec):
+    _need(x, "x"); _need(dy, "dy")
+    B, T, Cc = x.shape
+    ws = torch.empty(int(L.lib().obte_block_bwd_ws_bytes(B, T, Cc, H)), dtype=torch.uint8, device=x.device)
+    dx = torch.empty_like(x)
+    grads = [torch.empty_like(w) for w in params]
+    d = _block_desc(B, T, Cc, H, params, rope, mask)
+    L.check(L.lib().obte_block_bwd(C.byref(d), _ptr(x), _ptr(dy), _ptr(act), _ptr(ws), _ptr(dx), *[_ptr(g) for g in grads],
+                                    _stream()), "obte_block_bwd")
+    return dx, grads

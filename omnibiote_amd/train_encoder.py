@@ -1,0 +1,350 @@
+"""Data-parallel masked-LM training harness: the counterpart of the reference's ``training/train_encoder.py``
+for the MI355X path (one process per GPU under torchrun, DDP over RCCL).
+
+Kept from the reference (file:line = training/train_encoder.py):
+  * flags --batch_size / --mini_batch_size / --n_head / --n_embd / --n_layer / --ctx_len / --dropout / --lr / betas /
+    --epsilon / --weight_decay / --token_budget / --disable_flash / --force_lr / --checkpoint_freq / --use_padding /
+    --batch_ramp / --warmup_period (:438-467), global batch split evenly over ranks (:115-118);
+  * model + muP set-up: target, base (n_embd 24 / n_head 3) and delta (48 / 12) models, set_base_shapes, bf16 (:145-170);
+  * lr = args.lr * sqrt(batch_size) / 32, MuAdamW (or AdamW with --force_lr), LinearLR 1 -> 0 (:195-201);
+  * MLM corruption with the host NumPy RNG, 15 %, every selected token -> MASK (:273-279);
+  * gradient accumulation over rows/mini_batch_size micro-batches with loss / n_accum, masked-only CE averaged over
+    the masked tokens of the micro-batch (:284-305); clip_grad_norm_(1.0), optimizer, scheduler (:316-318);
+  * tokens/s = non-PAD tokens of all ranks / wall time, MFU formula 6N + 12 L C T (:350-364).
+Changed on purpose (same mathematics, MI355X-first mechanics):
+  * the attention mask travels as per-query key ranges built on the device (masks.RangeMask) instead of a dense
+    (B, H, T, T) tensor built by a Python loop behind a nonzero() host sync (:290-292);
+  * gradients are all-reduced once per optimizer step — DDP ``no_sync()`` on all but the last micro-batch — instead
+    of after every micro-batch (the reference never calls no_sync, :284-311); averaging already-averaged sums is
+    idempotent, so the result is the same while 1/n_accum of the bytes cross xGMI, in buckets that overlap with the
+    last micro-batch's backward;
+  * loss: fused CE forward+backward kernel (one pass over the logits); the per-step scalars (loss, token count) are
+    reduced with one small device all-reduce instead of two pickled gloo all_gather_object calls (:335,354);
+  * clip + AdamW run as fused kernels without a host sync (the clip coefficient stays on the device).
+Data: synthetic token batches of the reference loader's output contract — the datasets and wandb are
+not available offline; ``--base_dir`` is accepted and ignored with a notice.
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import math
+import os
+import time
+from typing import Callable, Dict, Iterable, List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+EOS_TOKEN, MASK_TOKEN, PAD_TOKEN = 3, 2, 1   # training/loader.py:4-6
+DNA_TAG, PROTEIN_TAG = 4, 18                   # tokenizer ids
+BANNED_MIXED = 65533                           # train_encoder.py:62-67
+
+
+# ----------------------------------------------------------------------------------------------- synthetic data
+def synthetic_rows(rows: int, ctx_len: int, vocab: int, rng: np.random.Generator, single_document: bool = True,
+                   nucleotide_fraction: float = 0.8) -> np.ndarray:
+    """int64 (rows, ctx_len) in the packed, un-padded format get_sequence(..., USE_PADDING=False) yields
+    (loader.py:118-163): documents ``tag, body..., EOS`` concatenated and truncated at ctx_len; 80 % of the rows
+    nucleotide (tag 4), 20 % peptide (tag 18) as the 'mixed' split (train_encoder.py:82-86); body ids uniform over
+    [20, vocab) minus the banned id.  single_document=True makes every row one document longer than ctx_len (no
+    interior EOS -> full attention), the variant the FLOP formula assumes."""
+    out = np.empty((rows, ctx_len), dtype=np.int64)
+    hi = min(vocab, 65536)
+    for r in range(rows):
+        nucleotide = rng.random() < nucleotide_fraction
+        tag = DNA_TAG if nucleotide else PROTEIN_TAG
+        pos = 0
+        while pos < ctx_len:
+            if single_document:
+                n = ctx_len
+            else:
+                lo_len, hi_len = (256, 8192) if nucleotide else (32, 512)
+                n = int(math.exp(rng.uniform(math.log(lo_len), math.log(hi_len))))
+            doc = rng.integers(20, hi, size=n + 2)
+            doc[doc == BANNED_MIXED] = 20
+            doc[0] = tag
+            doc[-1] = EOS_TOKEN
+            take = min(len(doc), ctx_len - pos)
+            out[r, pos:pos + take] = doc[:take]
+            pos += take
+    rng.shuffle(out, axis=0)   # loader.py:176
+    return out
+
+
+def mlm_corrupt(input_ids: torch.Tensor, mask_prob: float = 0.15):
+    """train_encoder.py:273-279: host NumPy Bernoulli, minus PAD and EOS positions, all selected -> MASK_TOKEN."""
+    draw = np.random.binomial(1, mask_prob, tuple(input_ids.shape))
+    mask = torch.as_tensor(draw, dtype=torch.bool, device=input_ids.device)
+    mask = mask & (input_ids != PAD_TOKEN) & (input_ids != EOS_TOKEN)
+    return input_ids.masked_fill(mask, MASK_TOKEN), mask
+
+
+# ---------------------------------------------------------------------------------------------------- optimizer
+class FusedAdamW(torch.optim.Optimizer):
+    """AdamW over bf16 parameters with bf16 moments (the reference's pure-bf16 regime) on the fused HIP kernels.
+    ``step(max_norm=...)`` also applies clip_grad_norm_ semantics (train_encoder.py:316) without a host sync: the
+    squared norm is accumulated on the device and the coefficient min(1, max_norm/(norm+1e-6)) is consumed by the
+    update kernel directly."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._norm_sq = None
+
+    @torch.no_grad()
+    def step(self, max_norm: Optional[float] = None):
+        from . import ops
+        params = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
+        if not params:
+            return None
+        dev = params[0].device
+        clip = None
+        if max_norm is not None:
+            if self._norm_sq is None or self._norm_sq.device != dev:
+                self._norm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._norm_sq.zero_()
+            for p in params:
+                ops.sumsq_(p.grad, self._norm_sq)
+            clip = torch.clamp(max_norm / (self._norm_sq.sqrt() + 1e-6), max=1.0)
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                ops.adamw_step_(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), b1, b2,
+                                group["eps"], group["weight_decay"], st["step"], clip)
+        return None if clip is None else self._norm_sq
+
+
+# --------------------------------------------------------------------------------------------------- train step
+class TrainStep:
+    """One optimizer step of train_encoder.py:241-323 over a (rows, ctx_len) batch of this rank's rows."""
+
+    def __init__(self, model, optimizer, scheduler=None, *, mini_batch_size: int, n_head: int, use_padding: bool = False,
+                 loss_impl: str = "fused", mask_impl: str = "ranges", sync_every_micro_step: bool = False,
+                 max_grad_norm: float = 1.0):
+        self.model, self.optimizer, self.scheduler = model, optimizer, scheduler
+        self.mini, self.n_head, self.use_padding = mini_batch_size, n_head, use_padding
+        self.loss_impl, self.mask_impl = loss_impl, mask_impl
+        self.sync_every = sync_every_micro_step
+        self.max_grad_norm = max_grad_norm
+
+    def _mask(self, tokens: torch.Tensor, dtype):
+        from . import masks
+        rm = masks.RangeMask.from_tokens(tokens, padding=self.use_padding)
+        if self.mask_impl == "ranges":
+            return rm
+        B, T = tokens.shape
+        return rm.dense(dtype).unsqueeze(1).expand(-1, self.n_head, -1, -1)   # train_encoder.py:292
+
+    def _loss_backward(self, logits, targets, mask, n_accum):
+        if self.loss_impl == "fused":
+            from . import ops
+            loss, dlogits = ops.masked_ce(logits, targets, mask, n_accum)
+            logits.backward(dlogits)
+            return loss.detach()
+        # the reference's own three lines (train_encoder.py:301-305)
+        loss = F.cross_entropy(logits.view(-1, logits.size(-1)), targets.reshape(-1), reduction="none") / n_accum
+        loss *= mask.reshape(-1).float()
+        loss = loss.sum() / mask.reshape(-1).sum()
+        loss.backward()
+        return loss.detach().float()
+
+    def __call__(self, input_ids: torch.Tensor) -> Dict[str, torch.Tensor]:
+        rows = input_ids.shape[0] // self.mini * self.mini
+        input_ids = input_ids[:rows]
+        n_accum = rows // self.mini
+        self.optimizer.zero_grad(set_to_none=True)
+        masked_ids, mask = mlm_corrupt(input_ids)
+        dtype = next(self.model.parameters()).dtype
+        cum_loss = torch.zeros((), dtype=torch.float32, device=input_ids.device)
+        for j in range(n_accum):
+            x = masked_ids[j * self.mini:(j + 1) * self.mini]
+            y = input_ids[j * self.mini:(j + 1) * self.mini]
+            attn_mask = self._mask(y, dtype)
+            last = j == n_accum - 1
+            ctx = contextlib.nullcontext()
+            if hasattr(self.model, "no_sync") and not last and not self.sync_every:
+                ctx = self.model.no_sync()
+            with ctx:
+                logits = self.model(x, attn_mask=attn_mask)
+                cum_loss += self._loss_backward(logits, y, mask[j * self.mini:(j + 1) * self.mini], n_accum)
+        if isinstance(self.optimizer, FusedAdamW):
+            self.optimizer.step(max_norm=self.max_grad_norm)
+        else:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_grad_norm)
+            self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        tokens = (input_ids != PAD_TOKEN).sum()
+        return {"loss": cum_loss, "tokens": tokens}
+
+
+# ------------------------------------------------------------------------------------------------- model set-up
+def build_model(args, device, dtype=torch.bfloat16, vocab_size: int = 2 ** 16):
+    """train_encoder.py:145-170: target model, muP base/delta models sharing ONE mutated config object,
+    set_base_shapes, cast, move."""
+    from .model import OmniBioTA, OmniBioTAConfig
+    try:
+        from mup import set_base_shapes  # type: ignore
+    except Exception:
+        from .mup_compat import set_base_shapes
+    config = OmniBioTAConfig()
+    config.vocab_size = vocab_size
+    config.dropout = args.dropout
+    config.block_size = args.ctx_len
+    config.n_embd = args.n_embd
+    config.n_layer = args.n_layer
+    config.n_head = args.n_head
+    config.flash = not args.disable_flash
+    config.checkpoint_freq = args.checkpoint_freq
+    m = OmniBioTA(config)
+    config.n_embd, config.n_head = 24, 3
+    base_model = OmniBioTA(config)
+    config.n_embd, config.n_head = 48, 12
+    delta_model = OmniBioTA(config)
+    set_base_shapes(m, base_model, delta=delta_model)
+    del base_model, delta_model
+    config.n_embd, config.n_head = args.n_embd, args.n_head   # the reference leaves 48/12 behind; nothing reads it
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")   # "Casting complex values to real": the reference's cos-only RoPE regime
+        m.to(dtype)
+    m.to(device)
+    return m
+
+
+def build_optimizer(model, args, total_iters: int, fused: bool = True):
+    """train_encoder.py:195-201."""
+    lr = args.lr * np.sqrt(args.batch_size) / 32
+    params = list(model.parameters())
+    betas = (args.beta1, args.beta2)
+    if args.force_lr:
+        groups = [{"params": params}]
+    else:
+        from .mup_compat import mu_param_groups
+        groups = mu_param_groups(params, lr, args.weight_decay)
+    if fused:
+        opt = FusedAdamW(groups, lr=lr, betas=betas, eps=args.epsilon, weight_decay=args.weight_decay)
+    else:
+        opt = torch.optim.AdamW(groups, lr=lr, betas=betas, eps=args.epsilon, weight_decay=args.weight_decay)
+    sched = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1.0, end_factor=0.0, total_iters=max(total_iters, 1))
+    return opt, sched
+
+
+def flops_per_token(num_model_params: int, n_layer: int, n_embd: int, ctx_len: int) -> float:
+    return 6.0 * num_model_params + 12.0 * n_layer * n_embd * ctx_len   # train_encoder.py:360
+
+
+def wrap_ddp(model, device_index: Optional[int], bucket_cap_mb: int = 100):
+    """DDP over RCCL.  Buckets of ~100 MB (a few per all-reduce of small's 470 MB) keep each ring/tree step long
+    enough to run at xGMI link rate while still overlapping the tail of backward; gradients are views into the
+    buckets, so the reducer never copies."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    kw = dict(bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, broadcast_buffers=False)
+    if device_index is None:
+        return DDP(model, **kw)
+    return DDP(model, device_ids=[device_index], **kw)
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="OmniBioTE masked-LM training on MI355X (synthetic data)")
+    p.add_argument("--batch_size", type=int, default=1024)
+    p.add_argument("--mini_batch_size", type=int, default=8)
+    p.add_argument("--n_head", type=int, default=8)
+    p.add_argument("--n_embd", type=int, default=1024)
+    p.add_argument("--n_layer", type=int, default=8)
+    p.add_argument("--ctx_len", type=int, default=2048)
+    p.add_argument("--dropout", type=float, default=0.1)
+    p.add_argument("--lr", type=float, default=1e-2)
+    p.add_argument("--beta1", type=float, default=0.9)
+    p.add_argument("--beta2", type=float, default=0.999)
+    p.add_argument("--epsilon", type=float, default=1e-8)
+    p.add_argument("--weight_decay", type=float, default=1e-2)
+    p.add_argument("--token_budget", type=float, default=20e9)
+    p.add_argument("--test_freq", type=int, default=int(1e7))
+    p.add_argument("--save_freq", type=int, default=int(1e9))
+    p.add_argument("--save_name", type=str, default="omnibiota")
+    p.add_argument("--disable_flash", action="store_true", default=False)
+    p.add_argument("--wandb_project_name", type=str, default="omnibiota")
+    p.add_argument("--base_dir", type=str, default="")
+    p.add_argument("--force_lr", action="store_true", default=False)
+    p.add_argument("--checkpoint_freq", type=int, default=0)
+    p.add_argument("--banned_token", type=int, default=BANNED_MIXED)
+    p.add_argument("--warmup_period", type=float, default=0.05)
+    p.add_argument("--batch_ramp", action="store_true", default=False)
+    p.add_argument("--train_type", type=str, default="mixed")
+    p.add_argument("--FSDP", action="store_true", default=False)
+    p.add_argument("--use_padding", action="store_true", default=False)
+    p.add_argument("--resume_from", type=int, default=0)
+    # additions
+    p.add_argument("--max_steps", type=int, default=0, help="stop after this many optimizer steps (0 = token budget)")
+    p.add_argument("--multi_document", action="store_true", default=False, help="synthetic rows with interior EOS")
+    return p.parse_args(argv)
+
+
+def effective_batch(i: int, total_iters: int, args, batch_size: int) -> int:
+    """Batch-size ramp of train_encoder.py:245-255."""
+    mini = args.mini_batch_size
+    if args.batch_ramp:
+        e = min((int(i / (total_iters * args.warmup_period) * batch_size) // mini) * mini + mini, batch_size)
+    else:
+        e = batch_size
+    return e // mini * mini
+
+
+def run(args):
+    if args.FSDP:
+        raise NotImplementedError("--FSDP is outside this build's scope (the north star names DDP)")
+    if args.resume_from:
+        raise NotImplementedError("--resume_from is outside this round's scope")
+    if args.base_dir:
+        print("note: --base_dir ignored; this harness trains on synthetic token batches")
+    dist.init_process_group("nccl")   # RCCL on ROCm
+    rank, world = dist.get_rank(), dist.get_world_size()
+    local = int(os.environ.get("LOCAL_RANK", rank % max(torch.cuda.device_count(), 1)))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    assert args.batch_size % world == 0, "Batch size must be divisible by the number of processes."
+    batch_size = args.batch_size // world
+    np.random.seed(1234 + rank)
+    torch.manual_seed(1234)   # identical initial weights on every rank (DDP broadcasts rank 0's anyway)
+    m = build_model(args, device)
+    n_params = m.get_num_params()
+    model = wrap_ddp(m, local) if world > 1 else m
+    total_iters = int(args.token_budget / (world * batch_size * args.ctx_len))
+    opt, sched = build_optimizer(m, args, total_iters)
+    step = TrainStep(model, opt, sched, mini_batch_size=args.mini_batch_size, n_head=args.n_head, use_padding=args.use_padding)
+    rng = np.random.default_rng(1234 + rank)
+    trained = 0
+    fpt = flops_per_token(n_params, args.n_layer, args.n_embd, args.ctx_len)
+    n_steps = total_iters if args.max_steps <= 0 else min(total_iters, args.max_steps)
+    for i in range(n_steps):
+        t0 = time.time()
+        rows = effective_batch(i, total_iters, args, batch_size)
+        ids = torch.from_numpy(synthetic_rows(rows, args.ctx_len, 2 ** 16, rng, single_document=not args.multi_document)).to(device)
+        out = step(ids)
+        stats = torch.stack([out["loss"], out["tokens"].float()])
+        if world > 1:
+            dist.all_reduce(stats)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        loss, toks = stats[0].item() / world, int(stats[1].item())
+        trained += toks
+        if rank == 0:
+            lrs = [g["lr"] for g in opt.param_groups]
+            print(f"step {i} loss {loss:.4f} lr {lrs[0]:.5f}|{lrs[-1]:.5f} tokens/s {toks / dt:,.0f} "
+                  f"MFMA-frac {toks / dt * fpt / (2.5e15 * world) * 100:.1f}% trained {trained / 1e6:.2f}M", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    run(parse_args())

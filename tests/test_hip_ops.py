@@ -1,0 +1,364 @@
+"""GPU parity tests, kernel level: every C-ABI entry point against the CPU oracle / a torch fp32 reference of the
+same op on the same seeded inputs.  Floating-point path, so the bar is a stated tolerance: inputs are bf16,
+accumulation fp32, outputs rounded to bf16 once — |got - ref| <= RTOL*|ref| + ATOL with RTOL = 2^-7 (two bf16
+ulps) unless a test says otherwise; ATOL scales with the magnitude of the reduction."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import omnibiote_ref as R
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+BF = torch.bfloat16
+RTOL = 2.0 ** -7
+
+
+def ops():
+    from omnibiote_amd import ops as o
+    return o
+
+
+def L():
+    from omnibiote_amd import _lib
+    return _lib
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def close(got, ref, atol, rtol=RTOL, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - ref).abs()
+    bound = rtol * ref.abs() + atol
+    bad = err > bound
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off; max err {err.max():.4g} (ref max {ref.abs().max():.4g})"
+
+
+# ------------------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(256, 384, 128), (200, 136, 192), (128, 128, 64), (1024, 1024, 1024), (77, 512, 256)])
+def test_gemm_forward_nt(M, N, K):
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    ref = x.float() @ w.float().t()
+    got = ops().linear_fwd(x.to(DEV), w.to(DEV))
+    close(got, ref, atol=0.02 * math.sqrt(K), what="gemm NT")
+
+
+def test_gemm_identity_asymmetric():
+    """A = I against an asymmetric B catches a transposed C write or a wrong operand lane map exactly."""
+    K = 128
+    eye = torch.eye(K).to(BF)
+    b = (torch.arange(256 * K).reshape(256, K) % 251 - 125).float().to(BF)  # exactly representable
+    got = ops().linear_fwd(eye.to(DEV), b.to(DEV))  # [128, 256] = I @ b^T
+    assert torch.equal(got.cpu().float(), b.float().t())
+    got = ops().linear_fwd(b.to(DEV), eye.to(DEV))  # [256, 128] = b @ I
+    assert torch.equal(got.cpu().float(), b.float())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 384), (300, 256, 384), (130, 512, 128), (64, 1024, 2048)])
+def test_gemm_dgrad_nn(M, N, K):
+    """dx[M,N] = dy[M,K] W[K,N]: B is read k-strided through the transposing LDS reads."""
+    dy, w = rnd(M, K, seed=3), rnd(K, N, seed=4)
+    ref = dy.float() @ w.float()
+    got = ops().linear_dgrad(dy.to(DEV), w.to(DEV))
+    close(got, ref, atol=0.02 * math.sqrt(K), what="gemm NN")
+
+
+def test_gemm_dgrad_identity():
+    N = 256
+    w = (torch.arange(128 * N).reshape(128, N) % 241 - 120).float().to(BF)
+    eye = torch.eye(128).to(BF)
+    got = ops().linear_dgrad(eye.to(DEV), w.to(DEV))
+    assert torch.equal(got.cpu().float(), w.float())
+
+
+@pytest.mark.parametrize("M,N,K", [(384, 256, 256), (384, 256, 300), (128, 136, 77), (1024, 256, 2048), (512, 128, 154)])
+def test_gemm_wgrad_tn(M, N, K):
+    """dW[M,N] = dy[K,M]^T x[K,N]: both operands k-strided; K (tokens) may be ragged — the tail is zero-filled
+    by the buffer bounds check."""
+    dy, x = rnd(K, M, seed=5), rnd(K, N, seed=6)
+    ref = dy.float().t() @ x.float()
+    got = ops().linear_wgrad(dy.to(DEV), x.to(DEV))
+    close(got, ref, atol=0.02 * math.sqrt(K), what="gemm TN")
+
+
+def test_gemm_wgrad_identity():
+    x = (torch.arange(128 * 256).reshape(128, 256) % 239 - 119).float().to(BF)
+    eye = torch.eye(128).to(BF)
+    got = ops().linear_wgrad(eye.to(DEV), x.to(DEV))  # I^T x
+    assert torch.equal(got.cpu().float(), x.float())
+
+
+def test_gemm_epilogues_and_alpha():
+    M, N, K = 200, 256, 128
+    x, w, r = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=0.2), rnd(M, N, seed=9)
+    acc = x.float() @ w.float().t()
+    o = ops()
+    # alpha
+    close(o.linear_fwd(x.to(DEV), w.to(DEV), alpha=1 / 42.0), acc / 42.0, atol=2e-3, what="alpha")
+    # residual add: bf16(aux + bf16(acc))
+    ref = (r.float() + acc.to(BF).float())
+    close(o.linear_fwd(x.to(DEV), w.to(DEV), epilogue=L().EPI_ADD, aux=r.to(DEV)), ref, atol=0.03, what="add")
+    # GELU: d = bf16(acc), d2 = gelu(d)
+    d, d2 = o.linear_fwd(x.to(DEV), w.to(DEV), epilogue=L().EPI_GELU)
+    close(d, acc, atol=0.03, what="gelu pre")
+    close(d2, R.gelu_erf(d.float().cpu()), atol=1e-3, rtol=2.0 ** -8, what="gelu act")
+    # GELU backward on dgrad
+    dy, w2, h = rnd(M, K, seed=10), rnd(K, N, seed=11, scale=0.2), rnd(M, N, seed=12)
+    hh = h.float().requires_grad_(True)
+    R.gelu_erf(hh).sum().backward()
+    ref = (dy.float() @ w2.float()).to(BF).float() * hh.grad
+    got = o.linear_dgrad(dy.to(DEV), w2.to(DEV), epilogue=L().EPI_GELU_BWD, aux=h.to(DEV))
+    close(got, ref, atol=0.03, what="gelu bwd")
+
+
+def test_gemm_rejects_bad_shapes():
+    o = ops()
+    with pytest.raises(RuntimeError):
+        o.linear_fwd(rnd(64, 100).to(DEV), rnd(64, 100).to(DEV))  # k-contiguous K % 64 != 0
+    with pytest.raises(RuntimeError):
+        o.linear_fwd(rnd(64, 64), rnd(64, 64))  # CPU tensors: no fallback
+
+
+# -------------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,cols", [(37, 128), (64, 256), (513, 1024), (9, 2048), (5, 1032)])
+def test_layernorm_fwd_bwd(rows, cols):
+    x, w, dy, dres = rnd(rows, cols, seed=1, scale=2.0), (1 + 0.3 * rnd(cols, seed=2).float()).to(BF), rnd(rows, cols, seed=3), rnd(rows, cols, seed=4)
+    xf, wf = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    yref = R.layer_norm(xf, wf)
+    yref.backward(dy.float())
+    o = ops()
+    y, mean, rstd = o.layernorm_fwd(x.to(DEV), w.to(DEV))
+    close(y, yref, atol=2e-3, what="ln fwd")
+    close(mean, x.float().mean(1), atol=1e-5, rtol=1e-5, what="ln mean")
+    dx, dw = o.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd)
+    close(dx, xf.grad, atol=4e-3, what="ln dx")
+    close(dw, wf.grad, atol=0.02 * math.sqrt(rows), what="ln dw")
+    dx2, _ = o.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, dresid=dres.to(DEV))
+    close(dx2, xf.grad + dres.float(), atol=8e-3, what="ln dx+resid")
+
+
+# ------------------------------------------------------------------------------------------------------- RoPE
+@pytest.mark.parametrize("hs", [64, 128])
+@pytest.mark.parametrize("mode", ["complex", "cos_only"])
+def test_rope(hs, mode):
+    B, T, H = 2, 37, 2
+    C = H * hs
+    qkv = rnd(B, T, 3 * C, seed=5)
+    tab = R.rope_table(hs, 64)
+    if mode == "cos_only":
+        tab = R.cast_rope_table(tab, BF)
+    from omnibiote_amd.model import rope_tables
+    cos, sin = rope_tables(tab.to(DEV))
+    got = ops().rope_qk_(qkv.clone().to(DEV), cos, sin, B, T, H, hs).cpu()
+    q, k, v = qkv.split(C, dim=2)
+    rq = R.apply_rope(q.reshape(B, T, H, hs), tab).reshape(B, T, C)
+    rk = R.apply_rope(k.reshape(B, T, H, hs), tab).reshape(B, T, C)
+    ref = torch.cat([rq, rk, v], dim=2)
+    # fp32 math on both sides, one bf16 rounding: allow 1 bf16 ulp for fma-contraction differences
+    close(got, ref, atol=1e-6, rtol=2.0 ** -8, what="rope")
+    assert torch.equal(got[..., 2 * C:], v)
+    # inverse is the transpose: <R x, y> == <x, R^T y>
+    y = rnd(B, T, 3 * C, seed=6)
+    ry = ops().rope_qk_(y.clone().to(DEV), cos, sin, B, T, H, hs, inverse=True).cpu()
+    lhs = (got.float()[..., :2 * C] * y.float()[..., :2 * C]).sum()
+    rhs = (qkv.float()[..., :2 * C] * ry.float()[..., :2 * C]).sum()
+    assert abs(lhs - rhs) <= 2e-2 * abs(lhs) + 1.0
+
+
+# -------------------------------------------------------------------------------------------------- attention
+def _blocks_to_masks(tokens, T):
+    blocks = R.document_blocks(tokens)
+    dense = R.dense_mask_from_blocks(blocks, T)
+    ranges = torch.from_numpy(R.key_ranges_from_blocks(blocks, T))
+    return dense, ranges
+
+
+def _attn_case(B, T, H, hs, seed):
+    C = H * hs
+    qkv = rnd(B, T, 3 * C, seed=seed)
+    q, k, v = [t.reshape(B, T, H, hs).transpose(1, 2).float() for t in qkv.split(C, dim=2)]
+    return qkv, q, k, v
+
+
+@pytest.mark.parametrize("hs", [64, 128])
+@pytest.mark.parametrize("T", [64, 77, 130, 256])
+@pytest.mark.parametrize("mode", ["none", "ranges", "dense"])
+def test_attention_fwd_bwd(hs, T, mode):
+    B, H = 2, 2
+    C = H * hs
+    scale = 8.0 / C
+    qkv, q, k, v = _attn_case(B, T, H, hs, seed=hs + T)
+    rng = np.random.default_rng(T)
+    tokens = rng.integers(20, 100, size=(B, T))
+    tokens[0, [T // 3, T // 2]] = R.EOS_TOKEN
+    tokens[1, [5, T - 10]] = R.EOS_TOKEN
+    dense, ranges = _blocks_to_masks(tokens, T)
+    o = ops()
+    mask_add, spec = None, None
+    if mode == "ranges":
+        mask_add, spec = dense.unsqueeze(1), o.MaskSpec(ranges=ranges.to(DEV))
+    elif mode == "dense":
+        mask_add = dense.unsqueeze(1)
+        spec = o.MaskSpec.from_user(dense.to(BF).to(DEV).unsqueeze(1).expand(B, H, T, T), B, T, H, DEV)
+    qf, kf, vf = q.requires_grad_(True), k.requires_grad_(True), v.requires_grad_(True)
+    ref = R.attention(qf, kf, vf, scale, mask_add)  # (B,H,T,hs)
+    d_o = rnd(B, T, C, seed=99)
+    ref.backward(d_o.reshape(B, T, H, hs).transpose(1, 2).float())
+    got, lse = o.attn_fwd(qkv.to(DEV), B, T, H, hs, scale, spec)
+    close(got, ref.transpose(1, 2).reshape(B, T, C), atol=6e-3, what=f"attn fwd {mode}")
+    att = (q @ k.transpose(-2, -1)) * scale
+    if mask_add is not None:
+        att = att + mask_add
+    close(lse, torch.logsumexp(att, dim=-1), atol=2e-3, rtol=1e-3, what="lse")
+    dqkv = o.attn_bwd(qkv.to(DEV), got, d_o.to(DEV), lse, B, T, H, hs, scale, spec)
+    dref = torch.cat([g.transpose(1, 2).reshape(B, T, C) for g in (qf.grad, kf.grad, vf.grad)], dim=2)
+    close(dqkv, dref, atol=1.5e-2, rtol=2.0 ** -6, what=f"attn bwd {mode}")
+
+
+def test_attention_softmax_rescale_branch():
+    """Spike one key late in the sequence so the running max jumps at a later KV tile: the online-softmax
+    rescale of O and l must be exact (cdna guide rule 26)."""
+    B, T, H, hs = 1, 256, 1, 128
+    C = H * hs
+    qkv = rnd(B, T, 3 * C, seed=123, scale=0.5)
+    qkv[0, 200, C:2 * C] = 6.0 * torch.sign(qkv[0, 17, :C].float()).to(BF)  # key 200 aligns with query 17
+    q, k, v = [t.reshape(B, T, H, hs).transpose(1, 2).float() for t in qkv.split(C, dim=2)]
+    scale = 0.25
+    ref = R.attention(q, k, v, scale)
+    got, _ = ops().attn_fwd(qkv.to(DEV), B, T, H, hs, scale)
+    close(got, ref.transpose(1, 2).reshape(B, T, C), atol=6e-3, what="rescale branch")
+
+
+def test_attention_rows_sum_to_one_full_size():
+    """BASELINE config 2 size (B=8,T=1024,H=8,hs=128): with V = 1 every output element must be 1 (softmax rows
+    sum to 1) whatever Q, K and the mask are — a size-independent property."""
+    B, T, H, hs = 8, 1024, 8, 128
+    C = H * hs
+    g = torch.Generator(device=DEV).manual_seed(0)
+    qkv = torch.randn(B, T, 3 * C, device=DEV, generator=g).to(BF)
+    qkv[..., 2 * C:] = 1.0
+    starts = torch.arange(T, device=DEV) // 300 * 300
+    ranges = torch.stack([starts, torch.clamp(starts + 300, max=T)], dim=1).to(torch.int32).unsqueeze(0).expand(B, T, 2).contiguous()
+    for spec in (None, ops().MaskSpec(ranges=ranges)):
+        o, lse = ops().attn_fwd(qkv, B, T, H, hs, 8.0 / C, spec)
+        assert torch.isfinite(lse).all()
+        assert (o.float() - 1.0).abs().max().item() <= 2.0 ** -7
+
+
+# -------------------------------------------------------------------------------------------------- embedding
+def test_embedding_fwd_bwd_with_heavy_duplicates():
+    V, C, rows = 512, 256, 1000
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, V, size=rows)
+    idx[rng.random(rows) < 0.3] = 2      # a MASK-like token hit ~300 times: spans many 32-row chunks
+    idx[100:140] = 7                     # a run that starts and ends inside chunk boundaries after sorting
+    idx = torch.from_numpy(idx)
+    wte, dout = rnd(V, C, seed=1), rnd(rows, C, seed=2)
+    o = ops()
+    got = o.embedding_fwd(idx.to(DEV), wte.to(DEV))
+    assert torch.equal(got.cpu(), wte[idx])
+    dw = o.embedding_bwd(idx.to(DEV), dout.to(DEV), V)
+    ref = torch.zeros(V, C).index_add_(0, idx, dout.float())
+    close(dw, ref, atol=2e-2, what="embedding bwd")
+    untouched = torch.ones(V, dtype=torch.bool); untouched[idx] = False
+    assert (dw.cpu()[untouched] == 0).all()
+    dw2 = o.embedding_bwd(idx.to(DEV), dout.to(DEV), V)
+    assert torch.equal(dw, dw2), "embedding backward must be bitwise reproducible"
+
+
+@pytest.mark.parametrize("rows", [1, 31, 32, 33, 64])
+def test_embedding_bwd_edge_sizes(rows):
+    V, C = 64, 128
+    idx = torch.full((rows,), 5, dtype=torch.int64)
+    if rows > 2:
+        idx[-1] = 9
+    dout = rnd(rows, C, seed=rows)
+    dw = ops().embedding_bwd(idx.to(DEV), dout.to(DEV), V)
+    ref = torch.zeros(V, C).index_add_(0, idx, dout.float())
+    close(dw, ref, atol=2e-2, what="embedding bwd edge")
+
+
+# --------------------------------------------------------------------------------------------- loss / optimizer
+@pytest.mark.parametrize("rows,V", [(64, 512), (50, 65536), (33, 1000)])
+def test_masked_ce(rows, V):
+    logits = rnd(rows, V, seed=1, scale=2.0)
+    tgt = torch.from_numpy(np.random.default_rng(1).integers(0, V, size=rows))
+    mask = torch.from_numpy(np.random.default_rng(2).random(rows) < 0.3)
+    mask[0] = True
+    lf = logits.float().requires_grad_(True)
+    ref = R.masked_lm_loss(lf, tgt, mask, n_accum=4)
+    ref.backward()
+    loss, dl = ops().masked_ce(logits.to(DEV), tgt.to(DEV), mask.to(DEV), 4)
+    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item()) + 1e-6
+    close(dl, lf.grad, atol=2e-7, rtol=2.0 ** -7, what="dlogits")
+    assert (dl.cpu()[~mask] == 0).all()
+    # gradient rows sum to ~0 for masked rows (softmax - onehot)
+    assert dl.float().sum(1).abs().max().item() < 1e-3
+
+
+def test_adamw_matches_fp32_formula():
+    n = 4096 + 8
+    p, g = rnd(n, seed=1), rnd(n, seed=2, scale=0.1)
+    m, v = rnd(n, seed=3, scale=0.01), (rnd(n, seed=4, scale=0.01).float() ** 2).to(BF)
+    lr, b1, b2, eps, wd, step, clip = 1e-2, 0.9, 0.999, 1e-8, 1e-2, 3, 0.5
+    gf = g.float() * clip
+    pf = p.float() * (1 - lr * wd)
+    mf = m.float() + (gf - m.float()) * (1 - b1)
+    vf = v.float() * b2 + gf * gf * (1 - b2)
+    denom = vf.sqrt() / math.sqrt(1 - b2 ** step) + eps
+    pf = pf - (lr / (1 - b1 ** step)) * mf / denom
+    pd, md, vd = p.clone().to(DEV), m.clone().to(DEV), v.clone().to(DEV)
+    cc = torch.tensor([clip], device=DEV)
+    ops().adamw_step_(pd, g.to(DEV), md, vd, lr, b1, b2, eps, wd, step, cc)
+    close(pd, pf, atol=1e-6, rtol=2.0 ** -8, what="adamw p")
+    close(md, mf, atol=1e-7, rtol=2.0 ** -8, what="adamw m")
+    close(vd, vf, atol=1e-9, rtol=2.0 ** -8, what="adamw v")
+    out = torch.zeros(1, device=DEV)
+    ops().sumsq_(g.to(DEV), out)
+    assert abs(out.item() - (g.float() ** 2).sum().item()) <= 1e-4 * out.item()
+
+
+# ------------------------------------------------------------------------------------------------------ block
+@pytest.mark.parametrize("C,H,T", [(128, 2, 64), (256, 2, 77), (1024, 8, 128)])
+@pytest.mark.parametrize("mode", ["complex", "cos_only"])
+def test_block_fwd_bwd_vs_oracle(C, H, T, mode):
+    B = 2
+    hs = C // H
+    cfg = R.RefConfig(block_size=T, vocab_size=256, n_layer=1, n_head=H, n_embd=C)
+    w = {k: v.to(BF) for k, v in R.hash_weights(cfg).items()}
+    pre = "transformer.h.0."
+    names = ["ln_1.weight", "attn.c_attn.weight", "attn.c_proj.weight", "ln_2.weight", "mlp.c_fc.weight", "mlp.c_proj.weight"]
+    x, dy = rnd(B, T, C, seed=1), rnd(B, T, C, seed=2, scale=0.1)
+    tokens = np.random.default_rng(3).integers(20, 100, size=(B, T))
+    tokens[0, T // 2] = R.EOS_TOKEN
+    dense, ranges = _blocks_to_masks(tokens, T)
+    tab = R.rope_table(hs, T)
+    if mode == "cos_only":
+        tab = R.cast_rope_table(tab, BF)
+    # oracle in fp32 arithmetic on the bf16-valued parameters
+    wf = {k: v.float().requires_grad_(True) for k, v in w.items()}
+    xf = x.float().requires_grad_(True)
+    ref = R.block_forward(xf, wf, pre, cfg, tab, dense.unsqueeze(1))
+    ref.backward(dy.float())
+    from omnibiote_amd.model import rope_tables
+    o = ops()
+    params = tuple(w[pre + n].to(DEV) for n in names)
+    rope = rope_tables(tab.to(DEV))
+    spec = o.MaskSpec(ranges=ranges.to(DEV))
+    y, act = o.block_fwd(x.to(DEV), params, rope, H, spec)
+    close(y, ref, atol=3e-2, rtol=2.0 ** -6, what="block fwd")
+    dx, grads = o.block_bwd(x.to(DEV), dy.to(DEV), act, params, rope, H, spec)
+    close(dx, xf.grad, atol=2e-2, rtol=2.0 ** -5, what="block dx")
+    for n, g in zip(names, grads):
+        gr = wf[pre + n].grad
+        tol = 0.03 * gr.abs().max().item() + 1e-3
+        close(g, gr, atol=tol, rtol=2.0 ** -5, what="block d" + n)

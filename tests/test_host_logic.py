@@ -1,0 +1,178 @@
+"""CPU tests of the host-side logic: the mask builder against the reference's golden masks and the oracle, the
+drop-in class surface, the muP stand-ins, and the C-ABI library's symbol table."""
+import ctypes
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import omnibiote_ref as R
+from omnibiote_amd import _lib, masks, mup_compat
+from omnibiote_amd.model import OmniBioTA, OmniBioTAConfig, precompute_freqs_cis, rope_tables
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_range_mask_builder_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "attention_masks.npz"))
+    for n in sorted({k.split("/")[0] for k in g.files}):
+        tok, padding, allowed = torch.from_numpy(g[n + "/tokens"]), bool(g[n + "/padding"]), g[n + "/allowed"]
+        rm = masks.RangeMask.from_tokens(tok, padding=padding)
+        dense = rm.dense(torch.float32)
+        np.testing.assert_array_equal((dense == 0).numpy(), allowed, err_msg=n)
+        assert set(np.unique(dense.numpy()).tolist()) <= {0.0, -1e9}
+        # in-place, signature-compatible builder
+        am = torch.ones(allowed.shape, dtype=torch.float32) * -1e9
+        out = masks.create_attention_mask(am, tok, padding=padding)
+        assert out is am
+        np.testing.assert_array_equal((am == 0).numpy(), allowed, err_msg=n)
+        # round trip dense -> ranges -> dense
+        back = masks.RangeMask.from_dense(dense.unsqueeze(1).expand(-1, 3, -1, -1))
+        np.testing.assert_array_equal((back.dense(torch.float32) == 0).numpy(), allowed, err_msg=n)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_range_mask_builder_random_vs_oracle(seed):
+    rng = np.random.default_rng(seed)
+    B, T = int(rng.integers(1, 6)), int(rng.integers(4, 70))
+    tok = rng.integers(4, 30, size=(B, T))
+    tok[rng.random((B, T)) < 0.12] = R.EOS_TOKEN
+    for padding in (False, True):
+        blocks = R.document_blocks(tok, padding=padding)
+        want = (R.dense_mask_from_blocks(blocks, T) == 0).numpy()
+        got = (masks.RangeMask.from_tokens(torch.from_numpy(tok), padding=padding).dense(torch.float32) == 0).numpy()
+        np.testing.assert_array_equal(got, want)
+
+
+def test_from_dense_rejects_non_block_masks():
+    m = torch.full((1, 4, 4), -1e9)
+    m[0, 0, 0] = 0; m[0, 0, 2] = 0
+    with pytest.raises(ValueError):
+        masks.RangeMask.from_dense(m)
+
+
+def make_cfg(**kw):
+    c = OmniBioTAConfig()
+    c.flash = True
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def test_class_surface_and_state_dict_keys():
+    c = OmniBioTAConfig()
+    assert (c.block_size, c.vocab_size, c.n_layer, c.n_head, c.n_embd, c.dropout, c.bias, c.autoregressive,
+            c.checkpoint_freq) == (2048, 65536, 12, 12, 1024, 0.1, False, False, 0)
+    c.n_head = 8
+    with pytest.raises(AttributeError):   # no `flash` field: callers set it ad hoc (train_encoder.py:152)
+        OmniBioTA(c)
+    cfg = make_cfg(block_size=32, vocab_size=128, n_layer=2, n_head=2, n_embd=128, dropout=0.0)
+    m = OmniBioTA(cfg)
+    want = ["transformer.wte.weight"]
+    for i in range(2):
+        p = f"transformer.h.{i}."
+        want += [p + "ln_1.weight", p + "attn.freqs_cis", p + "attn.c_attn.weight", p + "attn.c_proj.weight",
+                 p + "ln_2.weight", p + "mlp.c_fc.weight", p + "mlp.c_proj.weight"]
+    want += ["transformer.ln_f.weight", "lm_head.weight"]
+    assert list(m.state_dict().keys()) == want
+    assert [n for n, _ in m.named_parameters()] == R.param_names(2)
+    assert m.state_dict()["transformer.h.0.attn.freqs_cis"].dtype == torch.complex64
+    assert m.transformer.h[0].attn.n_head == 2 and m.transformer.h[0].attn.n_embd == 128
+    assert m.get_num_params() == sum(p.numel() for p in m.parameters()) - 128 * 128
+    assert m.get_num_params(non_embedding=False) == sum(p.numel() for p in m.parameters())
+    cfg.flash = False
+    m2 = OmniBioTA(cfg)
+    assert "transformer.h.0.attn.bias" in m2.state_dict()   # the reference's extra tril buffer (model.py:95)
+    # mutate-and-reuse the same config object for the muP base/delta models (train_encoder.py:158-164)
+    cfg.flash = True
+    cfg.n_embd, cfg.n_head = 24, 3
+    base = OmniBioTA(cfg)
+    cfg.n_embd, cfg.n_head = 48, 12
+    delta = OmniBioTA(cfg)
+    assert base.lm_head.weight.shape == (128, 24) and delta.transformer.h[0].attn.c_attn.weight.shape == (144, 48)
+
+
+def test_constructor_rng_order_matches_reference_layout():
+    """Same parameter creation order as the reference => same weights from the same seed (wte N(0,1), then per
+    block c_attn, attn.c_proj, c_fc, mlp.c_proj kaiming-uniform, then lm_head)."""
+    cfg = make_cfg(block_size=16, vocab_size=64, n_layer=1, n_head=2, n_embd=128, dropout=0.0)
+    torch.manual_seed(5)
+    m = OmniBioTA(cfg)
+    torch.manual_seed(5)
+    wte = torch.nn.Embedding(64, 128)
+    c_attn = torch.nn.Linear(128, 384, bias=False)
+    assert torch.equal(m.transformer.wte.weight, wte.weight)
+    assert torch.equal(m.transformer.h[0].attn.c_attn.weight, c_attn.weight)
+
+
+def test_module_behaviour_to_deepcopy_pickle_and_loud_cpu_failure():
+    import copy
+    cfg = make_cfg(block_size=16, vocab_size=64, n_layer=1, n_head=2, n_embd=128, dropout=0.0)
+    m = OmniBioTA(cfg)
+    m2 = copy.deepcopy(m)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert torch.equal(m3.lm_head.weight, m.lm_head.weight) and torch.equal(m2.lm_head.weight, m.lm_head.weight)
+    m3.load_state_dict(m.state_dict())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 4, dtype=torch.long))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.encode(torch.zeros(1, 4, dtype=torch.long))
+    with pytest.raises(AssertionError):
+        m(torch.zeros(1, 17, dtype=torch.long))   # T > block_size
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.to(torch.bfloat16)
+    f = m.transformer.h[0].attn.freqs_cis
+    assert f.dtype == torch.bfloat16 and not f.is_complex()   # cos only after the cast
+    cos, sin = rope_tables(f)
+    assert float(sin.abs().max()) == 0.0
+    want = R.cast_rope_table(R.rope_table(64, 16), torch.bfloat16).float()
+    assert torch.equal(cos, want)
+    cos_c, sin_c = rope_tables(precompute_freqs_cis(64, 16))
+    assert torch.equal(cos_c, R.rope_table(64, 16).real) and torch.equal(sin_c, R.rope_table(64, 16).imag)
+
+
+def test_mup_standins_width_mult_and_groups():
+    cfg = make_cfg(block_size=16, vocab_size=64, n_layer=1, n_head=2, n_embd=128, dropout=0.0)
+    m = OmniBioTA(cfg)
+    w0 = m.lm_head.weight.detach().clone()
+    with pytest.raises(AssertionError):
+        m.lm_head.width_mult()   # set_base_shapes not called yet
+    cfg.n_embd, cfg.n_head = 24, 3
+    base = OmniBioTA(cfg)
+    cfg.n_embd, cfg.n_head = 48, 12
+    delta = OmniBioTA(cfg)
+    mup_compat.set_base_shapes(m, base, delta=delta)
+    wm = 128 / 24
+    assert abs(m.lm_head.width_mult() - wm) < 1e-9
+    torch.testing.assert_close(m.lm_head.weight, w0 * wm ** 0.5)
+    opt = mup_compat.MuAdamW(m.parameters(), lr=0.01, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-8)
+    assert len(opt.param_groups) == 2
+    mat, vec = opt.param_groups
+    assert abs(mat["lr"] - 0.01 / wm) < 1e-12 and abs(mat["weight_decay"] - 0.01 * wm) < 1e-12
+    assert vec["lr"] == 0.01 and vec["weight_decay"] == 0.01
+    assert {tuple(p.shape) for p in mat["params"]} == {(384, 128), (128, 128), (512, 128), (128, 512)}
+    assert sum(p.numel() for p in vec["params"]) == 64 * 128 * 2 + 3 * 128
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.lib()
+    assert lib.obte_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "omnibiote_hip.h")).read()
+    declared = set(re.findall(r"\b(obte_[a-z0-9_]+)\s*\(", header))
+    declared -= {"obte_stream"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in the header but not exported"
+    # argument validation happens on the host, before any launch (no GPU needed): NULL descriptor -> EINVAL
+    assert lib.obte_gemm_bf16(None, None) == -1
+    assert b"null" in lib.obte_last_error()
