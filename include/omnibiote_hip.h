@@ -32,6 +32,15 @@ enum {
 int obte_abi_version(void);
 const char* obte_last_error(void);
 
+/* ---- opt-in launch profiler (measurement only; off by default) ----------------------------------------------
+ * While enabled, every obte_gemm_bf16 / obte_attn_fwd / obte_attn_bwd call is bracketed by two hipEvents on the
+ * caller's stream.  obte_profile_collect synchronises those events and returns up to cap records:
+ * ms[i] = elapsed milliseconds, dims[3*i..] = (M,N,K) for a GEMM or (B*H, T, head_dim) for attention,
+ * kind[i] = a_kmajor*8 + b_kmajor*4 + epilogue for a GEMM, 100 = attention forward, 101 = attention backward.
+ * Returns the number of records written (records are cleared). */
+int obte_profile_enable(int on);
+int obte_profile_collect(double* ms, int64_t* dims, int32_t* kind, int cap);
+
 /* ---- LayerNorm, weight only, eps inside (training/model.py:63-72; F.layer_norm) ------------------------- */
 /* y = (x-mean)*rstd*w ; saves mean,rstd (fp32, one per row) for backward.  cols % 8 == 0, cols <= 4096. */
 int obte_layernorm_fwd(const obte_bf16* x, const obte_bf16* w, obte_bf16* y, float* mean, float* rstd,

@@ -53,6 +53,8 @@ EPI_NONE, EPI_GELU, EPI_ADD, EPI_GELU_BWD = 0, 1, 2, 3
 SYMBOLS = {
     "obte_abi_version": (C.c_int, []),
     "obte_last_error": (C.c_char_p, []),
+    "obte_profile_enable": (C.c_int, [C.c_int]),
+    "obte_profile_collect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "obte_layernorm_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_float, c_stream]),
     "obte_layernorm_bwd_ws_rows": (C.c_int, []),
     "obte_layernorm_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, c_stream]),

@@ -674,7 +674,10 @@ extern "C" int obte_attn_fwd(const obte_attn_fwd_args* a, obte_stream s) {
     p.key_ranges = a->key_ranges; p.mask = (const bf16*)a->mask; p.mask_sb = a->mask_sb; p.mask_sh = a->mask_sh; p.mask_sq = a->mask_sq;
     p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
     const int mode = mask_mode(a->key_ranges, a->mask);
-    return a->head_dim == 128 ? launch_fwd<128>(p, mode, (hipStream_t)s) : launch_fwd<64>(p, mode, (hipStream_t)s);
+    const int prof = obte_prof_begin((hipStream_t)s, 100, a->B * a->n_head, a->T, a->head_dim);
+    rc = a->head_dim == 128 ? launch_fwd<128>(p, mode, (hipStream_t)s) : launch_fwd<64>(p, mode, (hipStream_t)s);
+    obte_prof_end(prof, (hipStream_t)s);
+    return rc;
 }
 
 extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
@@ -689,5 +692,8 @@ extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
     p.key_ranges = a->key_ranges; p.mask = (const bf16*)a->mask; p.mask_sb = a->mask_sb; p.mask_sh = a->mask_sh; p.mask_sq = a->mask_sq;
     p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
     const int mode = mask_mode(a->key_ranges, a->mask);
-    return a->head_dim == 128 ? launch_bwd<128>(p, mode, (hipStream_t)s) : launch_bwd<64>(p, mode, (hipStream_t)s);
+    const int prof = obte_prof_begin((hipStream_t)s, 101, a->B * a->n_head, a->T, a->head_dim);
+    rc = a->head_dim == 128 ? launch_bwd<128>(p, mode, (hipStream_t)s) : launch_bwd<64>(p, mode, (hipStream_t)s);
+    obte_prof_end(prof, (hipStream_t)s);
+    return rc;
 }

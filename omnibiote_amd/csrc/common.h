@@ -37,6 +37,10 @@ void obte_set_error(const char* fmt, ...);
         }                                                                                 \
     } while (0)
 
+// opt-in launch profiler (lib.cpp); idx < 0 = profiling off
+int obte_prof_begin(hipStream_t st, int kind, int64_t d0, int64_t d1, int64_t d2);
+void obte_prof_end(int idx, hipStream_t st);
+
 // ---- bf16 <-> f32 -----------------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }  // v_cvt_pk_bf16_f32: RNE, NaN-preserving

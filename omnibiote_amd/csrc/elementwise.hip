@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void masked_ce_kernel(const bf16* __restrict__
         m = mn;
     }
     const float wm = wave_max(m);
-    l = wave_sum(l * __expf(m - wm));
+    l = wave_sum(m == -INFINITY ? 0.f : l * __expf(m - wm));   // threads (or whole waves) without elements hold -inf
     if (lane == 0) { red[wave] = wm; red[4 + wave] = l; }
     __syncthreads();
     const float bm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));

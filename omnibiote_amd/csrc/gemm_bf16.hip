@@ -242,8 +242,12 @@ extern "C" int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s) {
     p.tiles_m = (int)tm; p.tiles_n = (int)tn;
     p.alpha = g->alpha;
     hipStream_t st = (hipStream_t)s;
-    if (g->a_kmajor && g->b_kmajor) return dispatch_epi<true, true>(p, g->epilogue, st);
-    if (g->a_kmajor && !g->b_kmajor) return dispatch_epi<true, false>(p, g->epilogue, st);
-    if (!g->a_kmajor && g->b_kmajor) return dispatch_epi<false, true>(p, g->epilogue, st);
-    return dispatch_epi<false, false>(p, g->epilogue, st);
+    const int prof = obte_prof_begin(st, (g->a_kmajor ? 8 : 0) + (g->b_kmajor ? 4 : 0) + g->epilogue, g->M, g->N, g->K);
+    int rc;
+    if (g->a_kmajor && g->b_kmajor) rc = dispatch_epi<true, true>(p, g->epilogue, st);
+    else if (g->a_kmajor && !g->b_kmajor) rc = dispatch_epi<true, false>(p, g->epilogue, st);
+    else if (!g->a_kmajor && g->b_kmajor) rc = dispatch_epi<false, true>(p, g->epilogue, st);
+    else rc = dispatch_epi<false, false>(p, g->epilogue, st);
+    obte_prof_end(prof, st);
+    return rc;
 }

@@ -13,3 +13,58 @@ void obte_set_error(const char* fmt, ...) {
 
 extern "C" const char* obte_last_error(void) { return g_err; }
 extern "C" int obte_abi_version(void) { return 1; }
+
+// ---- opt-in launch profiler ---------------------------------------------------------------------------------
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; int64_t d0, d1, d2; int kind; bool closed; };
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+bool g_prof_on = false;
+}
+
+int obte_prof_begin(hipStream_t st, int kind, int64_t d0, int64_t d1, int64_t d2) {
+    if (!g_prof_on) return -1;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r{};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+    r.d0 = d0; r.d1 = d1; r.d2 = d2; r.kind = kind; r.closed = false;
+    (void)hipEventRecord(r.a, st);
+    g_prof.push_back(r);
+    return (int)g_prof.size() - 1;
+}
+
+void obte_prof_end(int idx, hipStream_t st) {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (idx >= (int)g_prof.size()) return;
+    (void)hipEventRecord(g_prof[idx].b, st);
+    g_prof[idx].closed = true;
+}
+
+extern "C" int obte_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return OBTE_OK;
+}
+
+extern "C" int obte_profile_collect(double* ms, int64_t* dims, int32_t* kind, int cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0;
+    for (auto& r : g_prof) {
+        if (r.closed && n < cap) {
+            float t = 0.f;
+            (void)hipEventSynchronize(r.b);
+            if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+                ms[n] = t; dims[3 * n] = r.d0; dims[3 * n + 1] = r.d1; dims[3 * n + 2] = r.d2; kind[n] = r.kind;
+                ++n;
+            }
+        }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return n;
+}
