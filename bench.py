@@ -52,6 +52,7 @@ def parse():
     p.add_argument("--multi_document", action="store_true", help="rows with interior EOS (block-diagonal masks)")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
+    p.add_argument("--shapes_out", default="", help="write the per-shape launch table (from the profiler step) to this file")
     return p.parse_args()
 
 
@@ -205,6 +206,17 @@ def main():
         _lib.lib().obte_profile_enable(0)
         if len(ms):
             roofline = roofline_from_profile(ms, dims, kind, 1)
+            if a.shapes_out:
+                tab = {}
+                for t, d, k in zip(ms, dims, kind):
+                    key = (KIND_NAMES.get(int(k), str(int(k))), int(d[0]), int(d[1]), int(d[2]))
+                    e = tab.setdefault(key, [0, 0.0])
+                    e[0] += 1; e[1] += float(t)
+                with open(a.shapes_out, "w") as f:
+                    f.write(f"{'kernel':28s} {'d0':>7s} {'d1':>7s} {'d2':>7s} {'calls':>6s} {'avg_us':>9s} {'TFLOP/s':>8s} {'ms/step':>8s}\n")
+                    for (name, d0, d1, d2), (n, tt) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
+                        fl = 2.0 * d0 * d1 * d2 if not name.startswith("attn") else 4.0 * d0 * d1 * d1 * d2 * (1.0 if name == "attn_fwd" else 2.5)
+                        f.write(f"{name:28s} {d0:7d} {d1:7d} {d2:7d} {n:6d} {tt / n * 1e3:9.1f} {fl * n / (tt * 1e-3) / 1e12:8.1f} {tt:8.2f}\n")
     if world > 1:
         dist.barrier()
 

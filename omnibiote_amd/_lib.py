@@ -90,6 +90,10 @@ def lib():
         return _lib
     with _lock:
         if _lib is None:
+            # PyTorch-ROCm ships its own libamdhip64; load it first so that this library binds to the SAME HIP
+            # runtime instance that owns torch's streams and allocations (two runtimes in one process do not
+            # share devices, streams or pointers).
+            import torch  # noqa: F401
             if not os.path.exists(LIB_PATH):
                 raise HipLibraryError(f"{LIB_PATH} not found: the HIP library has not been built "
                                       "(make -C omnibiote_amd/csrc). There is no CPU fallback.")
