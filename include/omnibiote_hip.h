@@ -78,6 +78,12 @@ typedef struct {
     float alpha;
 } obte_gemm_args;
 int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s);
+/* Same, with a caller-owned scratch buffer that enables split-K (fp32 partial tiles summed in a fixed order by a
+ * second kernel) when the output has too few tiles to fill 256 CUs — the weight-gradient shapes.
+ * obte_gemm_workspace_bytes returns the size that lets the library split as it prefers (0 = no split wanted);
+ * a NULL or smaller workspace simply disables the split.  Split-K needs epilogue NONE and ldd == N. */
+int64_t obte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64_t workspace_bytes, obte_stream s);
 
 /* ---- RoPE on the q and k thirds of a packed qkv activation, in place (training/model.py:39-50,108) ------
  * qkv: [rows = B*T, 3*C]; pairs (2j,2j+1) of each head; position = row % T.  cos/sin: fp32 [T, hs/2].

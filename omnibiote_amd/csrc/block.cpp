@@ -31,7 +31,7 @@ struct ActLayout {
 };
 
 struct WsLayout {
-    int64_t dhpre, dh, dx1, dyattn, dqkv, delta, lnws, total;
+    int64_t dhpre, dh, dx1, dyattn, dqkv, delta, lnws, gemmws, gemmws_bytes, total;
     WsLayout(int64_t B, int64_t T, int C, int H) {
         const int64_t M = B * T;
         int64_t o = 0;
@@ -43,17 +43,24 @@ struct WsLayout {
         dqkv = take(M * 3 * C * 2);
         delta = take(B * H * T * 4);
         lnws = take((int64_t)obte_layernorm_bwd_ws_rows() * C * 4);
+        gemmws_bytes = 0;
+        const int64_t shapes[4][2] = {{C, 4 * C}, {4 * C, C}, {C, C}, {3 * C, C}};   // the four weight gradients
+        for (auto& sh : shapes) {
+            const int64_t b = obte_gemm_workspace_bytes(sh[0], sh[1], M);
+            if (b > gemmws_bytes) gemmws_bytes = b;
+        }
+        gemmws = take(gemmws_bytes > 0 ? gemmws_bytes : 256);
         total = o;
     }
 };
 
 int gemm(const obte_bf16* a, const obte_bf16* b, obte_bf16* d, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-         int ak, int bk, int epi, const obte_bf16* aux, obte_bf16* d2, obte_stream s) {
+         int ak, int bk, int epi, const obte_bf16* aux, obte_bf16* d2, obte_stream s, void* ws = nullptr, int64_t ws_bytes = 0) {
     obte_gemm_args g = {};
     g.a = a; g.b = b; g.d = d; g.aux = aux; g.d2 = d2;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldd = N;
     g.a_kmajor = ak; g.b_kmajor = bk; g.epilogue = epi; g.alpha = 1.0f;
-    return obte_gemm_bf16(&g, s);
+    return obte_gemm_bf16_ws(&g, ws, ws_bytes, s);
 }
 
 int check_desc(const char* who, const obte_block_desc* d) {
@@ -125,16 +132,17 @@ extern "C" int obte_block_bwd(const obte_block_desc* d, const obte_bf16* x, cons
     obte_bf16 *dhpre = (obte_bf16*)(S + W.dhpre), *dh = (obte_bf16*)(S + W.dh), *dx1 = (obte_bf16*)(S + W.dx1),
               *dyattn = (obte_bf16*)(S + W.dyattn), *dqkv = (obte_bf16*)(S + W.dqkv);
     float *delta = (float*)(S + W.delta), *lnws = (float*)(S + W.lnws);
+    void* gws = W.gemmws_bytes > 0 ? (void*)(S + W.gemmws) : nullptr;
 
     // MLP: out = x1 + hact W_mlp^T
     TRY(gemm(dy, d->mlp_w, dhpre, M, 4 * C, C, C, 4 * C, 1, 0, OBTE_EPI_GELU_BWD, hpre, nullptr, s));          // dhpre = (dy W_mlp) * gelu'(hpre)
-    TRY(gemm(dy, hact, dmlp_w, C, 4 * C, M, C, 4 * C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s));               // dW_mlp = dy^T hact
+    TRY(gemm(dy, hact, dmlp_w, C, 4 * C, M, C, 4 * C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_mlp = dy^T hact
     TRY(gemm(dhpre, d->fc_w, dh, M, C, 4 * C, 4 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh2 = dhpre W_fc
-    TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, M, 4 * C, C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s));               // dW_fc = dhpre^T h2
+    TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, M, 4 * C, C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_fc = dhpre^T h2
     TRY(obte_layernorm_bwd(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, lnws, M, C, s));                     // dx1 = dy + LN2'(dh2)
     // attention: x1 = x + y W_proj^T
     TRY(gemm(dx1, d->proj_w, dyattn, M, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));                  // dy_attn = dx1 W_proj
-    TRY(gemm(dx1, yat, dproj_w, C, C, M, C, C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s));                       // dW_proj = dx1^T y
+    TRY(gemm(dx1, yat, dproj_w, C, C, M, C, C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s, gws, W.gemmws_bytes));                       // dW_proj = dx1^T y
     obte_attn_bwd_args ab = {};
     ab.qkv = qkv; ab.o = yat; ab.d_o = dyattn; ab.lse = lse; ab.delta = delta; ab.dqkv = dqkv;
     ab.rope_cos = d->rope_cos; ab.rope_sin = d->rope_sin;
@@ -142,7 +150,7 @@ extern "C" int obte_block_bwd(const obte_block_desc* d, const obte_bf16* x, cons
     ab.B = d->B; ab.T = d->T; ab.n_head = H; ab.head_dim = hs; ab.scale = 8.0f / (float)C;
     TRY(obte_attn_bwd(&ab, s));
     TRY(gemm(dqkv, d->attn_w, dh, M, C, 3 * C, 3 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh1 = dqkv W_attn
-    TRY(gemm(dqkv, h1, dattn_w, 3 * C, C, M, 3 * C, C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s));               // dW_attn = dqkv^T h1
+    TRY(gemm(dqkv, h1, dattn_w, 3 * C, C, M, 3 * C, C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_attn = dqkv^T h1
     TRY(obte_layernorm_bwd(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, lnws, M, C, s));                      // dx = dx1 + LN1'(dh1)
     return OBTE_OK;
 }

@@ -1,3 +1,4 @@
+// bf16 GEMM, first structure (kept selectable with OBTE_GEMM=v1 for A/B runs; the default is gemm_bf16_v2.hip).
 // bf16 GEMM on CDNA4 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate, bf16 output with fused epilogues.
 //
 // Replaces the nn.Linear calls of the reference's block and readout (training/model.py:102,151,163,166,253)
@@ -217,7 +218,7 @@ int dispatch_epi(const GemmParams& p, int epi, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s) {
+int obte_gemm_bf16_v1(const obte_gemm_args* g, obte_stream s) {
     OBTE_REQUIRE(g && g->a && g->b && g->d, "obte_gemm_bf16: null pointer");
     OBTE_REQUIRE(g->M > 0 && g->N > 0 && g->K > 0, "obte_gemm_bf16: empty problem M=%lld N=%lld K=%lld",
                  (long long)g->M, (long long)g->N, (long long)g->K);
@@ -242,12 +243,8 @@ extern "C" int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s) {
     p.tiles_m = (int)tm; p.tiles_n = (int)tn;
     p.alpha = g->alpha;
     hipStream_t st = (hipStream_t)s;
-    const int prof = obte_prof_begin(st, (g->a_kmajor ? 8 : 0) + (g->b_kmajor ? 4 : 0) + g->epilogue, g->M, g->N, g->K);
-    int rc;
-    if (g->a_kmajor && g->b_kmajor) rc = dispatch_epi<true, true>(p, g->epilogue, st);
-    else if (g->a_kmajor && !g->b_kmajor) rc = dispatch_epi<true, false>(p, g->epilogue, st);
-    else if (!g->a_kmajor && g->b_kmajor) rc = dispatch_epi<false, true>(p, g->epilogue, st);
-    else rc = dispatch_epi<false, false>(p, g->epilogue, st);
-    obte_prof_end(prof, st);
-    return rc;
+    if (g->a_kmajor && g->b_kmajor) return dispatch_epi<true, true>(p, g->epilogue, st);
+    if (g->a_kmajor && !g->b_kmajor) return dispatch_epi<true, false>(p, g->epilogue, st);
+    if (!g->a_kmajor && g->b_kmajor) return dispatch_epi<false, true>(p, g->epilogue, st);
+    return dispatch_epi<false, false>(p, g->epilogue, st);
 }

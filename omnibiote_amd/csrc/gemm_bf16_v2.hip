@@ -1,0 +1,359 @@
+// bf16 GEMM on CDNA4 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate, bf16 output with fused epilogues.
+// Second structure (default): 256x128 output tile per 512-thread workgroup, three LDS stages, loads two K-tiles
+// ahead.
+//
+// Replaces the nn.Linear calls of the reference's block and readout (training/model.py:102,151,163,166,253)
+// in all three passes: forward (A,B k-contiguous), dgrad (B k-strided), wgrad (A and B k-strided).
+//
+// Why this shape: the first structure (128x128, two stages, vmcnt(0) + barrier per K-step) measured ~3000 cycles
+// per K-step against 512 cycles of MFMA work per wave — every step waited for its own LDS-DMA round trip.  Here
+//   * 8 waves (4 along M x 2 along N, 64x64 each) share one 256x128 tile: two waves per SIMD, one workgroup per CU;
+//   * the LDS ring holds three K-tiles (3 x 48 KiB); tile t+2 is issued right after the barrier that opens
+//     step t, so each LDS-DMA piece has two full steps (>= 2 x 1024 MFMA cycles per SIMD) to land;
+//   * the only wait in the loop is a COUNTED s_waitcnt vmcnt(6) (= the six pieces of tile t+1 stay in flight)
+//     followed by a raw s_barrier — never vmcnt(0), never __syncthreads() (whose fence would drain the DMA);
+//   * all LDS lives in one extern array (a second __shared__ object makes hipcc drain vmcnt before ds_reads).
+// LDS images and swizzles (bank-conflict-free fragment reads; LDS-DMA writes linearly, so the permutation is
+// applied to each lane's SOURCE address and again on the read):
+//   k-contiguous operand : [rows][64 k], 128-B rows, 16-B chunk c of row r at c ^ ((r>>1)&7); ds_read_b128.
+//   k-strided operand    : [64 k][mn], 512-B (A) / 256-B (B) rows, chunk c of k-row r at c ^ f(r),
+//                          f(r) = ((r&3) | ((r>>3)&1)<<2) << 1; ds_read_b64_tr_b16 (hardware transpose).
+// The MFMA is issued with swapped operands (C^T tiles) so each lane holds four consecutive output columns; the
+// tile is staged through LDS and written in 16-B pieces of full 128-B row segments, applying the epilogue.
+// Split-K (for weight gradients whose output has fewer tiles than the chip has CUs): each split writes an fp32
+// partial tile to a slab; a second kernel sums the splits in a fixed order (bitwise reproducible) and rounds once.
+#include "common.h"
+
+int obte_gemm_bf16_v1(const obte_gemm_args* g, obte_stream s);
+
+namespace {
+
+constexpr int BM = 256, BN = 128, BKT = 64;
+constexpr int NTHREADS = 512;
+constexpr int A_TILE = BM * BKT * 2;            // 32 KiB
+constexpr int B_TILE = BN * BKT * 2;            // 16 KiB
+constexpr int STAGE_BYTES = A_TILE + B_TILE;    // 48 KiB
+constexpr int NSTAGE = 3;
+constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB: one workgroup per CU
+constexpr int DMA_PER_TILE = 6;                 // LDS-DMA instructions per wave per K-tile (4 for A, 2 for B)
+constexpr int EPI_LD = 144;                     // bytes per staged bf16 row: 64 bf16 + 16 B pad
+constexpr int EPI_LD_F32 = 272;                 // bytes per staged f32 row: 64 f32 + 16 B pad
+
+struct GemmParams {
+    const bf16* a; const bf16* b; bf16* d; const bf16* aux; bf16* d2; float* slab;
+    int64_t M, N, K, lda, ldb, ldd;
+    int64_t a_elems, b_elems;
+    int tiles_m, tiles_n, splits, k_per_split;   // k_per_split in K-tiles
+    float alpha;
+};
+
+__device__ __forceinline__ int kmaj_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int mn_f(int krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
+template <int ROWB>
+__device__ __forceinline__ int mnmaj_off(int krow, int chunk) { return krow * ROWB + ((chunk ^ mn_f(krow)) << 4); }
+
+// byte offsets, relative to the tile origin, of the LDS-DMA pieces this lane issues (piece = wave + 8*i)
+template <bool KMAJOR, int MN, int NP>
+__device__ __forceinline__ void dma_offsets(int wave, int lane, int64_t ld, int (&voff)[NP]) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int piece = wave + 8 * i;  // 1 KiB of the image
+        if (KMAJOR) {
+            const int row = piece * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            voff[i] = (int)((row * ld + chunk * 8) * 2);
+        } else {
+            constexpr int CPR = MN / 8;          // 16-B chunks per k-row: 32 (A) or 16 (B)
+            constexpr int RPP = 64 / CPR;        // k-rows per 1-KiB piece: 2 or 4
+            const int krow = piece * RPP + lane / CPR;
+            const int chunk = (lane % CPR) ^ mn_f(krow);
+            voff[i] = (int)((krow * ld + chunk * 8) * 2);
+        }
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void dma_tile(const bf16* origin, int64_t elems_left, const int (&voff)[NP], char* lds_tile, int wave) {
+    __amdgpu_buffer_rsrc_t rsrc = make_rsrc(origin, elems_left * 2);
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + (wave + 8 * i) * 1024), 16, voff[i], 0, 0, 0);
+}
+
+// 16 (m or n) x 32 (k) fragment for v_mfma_f32_16x16x32_bf16: lane l holds index (l&15), k = 8*(l>>4)+j.
+template <bool KMAJOR, int MN>
+__device__ __forceinline__ bf16x8 load_frag(const char* tile, int mn0, int s, int lane) {
+    if (KMAJOR) {
+        return *reinterpret_cast<const bf16x8*>(tile + kmaj_off(mn0 + (lane & 15), 4 * s + (lane >> 4)));
+    } else {
+        const int li = lane & 15;
+        const int krow = 32 * s + 8 * (lane >> 4) + (li >> 2);
+        const int chunk = (mn0 >> 3) + ((li & 3) >> 1);
+        const int sub = (li & 1) * 8;
+        const bf16x4 lo = lds_read_tr16(tile + mnmaj_off<MN * 2>(krow, chunk) + sub);
+        const bf16x4 hi = lds_read_tr16(tile + mnmaj_off<MN * 2>(krow + 4, chunk) + sub);
+        return join8(lo, hi);
+    }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPLIT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+
+    // ---- workgroup -> (tile, split): bijective XCD remap, then 8-row groups of tiles ------------------------
+    const int nwg = p.tiles_m * p.tiles_n * p.splits;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int split = wgid % p.splits;
+    const int tid_ = wgid / p.splits;
+    const int group_sz = 8 * p.tiles_n;
+    const int first_m = (tid_ / group_sz) * 8;
+    const int gsz = min(p.tiles_m - first_m, 8);
+    const int tm = first_m + (tid_ % group_sz) % gsz;
+    const int tn = (tid_ % group_sz) / gsz;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+    int voff_a[4], voff_b[2];
+    dma_offsets<A_KMAJOR, BM, 4>(wave, lane, p.lda, voff_a);
+    dma_offsets<B_KMAJOR, BN, 2>(wave, lane, p.ldb, voff_b);
+
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk_total = (int)((p.K + BKT - 1) / BKT);
+    const int kt0 = split * p.k_per_split;
+    const int nk = min(p.k_per_split, nk_total - kt0);
+
+    auto issue = [&](int t, int stage) {
+        const int64_t k0 = (int64_t)(kt0 + t) * BKT;
+        const int64_t ao = A_KMAJOR ? (m0 * p.lda + k0) : (k0 * p.lda + m0);
+        const int64_t bo = B_KMAJOR ? (n0 * p.ldb + k0) : (k0 * p.ldb + n0);
+        char* st = smem + stage * STAGE_BYTES;
+        dma_tile<4>(p.a + ao, p.a_elems - ao, voff_a, st, wave);
+        dma_tile<2>(p.b + bo, p.b_elems - bo, voff_b, st + A_TILE, wave);
+    };
+
+    if (nk > 0) issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+        // tile t has landed once at most the six pieces of tile t+1 are still in flight
+        if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // every wave has finished reading stage (t-1)%3 before it reached this barrier: refill it with tile t+2
+        if (t + 2 < nk) issue(t + 2, stage == 0 ? 2 : stage - 1);
+        const char* ta = smem + stage * STAGE_BYTES;
+        const char* tb = ta + A_TILE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KMAJOR, BM>(ta, wm * 64 + i * 16, s, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bfr[i] = load_frag<B_KMAJOR, BN>(tb, wn * 64 + i * 16, s, lane);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    // operands swapped: the accumulator holds C^T (row = n, col = m)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    __syncthreads();  // all fragment reads done (and no DMA outstanding): LDS becomes the epilogue staging area
+
+    const int em = lane & 15, en = (lane >> 4) * 4;
+    if (SPLIT) {
+        // fp32 partial tile -> slab[split][M][N]
+        char* stg = smem + wave * (64 * EPI_LD_F32);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                *reinterpret_cast<f32x4*>(stg + (mi * 16 + em) * EPI_LD_F32 + (ni * 16 + en) * 4) = acc[ni][mi];
+        __syncthreads();
+        float* out = p.slab + (int64_t)split * p.M * p.N;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 4 + (lane >> 4);
+            const int c4 = lane & 15;
+            const int64_t m = m0 + wm * 64 + row;
+            const int64_t n = n0 + wn * 64 + c4 * 4;
+            if (m < p.M && n < p.N)
+                *reinterpret_cast<f32x4*>(out + m * p.N + n) = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD_F32 + c4 * 16);
+        }
+        return;
+    }
+
+    char* stg = smem + wave * (64 * EPI_LD);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = f2bf(acc[ni][mi][r] * p.alpha);
+            *reinterpret_cast<bf16x4*>(stg + (mi * 16 + em) * EPI_LD + (ni * 16 + en) * 2) = v;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const int c8 = lane & 7;
+        const int64_t m = m0 + wm * 64 + row;
+        const int64_t n = n0 + wn * 64 + c8 * 8;
+        if (m < p.M && n < p.N) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * EPI_LD + c8 * 16);
+            const int64_t o = m * p.ldd + n;
+            if (EPI == OBTE_EPI_GELU) {
+                bf16x8 g;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = f2bf(gelu_ref(bf2f(v[j])));
+                *reinterpret_cast<bf16x8*>(p.d2 + o) = g;
+            } else if (EPI == OBTE_EPI_ADD) {
+                const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.aux + o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(r[j]) + bf2f(v[j]));
+            } else if (EPI == OBTE_EPI_GELU_BWD) {
+                const bf16x8 h = *reinterpret_cast<const bf16x8*>(p.aux + o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * gelu_ref_grad(bf2f(h[j])));
+            }
+            *reinterpret_cast<bf16x8*>(p.d + o) = v;
+        }
+    }
+}
+
+// d[m][n] = bf16(alpha * sum_s slab[s][m][n]) in split order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, bf16* __restrict__ d, int64_t MN4,
+                                                             int64_t MN, int splits, float alpha) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < MN4; i += (int64_t)gridDim.x * 256) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(slab + i * 4);
+        for (int k = 1; k < splits; ++k) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(slab + k * MN + i * 4);
+            s += t;
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f2bf(s[j] * alpha);
+        *reinterpret_cast<bf16x4*>(d + i * 4) = o;
+    }
+}
+
+template <bool AK, bool BK, int EPI, bool SPLIT>
+int launch(const GemmParams& p, hipStream_t st) {
+    static bool attr_set = false;  // idempotent; a race only repeats the call
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<AK, BK, EPI, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_v2_kernel<AK, BK, EPI, SPLIT>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(NTHREADS), SMEM_BYTES, st, p);
+    OBTE_CHECK_LAUNCH("obte_gemm_bf16");
+    return OBTE_OK;
+}
+
+template <bool AK, bool BK>
+int dispatch(const GemmParams& p, int epi, hipStream_t st) {
+    if (p.splits > 1) return launch<AK, BK, OBTE_EPI_NONE, true>(p, st);
+    switch (epi) {
+        case OBTE_EPI_NONE: return launch<AK, BK, OBTE_EPI_NONE, false>(p, st);
+        case OBTE_EPI_GELU: return launch<AK, BK, OBTE_EPI_GELU, false>(p, st);
+        case OBTE_EPI_ADD: return launch<AK, BK, OBTE_EPI_ADD, false>(p, st);
+        case OBTE_EPI_GELU_BWD: return launch<AK, BK, OBTE_EPI_GELU_BWD, false>(p, st);
+    }
+    obte_set_error("obte_gemm_bf16: unknown epilogue %d", epi);
+    return OBTE_EINVAL;
+}
+
+bool use_v1() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("OBTE_GEMM");
+        v = (e && e[0] == 'v' && e[1] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
+}  // namespace
+
+// Split-K heuristic: fill the chip when the output has few tiles and K is long.  Returns 1 when no split pays.
+static int choose_splits(int64_t tiles, int64_t nk) {
+    if (tiles >= 192 || nk < 16) return 1;
+    int s = (int)((256 + tiles - 1) / tiles);
+    while (s > 1 && nk / s < 8) --s;
+    return s < 1 ? 1 : (s > 16 ? 16 : s);
+}
+
+extern "C" int64_t obte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles = cdiv64(M, BM) * cdiv64(N, BN);
+    const int s = choose_splits(tiles, cdiv64(K, BKT));
+    return s > 1 ? (int64_t)s * M * N * 4 : 0;
+}
+
+extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64_t workspace_bytes, obte_stream s) {
+    OBTE_REQUIRE(g && g->a && g->b && g->d, "obte_gemm_bf16: null pointer");
+    OBTE_REQUIRE(g->M > 0 && g->N > 0 && g->K > 0, "obte_gemm_bf16: empty problem M=%lld N=%lld K=%lld",
+                 (long long)g->M, (long long)g->N, (long long)g->K);
+    OBTE_REQUIRE(g->lda % 8 == 0 && g->ldb % 8 == 0 && g->ldd % 8 == 0 && g->N % 8 == 0,
+                 "obte_gemm_bf16: lda/ldb/ldd/N must be multiples of 8 (16-byte rows)");
+    OBTE_REQUIRE(!(g->a_kmajor) || g->K % 64 == 0, "obte_gemm_bf16: k-contiguous A needs K %% 64 == 0 (K=%lld)", (long long)g->K);
+    OBTE_REQUIRE(!(g->b_kmajor) || g->K % 64 == 0, "obte_gemm_bf16: k-contiguous B needs K %% 64 == 0 (K=%lld)", (long long)g->K);
+    OBTE_REQUIRE(g->a_kmajor ? g->lda >= g->K : g->lda >= g->M, "obte_gemm_bf16: lda too small");
+    OBTE_REQUIRE(g->b_kmajor ? g->ldb >= g->K : g->ldb >= g->N, "obte_gemm_bf16: ldb too small");
+    OBTE_REQUIRE(g->ldd >= g->N, "obte_gemm_bf16: ldd too small");
+    OBTE_REQUIRE(g->lda <= 1 << 20 && g->ldb <= 1 << 20, "obte_gemm_bf16: leading dimension too large");
+    if (g->epilogue == OBTE_EPI_ADD || g->epilogue == OBTE_EPI_GELU_BWD) OBTE_REQUIRE(g->aux, "obte_gemm_bf16: epilogue needs aux");
+    if (g->epilogue == OBTE_EPI_GELU) OBTE_REQUIRE(g->d2, "obte_gemm_bf16: GELU epilogue needs d2");
+    if (g->epilogue != OBTE_EPI_NONE) OBTE_REQUIRE(g->alpha == 1.0f, "obte_gemm_bf16: alpha != 1 only with EPI_NONE");
+    hipStream_t st = (hipStream_t)s;
+    const int prof = obte_prof_begin(st, (g->a_kmajor ? 8 : 0) + (g->b_kmajor ? 4 : 0) + g->epilogue, g->M, g->N, g->K);
+    int rc;
+    if (use_v1()) {
+        rc = obte_gemm_bf16_v1(g, s);
+        obte_prof_end(prof, st);
+        return rc;
+    }
+    GemmParams p;
+    p.a = (const bf16*)g->a; p.b = (const bf16*)g->b; p.d = (bf16*)g->d; p.aux = (const bf16*)g->aux; p.d2 = (bf16*)g->d2;
+    p.slab = (float*)workspace;
+    p.M = g->M; p.N = g->N; p.K = g->K; p.lda = g->lda; p.ldb = g->ldb; p.ldd = g->ldd;
+    p.a_elems = (g->a_kmajor ? g->M : g->K) * g->lda;
+    p.b_elems = (g->b_kmajor ? g->N : g->K) * g->ldb;
+    const int64_t tm = cdiv64(g->M, BM), tn = cdiv64(g->N, BN);
+    OBTE_REQUIRE(tm * tn < (1ll << 26), "obte_gemm_bf16: too many tiles");
+    p.tiles_m = (int)tm; p.tiles_n = (int)tn;
+    const int64_t nk = cdiv64(g->K, BKT);
+    int splits = 1;
+    if (workspace && g->epilogue == OBTE_EPI_NONE && g->ldd == g->N) {
+        splits = choose_splits(tm * tn, nk);
+        if ((int64_t)splits * g->M * g->N * 4 > workspace_bytes) splits = 1;
+    }
+    p.k_per_split = (int)cdiv64(nk, splits);
+    p.splits = (int)cdiv64(nk, p.k_per_split);   // no empty splits
+    p.alpha = g->alpha;
+    if (g->a_kmajor && g->b_kmajor) rc = dispatch<true, true>(p, g->epilogue, st);
+    else if (g->a_kmajor && !g->b_kmajor) rc = dispatch<true, false>(p, g->epilogue, st);
+    else if (!g->a_kmajor && g->b_kmajor) rc = dispatch<false, true>(p, g->epilogue, st);
+    else rc = dispatch<false, false>(p, g->epilogue, st);
+    if (rc == OBTE_OK && p.splits > 1) {
+        const int64_t mn = g->M * g->N;
+        int64_t blocks = cdiv64(mn / 4, 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)workspace, (bf16*)g->d,
+                           mn / 4, mn, p.splits, g->alpha);
+        hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) { obte_set_error("obte_gemm_bf16(split-K reduce): %s", hipGetErrorString(e_)); rc = OBTE_ELAUNCH; }
+    }
+    obte_prof_end(prof, st);
+    return rc;
+}
+
+extern "C" int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s) { return obte_gemm_bf16_ws(g, nullptr, 0, s); }

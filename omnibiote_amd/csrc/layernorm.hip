@@ -6,7 +6,7 @@
 
 namespace {
 
-constexpr int LN_BWD_MAX_BLOCKS = 1024;
+constexpr int LN_BWD_MAX_BLOCKS = 512;
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
@@ -131,16 +131,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         ws[(int64_t)blockIdx.x * cols + c] = red[c] + red[cols + c] + red[2 * cols + c] + red[3 * cols + c];
 }
 
+// dw[c] = sum over the per-workgroup partial rows; 32 columns x 8 row-groups per workgroup, 128-B row segments.
 __global__ __launch_bounds__(256) void ln_dw_reduce_kernel(const float* __restrict__ ws, bf16* __restrict__ dw, int nblk, int cols) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    float s = 0.f;
-    if (c < cols)
-        for (int b = part; b < nblk; b += 4) s += ws[(int64_t)b * cols + c];
-    red[part][cl] = s;
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < cols) {
+        int b = part;
+        for (; b + 24 < nblk; b += 32) {
+            s0 += ws[(int64_t)b * cols + c];
+            s1 += ws[(int64_t)(b + 8) * cols + c];
+            s2 += ws[(int64_t)(b + 16) * cols + c];
+            s3 += ws[(int64_t)(b + 24) * cols + c];
+        }
+        for (; b < nblk; b += 8) s0 += ws[(int64_t)b * cols + c];
+    }
+    red[part][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (part == 0 && c < cols) dw[c] = f2bf(red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+    if (part == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][cl];
+        dw[c] = f2bf(t);
+    }
 }
 
 int nch_for(int cols) {
@@ -203,7 +217,7 @@ extern "C" int obte_layernorm_bwd(const obte_bf16* dy, const obte_bf16* x, const
     }
 #undef LN_BWD
     OBTE_CHECK_LAUNCH("obte_layernorm_bwd");
-    hipLaunchKernelGGL(ln_dw_reduce_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, (const float*)ws, (bf16*)dw, nblk, cols);
+    hipLaunchKernelGGL(ln_dw_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, (const float*)ws, (bf16*)dw, nblk, cols);
     OBTE_CHECK_LAUNCH("obte_layernorm_bwd(dw reduce)");
     return OBTE_OK;
 }

@@ -363,3 +363,42 @@ def test_block_fwd_bwd_vs_oracle(C, H, T, mode):
         gr = wf[pre + n].grad
         tol = 0.03 * gr.abs().max().item() + 1e-3
         close(g, gr, atol=tol, rtol=2.0 ** -5, what="block d" + n)
+
+
+# ------------------------------------------------------------------------------ GEMM: split-K and big-tile paths
+@pytest.mark.parametrize("M,N,K", [(1024, 1024, 2048), (384, 256, 4096), (256, 128, 8192), (3072, 1024, 1100)])
+def test_gemm_wgrad_split_k(M, N, K):
+    """Weight-gradient shapes with few output tiles and a long token dimension take the split-K path (fp32 slabs
+    + fixed-order reduce): same answer, bitwise reproducible."""
+    assert L().lib().obte_gemm_workspace_bytes(M, N, K) > 0
+    dy, x = rnd(K, M, seed=21, scale=0.5), rnd(K, N, seed=22, scale=0.5)
+    ref = dy.float().t() @ x.float()
+    got = ops().linear_wgrad(dy.to(DEV), x.to(DEV))
+    close(got, ref, atol=0.01 * math.sqrt(K), what="gemm TN split-K")
+    assert torch.equal(got, ops().linear_wgrad(dy.to(DEV), x.to(DEV)))
+
+
+def test_gemm_long_k_and_many_tiles():
+    """Ring wrap-around over many K-tiles (3-stage ring, loads two tiles ahead) and a multi-tile grid."""
+    M, N, K = 520, 392, 4096
+    x, w = rnd(M, K, seed=31, scale=0.3), rnd(N, K, seed=32, scale=0.3)
+    close(ops().linear_fwd(x.to(DEV), w.to(DEV)), x.float() @ w.float().t(), atol=0.02 * math.sqrt(K) * 0.09, what="long K NT")
+    dy, w2 = rnd(M, K, seed=33, scale=0.3), rnd(K, N, seed=34, scale=0.3)
+    close(ops().linear_dgrad(dy.to(DEV), w2.to(DEV)), dy.float() @ w2.float(), atol=0.02 * math.sqrt(K) * 0.09, what="long K NN")
+
+
+def test_gemm_linearity_full_size():
+    """BASELINE config-2 sized forward GEMM (8192 x 3072 x 1024): f(x1 + x2) == f(x1) + f(x2) up to bf16 rounding of
+    the outputs, and exact agreement with a row subsample of the fp32 reference."""
+    M, N, K = 8192, 3072, 1024
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x1 = torch.randn(M, K, device=DEV, generator=g).to(BF)
+    x2 = (torch.randn(M, K, device=DEV, generator=g) * 0.5).to(BF)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.03).to(BF)
+    xs = (x1.float() + x2.float()).to(BF)
+    y = ops().linear_fwd(xs, w).float()
+    y12 = ops().linear_fwd(x1, w).float() + ops().linear_fwd(x2, w).float()
+    assert (y - y12).abs().max().item() <= 0.06
+    rows = torch.arange(0, M, 257, device=DEV)
+    ref = xs[rows].float() @ w.float().t()
+    close(y[rows], ref, atol=0.02, what="full-size rows")
