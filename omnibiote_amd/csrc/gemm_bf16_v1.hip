@@ -19,7 +19,7 @@
 // Workgroup ids are remapped so that each XCD (own L2) works on a compact 8 x n group of tiles.
 #include "common.h"
 
-namespace {
+namespace obte_gemm_v1 {
 
 constexpr int BM = 128, BN = 128, BKT = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;      // one operand tile
@@ -216,7 +216,8 @@ int dispatch_epi(const GemmParams& p, int epi, hipStream_t st) {
     return OBTE_EINVAL;
 }
 
-}  // namespace
+}  // namespace obte_gemm_v1
+using namespace obte_gemm_v1;
 
 int obte_gemm_bf16_v1(const obte_gemm_args* g, obte_stream s) {
     OBTE_REQUIRE(g && g->a && g->b && g->d, "obte_gemm_bf16: null pointer");

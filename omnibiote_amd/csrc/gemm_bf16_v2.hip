@@ -26,7 +26,7 @@
 
 int obte_gemm_bf16_v1(const obte_gemm_args* g, obte_stream s);
 
-namespace {
+namespace obte_gemm_v2 {
 
 constexpr int BM = 256, BN = 128, BKT = 64;
 constexpr int NTHREADS = 512;
@@ -282,7 +282,8 @@ bool use_v1() {
     return v == 1;
 }
 
-}  // namespace
+}  // namespace obte_gemm_v2
+using namespace obte_gemm_v2;
 
 // Split-K heuristic: fill the chip when the output has few tiles and K is long.  Returns 1 when no split pays.
 static int choose_splits(int64_t tiles, int64_t nk) {
