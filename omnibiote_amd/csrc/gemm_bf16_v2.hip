@@ -232,6 +232,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
     }
 }
 
+// Explicit instantiations: with implicit instantiation alone hipcc (ROCm 7.2) emitted the host stub of only the
+// first specialisation it met; the library then failed to load with undefined kernel symbols.
+#define OBTE_INST(AK, BK)                                                                    \
+    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_NONE, true>(GemmParams);        \
+    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_NONE, false>(GemmParams);       \
+    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_GELU, false>(GemmParams);       \
+    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_ADD, false>(GemmParams);        \
+    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_GELU_BWD, false>(GemmParams);
+OBTE_INST(true, true)
+OBTE_INST(true, false)
+OBTE_INST(false, true)
+OBTE_INST(false, false)
+#undef OBTE_INST
+
 // d[m][n] = bf16(alpha * sum_s slab[s][m][n]) in split order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, bf16* __restrict__ d, int64_t MN4,
                                                              int64_t MN, int splits, float alpha) {
