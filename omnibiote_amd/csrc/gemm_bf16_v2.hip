@@ -28,15 +28,22 @@ int obte_gemm_bf16_v1(const obte_gemm_args* g, obte_stream s);
 
 namespace obte_gemm_v2 {
 
-constexpr int BM = 256, BN = 128, BKT = 64;
+constexpr int BM = 256, BKT = 64;
 constexpr int NTHREADS = 512;
 constexpr int A_TILE = BM * BKT * 2;            // 32 KiB
-constexpr int B_TILE = BN * BKT * 2;            // 16 KiB
-constexpr int STAGE_BYTES = A_TILE + B_TILE;    // 48 KiB
-constexpr int NSTAGE = 3;
-constexpr int SMEM_BYTES = NSTAGE * STAGE_BYTES;  // 144 KiB: one workgroup per CU
-constexpr int DMA_PER_TILE = 6;                 // LDS-DMA instructions per wave per K-tile (4 for A, 2 for B)
-constexpr int EPI_LD = 144;                     // bytes per staged bf16 row: 64 bf16 + 16 B pad
+// Two tile widths.  BN = 128: 48 KiB per stage, 3-stage ring (loads two K-tiles ahead) — used where the grid
+// would otherwise not fill the chip (N = 1024 outputs).  BN = 256: 64 KiB per stage, two stages — 131 FLOP per
+// loaded byte instead of 87; a CU pulls ~70 GB/s from its L2 and ~25-30 GB/s from beyond it (measured), and at
+// ~8 TFLOP/s per CU a 256x128 tile needs 94 GB/s: the wide tile is what keeps the MFMAs fed.
+template <int BN> struct Cfg {
+    static constexpr int B_TILE = BN * BKT * 2;
+    static constexpr int STAGE = A_TILE + B_TILE;
+    static constexpr int NSTAGE = BN == 128 ? 3 : 2;
+    static constexpr int EPI_BYTES = 8 * 64 * 272;       // epilogue staging: 8 waves x 64 rows x (<=128 bf16 | 64 f32, + pad)
+    static constexpr int SMEM = NSTAGE * STAGE > EPI_BYTES ? NSTAGE * STAGE : EPI_BYTES;   // 144 KiB / 136 KiB: one workgroup per CU
+    static constexpr int NPB = BN / 64;                  // LDS-DMA pieces per wave for the B tile (A: 4)
+    static constexpr int NJ = BN / 32;                   // 16-wide n sub-tiles per wave (wave tile 64 x BN/2)
+};
 constexpr int EPI_LD_F32 = 272;                 // bytes per staged f32 row: 64 f32 + 16 B pad
 
 struct GemmParams {
@@ -96,8 +103,10 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, int mn0, int s, in
     }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPLIT>
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPLIT, int BN>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
+    using CF = Cfg<BN>;
+    constexpr int NJ = CF::NJ, NPB = CF::NPB, STAGE_BYTES = CF::STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -115,15 +124,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
     const int tm = first_m + (tid_ % group_sz) % gsz;
     const int tn = (tid_ % group_sz) / gsz;
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    constexpr int NW = BN / 2;   // wave tile width
 
-    int voff_a[4], voff_b[2];
+    int voff_a[4], voff_b[NPB];
     dma_offsets<A_KMAJOR, BM, 4>(wave, lane, p.lda, voff_a);
-    dma_offsets<B_KMAJOR, BN, 2>(wave, lane, p.ldb, voff_b);
+    dma_offsets<B_KMAJOR, BN, NPB>(wave, lane, p.ldb, voff_b);
 
     const int wm = wave >> 1, wn = wave & 1;
-    f32x4 acc[4][4];
+    f32x4 acc[NJ][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NJ; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -137,81 +147,97 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
         const int64_t bo = B_KMAJOR ? (n0 * p.ldb + k0) : (k0 * p.ldb + n0);
         char* st = smem + stage * STAGE_BYTES;
         dma_tile<4>(p.a + ao, p.a_elems - ao, voff_a, st, wave);
-        dma_tile<2>(p.b + bo, p.b_elems - bo, voff_b, st + A_TILE, wave);
+        dma_tile<NPB>(p.b + bo, p.b_elems - bo, voff_b, st + A_TILE, wave);
     };
 
     if (nk > 0) issue(0, 0);
-    if (nk > 1) issue(1, 1);
+    if (CF::NSTAGE == 3 && nk > 1) issue(1, 1);
     int stage = 0;
     for (int t = 0; t < nk; ++t) {
-        // tile t has landed once at most the six pieces of tile t+1 are still in flight
-        if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // every wave has finished reading stage (t-1)%3 before it reached this barrier: refill it with tile t+2
-        if (t + 2 < nk) issue(t + 2, stage == 0 ? 2 : stage - 1);
+        if (CF::NSTAGE == 3) {
+            // tile t has landed once at most the six pieces of tile t+1 are still in flight
+            if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // every wave has finished reading stage (t-1)%3 before it reached this barrier: refill it with tile t+2
+            if (t + 2 < nk) issue(t + 2, stage == 0 ? 2 : stage - 1);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 1 < nk) issue(t + 1, stage ^ 1);   // the stage read during step t-1
+        }
         const char* ta = smem + stage * STAGE_BYTES;
         const char* tb = ta + A_TILE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 af[4], bfr[4];
+            bf16x8 af[4], bfr[NJ];
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KMAJOR, BM>(ta, wm * 64 + i * 16, s, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bfr[i] = load_frag<B_KMAJOR, BN>(tb, wn * 64 + i * 16, s, lane);
+            for (int i = 0; i < NJ; ++i) bfr[i] = load_frag<B_KMAJOR, BN>(tb, wn * (BN / 2) + i * 16, s, lane);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < NJ; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     // operands swapped: the accumulator holds C^T (row = n, col = m)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
         }
-        stage = stage == 2 ? 0 : stage + 1;
+        if (CF::NSTAGE == 3) stage = stage == 2 ? 0 : stage + 1;
+        else stage ^= 1;
     }
     __syncthreads();  // all fragment reads done (and no DMA outstanding): LDS becomes the epilogue staging area
 
     const int em = lane & 15, en = (lane >> 4) * 4;
     if (SPLIT) {
         // fp32 partial tile -> slab[split][M][N]
+        // 64 columns at a time through a per-wave fp32 staging area (8 x 17 KiB fits both tile widths)
         char* stg = smem + wave * (64 * EPI_LD_F32);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-                *reinterpret_cast<f32x4*>(stg + (mi * 16 + em) * EPI_LD_F32 + (ni * 16 + en) * 4) = acc[ni][mi];
-        __syncthreads();
         float* out = p.slab + (int64_t)split * p.M * p.N;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int row = it * 4 + (lane >> 4);
-            const int c4 = lane & 15;
-            const int64_t m = m0 + wm * 64 + row;
-            const int64_t n = n0 + wn * 64 + c4 * 4;
-            if (m < p.M && n < p.N)
-                *reinterpret_cast<f32x4*>(out + m * p.N + n) = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD_F32 + c4 * 16);
+        for (int half = 0; half < NJ / 4; ++half) {
+            if (half) __syncthreads();
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    *reinterpret_cast<f32x4*>(stg + (mi * 16 + em) * EPI_LD_F32 + (ni * 16 + en) * 4) = acc[half * 4 + ni][mi];
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 4 + (lane >> 4);
+                const int c4 = lane & 15;
+                const int64_t m = m0 + wm * 64 + row;
+                const int64_t n = n0 + wn * NW + half * 64 + c4 * 4;
+                if (m < p.M && n < p.N)
+                    *reinterpret_cast<f32x4*>(out + m * p.N + n) = *reinterpret_cast<const f32x4*>(stg + row * EPI_LD_F32 + c4 * 16);
+            }
         }
         return;
     }
 
-    char* stg = smem + wave * (64 * EPI_LD);
+    // staged row: NW bf16 + 16 B pad (144 B for the 64-wide wave tile, 272 B for the 128-wide one)
+    constexpr int LDE = NW * 2 + 16;
+    constexpr int CPRE = NW / 8;            // 16-B chunks per staged row
+    constexpr int RPI = 64 / CPRE;          // rows covered by one wave-wide 16-B access
+    char* stg = smem + wave * (64 * LDE);
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+    for (int ni = 0; ni < NJ; ++ni)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             bf16x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = f2bf(acc[ni][mi][r] * p.alpha);
-            *reinterpret_cast<bf16x4*>(stg + (mi * 16 + em) * EPI_LD + (ni * 16 + en) * 2) = v;
+            *reinterpret_cast<bf16x4*>(stg + (mi * 16 + em) * LDE + (ni * 16 + en) * 2) = v;
         }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int row = it * 8 + (lane >> 3);
-        const int c8 = lane & 7;
+    for (int it = 0; it < 64 / RPI; ++it) {
+        const int row = it * RPI + lane / CPRE;
+        const int c8 = lane % CPRE;
         const int64_t m = m0 + wm * 64 + row;
-        const int64_t n = n0 + wn * 64 + c8 * 8;
+        const int64_t n = n0 + wn * NW + c8 * 8;
         if (m < p.M && n < p.N) {
-            bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * EPI_LD + c8 * 16);
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * LDE + c8 * 16);
             const int64_t o = m * p.ldd + n;
             if (EPI == OBTE_EPI_GELU) {
                 bf16x8 g;
@@ -234,16 +260,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
 
 // Explicit instantiations: with implicit instantiation alone hipcc (ROCm 7.2) emitted the host stub of only the
 // first specialisation it met; the library then failed to load with undefined kernel symbols.
-#define OBTE_INST(AK, BK)                                                                    \
-    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_NONE, true>(GemmParams);        \
-    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_NONE, false>(GemmParams);       \
-    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_GELU, false>(GemmParams);       \
-    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_ADD, false>(GemmParams);        \
-    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_GELU_BWD, false>(GemmParams);
-OBTE_INST(true, true)
-OBTE_INST(true, false)
-OBTE_INST(false, true)
-OBTE_INST(false, false)
+#define OBTE_INST(AK, BK, BN)                                                                    \
+    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_NONE, true, BN>(GemmParams);        \
+    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_NONE, false, BN>(GemmParams);       \
+    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_GELU, false, BN>(GemmParams);       \
+    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_ADD, false, BN>(GemmParams);        \
+    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_GELU_BWD, false, BN>(GemmParams);
+OBTE_INST(true, true, 128)
+OBTE_INST(true, false, 128)
+OBTE_INST(false, true, 128)
+OBTE_INST(false, false, 128)
+OBTE_INST(true, true, 256)
+OBTE_INST(true, false, 256)
+OBTE_INST(false, true, 256)
+OBTE_INST(false, false, 256)
 #undef OBTE_INST
 
 // d[m][n] = bf16(alpha * sum_s slab[s][m][n]) in split order
@@ -262,29 +292,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <bool AK, bool BK, int EPI, bool SPLIT>
+template <bool AK, bool BK, int EPI, bool SPLIT, int BN>
 int launch(const GemmParams& p, hipStream_t st) {
     static bool attr_set = false;  // idempotent; a race only repeats the call
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<AK, BK, EPI, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<AK, BK, EPI, SPLIT, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<BN>::SMEM);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_v2_kernel<AK, BK, EPI, SPLIT>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(NTHREADS), SMEM_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_v2_kernel<AK, BK, EPI, SPLIT, BN>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(NTHREADS), Cfg<BN>::SMEM, st, p);
     OBTE_CHECK_LAUNCH("obte_gemm_bf16");
     return OBTE_OK;
 }
 
-template <bool AK, bool BK>
-int dispatch(const GemmParams& p, int epi, hipStream_t st) {
-    if (p.splits > 1) return launch<AK, BK, OBTE_EPI_NONE, true>(p, st);
+template <bool AK, bool BK, int BN>
+int dispatch_bn(const GemmParams& p, int epi, hipStream_t st) {
+    if (p.splits > 1) return launch<AK, BK, OBTE_EPI_NONE, true, BN>(p, st);
     switch (epi) {
-        case OBTE_EPI_NONE: return launch<AK, BK, OBTE_EPI_NONE, false>(p, st);
-        case OBTE_EPI_GELU: return launch<AK, BK, OBTE_EPI_GELU, false>(p, st);
-        case OBTE_EPI_ADD: return launch<AK, BK, OBTE_EPI_ADD, false>(p, st);
-        case OBTE_EPI_GELU_BWD: return launch<AK, BK, OBTE_EPI_GELU_BWD, false>(p, st);
+        case OBTE_EPI_NONE: return launch<AK, BK, OBTE_EPI_NONE, false, BN>(p, st);
+        case OBTE_EPI_GELU: return launch<AK, BK, OBTE_EPI_GELU, false, BN>(p, st);
+        case OBTE_EPI_ADD: return launch<AK, BK, OBTE_EPI_ADD, false, BN>(p, st);
+        case OBTE_EPI_GELU_BWD: return launch<AK, BK, OBTE_EPI_GELU_BWD, false, BN>(p, st);
     }
     obte_set_error("obte_gemm_bf16: unknown epilogue %d", epi);
     return OBTE_EINVAL;
+}
+
+template <bool AK, bool BK>
+int dispatch(const GemmParams& p, int epi, int bn, hipStream_t st) {
+    return bn == 256 ? dispatch_bn<AK, BK, 256>(p, epi, st) : dispatch_bn<AK, BK, 128>(p, epi, st);
 }
 
 bool use_v1() {
@@ -299,18 +334,34 @@ bool use_v1() {
 }  // namespace obte_gemm_v2
 using namespace obte_gemm_v2;
 
-// Split-K heuristic: fill the chip when the output has few tiles and K is long.  Returns 1 when no split pays.
-static int choose_splits(int64_t tiles, int64_t nk) {
-    if (tiles >= 192 || nk < 16) return 1;
+// Tile width and split-K plan.  Prefer the 256-wide tile (higher FLOP per loaded byte) whenever it still yields
+// at least one workgroup per CU, directly or through a split of a long K; otherwise the 128-wide tile.
+// Split-K needs a workspace, epilogue NONE and ldd == N.
+struct Plan { int bn; int splits; };
+static int splits_for(int64_t tiles, int64_t nk) {
+    if (tiles >= 200 || nk < 16) return 1;
     int s = (int)((256 + tiles - 1) / tiles);
     while (s > 1 && nk / s < 8) --s;
     return s < 1 ? 1 : (s > 16 ? 16 : s);
 }
+static Plan make_plan(int64_t M, int64_t N, int64_t K, bool can_split) {
+    const int64_t nk = cdiv64(K, BKT);
+    const int64_t tm = cdiv64(M, BM);
+    const char* force = getenv("OBTE_GEMM_BN");
+    int bn = 0;
+    if (force) bn = atoi(force) == 256 ? 256 : 128;
+    if (!bn) {
+        const int64_t t256 = tm * cdiv64(N, 256);
+        const int s256 = can_split ? splits_for(t256, nk) : 1;
+        bn = (N >= 256 && t256 * s256 >= 200) ? 256 : 128;
+    }
+    const int64_t tiles = tm * cdiv64(N, bn);
+    return Plan{bn, can_split ? splits_for(tiles, nk) : 1};
+}
 
 extern "C" int64_t obte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-    const int64_t tiles = cdiv64(M, BM) * cdiv64(N, BN);
-    const int s = choose_splits(tiles, cdiv64(K, BKT));
-    return s > 1 ? (int64_t)s * M * N * 4 : 0;
+    const Plan pl = make_plan(M, N, K, true);
+    return pl.splits > 1 ? (int64_t)pl.splits * M * N * 4 : 0;
 }
 
 extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64_t workspace_bytes, obte_stream s) {
@@ -342,22 +393,21 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     p.M = g->M; p.N = g->N; p.K = g->K; p.lda = g->lda; p.ldb = g->ldb; p.ldd = g->ldd;
     p.a_elems = (g->a_kmajor ? g->M : g->K) * g->lda;
     p.b_elems = (g->b_kmajor ? g->N : g->K) * g->ldb;
-    const int64_t tm = cdiv64(g->M, BM), tn = cdiv64(g->N, BN);
+    const bool can_split = workspace && g->epilogue == OBTE_EPI_NONE && g->ldd == g->N;
+    Plan pl = make_plan(g->M, g->N, g->K, can_split);
+    if (pl.splits > 1 && (int64_t)pl.splits * g->M * g->N * 4 > workspace_bytes) pl = make_plan(g->M, g->N, g->K, false);
+    const int64_t tm = cdiv64(g->M, BM), tn = cdiv64(g->N, pl.bn);
     OBTE_REQUIRE(tm * tn < (1ll << 26), "obte_gemm_bf16: too many tiles");
     p.tiles_m = (int)tm; p.tiles_n = (int)tn;
     const int64_t nk = cdiv64(g->K, BKT);
-    int splits = 1;
-    if (workspace && g->epilogue == OBTE_EPI_NONE && g->ldd == g->N) {
-        splits = choose_splits(tm * tn, nk);
-        if ((int64_t)splits * g->M * g->N * 4 > workspace_bytes) splits = 1;
-    }
+    const int splits = pl.splits;
     p.k_per_split = (int)cdiv64(nk, splits);
     p.splits = (int)cdiv64(nk, p.k_per_split);   // no empty splits
     p.alpha = g->alpha;
-    if (g->a_kmajor && g->b_kmajor) rc = dispatch<true, true>(p, g->epilogue, st);
-    else if (g->a_kmajor && !g->b_kmajor) rc = dispatch<true, false>(p, g->epilogue, st);
-    else if (!g->a_kmajor && g->b_kmajor) rc = dispatch<false, true>(p, g->epilogue, st);
-    else rc = dispatch<false, false>(p, g->epilogue, st);
+    if (g->a_kmajor && g->b_kmajor) rc = dispatch<true, true>(p, g->epilogue, pl.bn, st);
+    else if (g->a_kmajor && !g->b_kmajor) rc = dispatch<true, false>(p, g->epilogue, pl.bn, st);
+    else if (!g->a_kmajor && g->b_kmajor) rc = dispatch<false, true>(p, g->epilogue, pl.bn, st);
+    else rc = dispatch<false, false>(p, g->epilogue, pl.bn, st);
     if (rc == OBTE_OK && p.splits > 1) {
         const int64_t mn = g->M * g->N;
         int64_t blocks = cdiv64(mn / 4, 256);

@@ -402,3 +402,33 @@ def test_gemm_linearity_full_size():
     rows = torch.arange(0, M, 257, device=DEV)
     ref = xs[rows].float() @ w.float().t()
     close(y[rows], ref, atol=0.02, what="full-size rows")
+
+
+@pytest.mark.parametrize("bn", ["128", "256"])
+def test_gemm_both_tile_widths(monkeypatch, bn):
+    """Every layout, epilogue and the split-K path on both tile widths (the library picks per shape; here forced)."""
+    monkeypatch.setenv("OBTE_GEMM_BN", bn)
+    o = ops()
+    for (M, N, K) in [(520, 392, 256), (256, 256, 128), (300, 1024, 1024)]:
+        x, w = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=0.2)
+        close(o.linear_fwd(x.to(DEV), w.to(DEV)), x.float() @ w.float().t(), atol=0.02 * math.sqrt(K) * 0.2, what=f"NT bn{bn}")
+        dy, w2 = rnd(M, K, seed=43), rnd(K, N, seed=44, scale=0.2)
+        close(o.linear_dgrad(dy.to(DEV), w2.to(DEV)), dy.float() @ w2.float(), atol=0.02 * math.sqrt(K) * 0.2, what=f"NN bn{bn}")
+    for (M, N, K) in [(384, 520, 300), (1024, 1024, 2048), (256, 264, 77)]:
+        dy, xx = rnd(K, M, seed=45, scale=0.5), rnd(K, N, seed=46, scale=0.5)
+        close(o.linear_wgrad(dy.to(DEV), xx.to(DEV)), dy.float().t() @ xx.float(), atol=0.01 * math.sqrt(K), what=f"TN bn{bn}")
+    # identity checks: exact
+    eye = torch.eye(256).to(BF)
+    b = (torch.arange(512 * 256).reshape(512, 256) % 251 - 125).float().to(BF)
+    assert torch.equal(o.linear_fwd(eye.to(DEV), b.to(DEV)).cpu().float(), b.float().t())
+    assert torch.equal(o.linear_dgrad(eye.to(DEV), b.t().contiguous().to(DEV)).cpu().float(), b.float().t())
+    assert torch.equal(o.linear_wgrad(eye.to(DEV), b.t().contiguous().to(DEV)).cpu().float(), b.float().t())
+    # epilogues
+    M, N, K = 300, 512, 128
+    x, w, r = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=0.2), rnd(M, N, seed=9)
+    acc = x.float() @ w.float().t()
+    close(o.linear_fwd(x.to(DEV), w.to(DEV), epilogue=L().EPI_ADD, aux=r.to(DEV)), r.float() + acc.to(BF).float(), atol=0.03, what="add")
+    d, d2 = o.linear_fwd(x.to(DEV), w.to(DEV), epilogue=L().EPI_GELU)
+    close(d, acc, atol=0.03, what="gelu pre")
+    close(d2, R.gelu_erf(d.float().cpu()), atol=1e-3, rtol=2.0 ** -8, what="gelu act")
+    close(o.linear_fwd(x.to(DEV), w.to(DEV), alpha=1 / 42.0), acc / 42.0, atol=2e-3, what="alpha")
