@@ -165,6 +165,8 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         m = TE.build_model(h, dev)
     n_params = m.get_num_params()
+    from omnibiote_amd import tune
+    tune.tune_model_shapes(a.mini_batch_size * cfg["ctx_len"], cfg["n_embd"], 2 ** 16, device=dev, verbose=(rank == 0 and bool(a.shapes_out)))
     model = TE.wrap_ddp(m, local) if world > 1 else m
     total_iters = 1000
     opt, sched = TE.build_optimizer(m, h, total_iters)

@@ -84,6 +84,15 @@ int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s);
  * a NULL or smaller workspace simply disables the split.  Split-K needs epilogue NONE and ldd == N. */
 int64_t obte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64_t workspace_bytes, obte_stream s);
+/* Tuned plans.  The library holds two GEMM structures (1: 128x128 tiles, two workgroups per CU; 2: 256x128 or
+ * 256x256 tiles, one workgroup per CU, optional split-K); which is fastest depends on the shape (tile quantisation
+ * against 256 CUs, K length, where the operands are served from).  A host-side tuner times the candidates once per
+ * (layout, epilogue, M, N, K) and records the winner here; unknown shapes fall back to a built-in heuristic.
+ * obte_gemm_workspace_bytes_max: a workspace size that admits any recordable plan. */
+int obte_gemm_plan_set(int a_kmajor, int b_kmajor, int epilogue, int64_t M, int64_t N, int64_t K, int variant, int bn,
+                       int splits);
+int obte_gemm_plan_clear(void);
+int64_t obte_gemm_workspace_bytes_max(int64_t M, int64_t N, int64_t K);
 
 /* ---- RoPE on the q and k thirds of a packed qkv activation, in place (training/model.py:39-50,108) ------
  * qkv: [rows = B*T, 3*C]; pairs (2j,2j+1) of each head; position = row % T.  cos/sin: fp32 [T, hs/2].

@@ -61,6 +61,9 @@ SYMBOLS = {
     "obte_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), c_stream]),
     "obte_gemm_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "obte_gemm_bf16_ws": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_int64, c_stream]),
+    "obte_gemm_plan_set": (C.c_int, [C.c_int] * 3 + [C.c_int64] * 3 + [C.c_int] * 3),
+    "obte_gemm_plan_clear": (C.c_int, []),
+    "obte_gemm_workspace_bytes_max": (C.c_int64, [C.c_int64] * 3),
     "obte_rope_qk_inplace": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, c_stream]),
     "obte_attn_fwd": (C.c_int, [C.POINTER(AttnFwdArgs), c_stream]),
     "obte_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), c_stream]),

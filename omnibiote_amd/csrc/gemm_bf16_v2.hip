@@ -337,7 +337,7 @@ using namespace obte_gemm_v2;
 // Tile width and split-K plan.  Prefer the 256-wide tile (higher FLOP per loaded byte) whenever it still yields
 // at least one workgroup per CU, directly or through a split of a long K; otherwise the 128-wide tile.
 // Split-K needs a workspace, epilogue NONE and ldd == N.
-struct Plan { int bn; int splits; };
+struct Plan { int bn; int splits; int variant; };   // variant: 1 = first structure (gemm_bf16_v1.hip), 2 = this file
 static int splits_for(int64_t tiles, int64_t nk) {
     if (tiles >= 200 || nk < 16) return 1;
     int s = (int)((256 + tiles - 1) / tiles);
@@ -356,13 +356,58 @@ static Plan make_plan(int64_t M, int64_t N, int64_t K, bool can_split) {
         bn = (N >= 256 && t256 * s256 >= 200) ? 256 : 128;
     }
     const int64_t tiles = tm * cdiv64(N, bn);
-    return Plan{bn, can_split ? splits_for(tiles, nk) : 1};
+    return Plan{bn, can_split ? splits_for(tiles, nk) : 1, 2};
 }
 
-extern "C" int64_t obte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-    const Plan pl = make_plan(M, N, K, true);
-    return pl.splits > 1 ? (int64_t)pl.splits * M * N * 4 : 0;
+// ---- tuned plans: (layout, epilogue, M, N, K) -> plan, filled by the host-side tuner (omnibiote_amd/tune.py), which
+// times the candidates on the actual device once per shape.  Lookups are per call, under a mutex.
+#include <map>
+#include <mutex>
+#include <tuple>
+typedef std::tuple<int, int, int64_t, int64_t, int64_t> PlanKey;
+static std::mutex g_plan_mu;
+static std::map<PlanKey, Plan> g_plans;
+static bool lookup_plan(const obte_gemm_args* g, Plan* out) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plans.find(PlanKey((g->a_kmajor ? 2 : 0) + (g->b_kmajor ? 1 : 0), g->epilogue, g->M, g->N, g->K));
+    if (it == g_plans.end()) return false;
+    *out = it->second;
+    return true;
 }
+
+extern "C" int obte_gemm_plan_set(int a_kmajor, int b_kmajor, int epilogue, int64_t M, int64_t N, int64_t K, int variant,
+                                  int bn, int splits) {
+    OBTE_REQUIRE((variant == 1 || variant == 2) && (bn == 128 || bn == 256) && splits >= 1 && splits <= 64, "obte_gemm_plan_set: bad plan");
+    OBTE_REQUIRE(!(variant == 1 && splits != 1), "obte_gemm_plan_set: the first structure has no split-K");
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    g_plans[PlanKey((a_kmajor ? 2 : 0) + (b_kmajor ? 1 : 0), epilogue, M, N, K)] = Plan{bn, splits, variant};
+    return OBTE_OK;
+}
+extern "C" int obte_gemm_plan_clear(void) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    g_plans.clear();
+    return OBTE_OK;
+}
+extern "C" int64_t obte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+    int splits = make_plan(M, N, K, true).splits;
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        bool tuned = false;
+        int ts = 1;
+        for (auto& kv : g_plans)
+            if (std::get<2>(kv.first) == M && std::get<3>(kv.first) == N && std::get<4>(kv.first) == K) {
+                tuned = true;
+                if (kv.second.splits > ts) ts = kv.second.splits;
+            }
+        if (tuned) splits = ts;
+    }
+    return splits > 1 ? (int64_t)splits * M * N * 4 : 0;
+}
+extern "C" int64_t obte_gemm_workspace_bytes_max(int64_t M, int64_t N, int64_t K) {
+    (void)K;
+    return 8 * M * N * 4;   // enough for any plan the tuner tries (splits <= 8)
+}
+
 
 extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64_t workspace_bytes, obte_stream s) {
     OBTE_REQUIRE(g && g->a && g->b && g->d, "obte_gemm_bf16: null pointer");
@@ -382,7 +427,11 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     hipStream_t st = (hipStream_t)s;
     const int prof = obte_prof_begin(st, (g->a_kmajor ? 8 : 0) + (g->b_kmajor ? 4 : 0) + g->epilogue, g->M, g->N, g->K);
     int rc;
-    if (use_v1()) {
+    const bool can_split = workspace && g->epilogue == OBTE_EPI_NONE && g->ldd == g->N;
+    Plan pl;
+    if (!lookup_plan(g, &pl)) pl = make_plan(g->M, g->N, g->K, can_split);
+    if (pl.splits > 1 && (!can_split || (int64_t)pl.splits * g->M * g->N * 4 > workspace_bytes)) pl = make_plan(g->M, g->N, g->K, false);
+    if (use_v1() || pl.variant == 1) {
         rc = obte_gemm_bf16_v1(g, s);
         obte_prof_end(prof, st);
         return rc;
@@ -393,9 +442,6 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     p.M = g->M; p.N = g->N; p.K = g->K; p.lda = g->lda; p.ldb = g->ldb; p.ldd = g->ldd;
     p.a_elems = (g->a_kmajor ? g->M : g->K) * g->lda;
     p.b_elems = (g->b_kmajor ? g->N : g->K) * g->ldb;
-    const bool can_split = workspace && g->epilogue == OBTE_EPI_NONE && g->ldd == g->N;
-    Plan pl = make_plan(g->M, g->N, g->K, can_split);
-    if (pl.splits > 1 && (int64_t)pl.splits * g->M * g->N * 4 > workspace_bytes) pl = make_plan(g->M, g->N, g->K, false);
     const int64_t tm = cdiv64(g->M, BM), tn = cdiv64(g->N, pl.bn);
     OBTE_REQUIRE(tm * tn < (1ll << 26), "obte_gemm_bf16: too many tiles");
     p.tiles_m = (int)tm; p.tiles_n = (int)tn;

@@ -84,7 +84,7 @@ def gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True, epilogue=L.EPI_NONE, aux=N
         _need(aux, "aux"); assert aux.numel() == M * N
     g = L.GemmArgs(_ptr(a), _ptr(b), _ptr(d), _ptr(aux), _ptr(d2), M, N, K, lda, ldb, N,
                    int(a_kmajor), int(b_kmajor), epilogue, float(alpha))
-    ws_bytes = int(L.lib().obte_gemm_workspace_bytes(M, N, K)) if epilogue == L.EPI_NONE else 0
+    ws_bytes = int(L.lib().obte_gemm_workspace_bytes(M, N, K)) if (epilogue == L.EPI_NONE and M * N <= (1 << 23)) else 0
     if ws_bytes > 0:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
         L.check(L.lib().obte_gemm_bf16_ws(C.byref(g), _ptr(ws), ws_bytes, _stream()), "obte_gemm_bf16_ws")

@@ -319,6 +319,8 @@ def run(args):
     torch.manual_seed(1234)   # identical initial weights on every rank (DDP broadcasts rank 0's anyway)
     m = build_model(args, device)
     n_params = m.get_num_params()
+    from . import tune
+    tune.tune_model_shapes(args.mini_batch_size * args.ctx_len, args.n_embd, 2 ** 16, device=device, verbose=(rank == 0))
     model = wrap_ddp(m, local) if world > 1 else m
     total_iters = int(args.token_budget / (world * batch_size * args.ctx_len))
     opt, sched = build_optimizer(m, args, total_iters)

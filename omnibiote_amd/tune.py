@@ -1,0 +1,96 @@
+"""GEMM plan tuner: measure, don't guess.
+
+The library holds two GEMM structures and several tile/split choices (include/omnibiote_hip.h, "Tuned plans").
+Which one is fastest for a shape depends on tile quantisation against 256 CUs, on K, and on where the operands
+are served from — the measured spread on the small config is up to 2x per shape.  ``tune_model_shapes`` times every
+candidate once per GEMM shape of the training step on the actual device (HIP events on the launch stream, random
+data) and records the winner in the library's plan table; it is called once at start-up (bench.py, the harness).
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+_done: Dict[tuple, tuple] = {}
+
+
+def _time_once(a, b, M, N, K, ak, bk, epi, aux, out, reps=3) -> float:
+    ops.gemm(a, b, M, N, K, ak, bk, epi, aux, out=out)
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.gemm(a, b, M, N, K, ak, bk, epi, aux, out=out)
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+
+
+def candidates(M: int, N: int, K: int, epi: int) -> List[Tuple[int, int, int]]:
+    """(variant, bn, splits)."""
+    c = [(1, 128, 1), (2, 128, 1)]
+    if N >= 256:
+        c.append((2, 256, 1))
+    nk = (K + 63) // 64
+    if epi == L.EPI_NONE and M * N * 4 * 8 <= (1 << 28):   # split-K only for small outputs (weight gradients)
+        for bn in (128, 256):
+            if bn == 256 and N < 256:
+                continue
+            tiles = ((M + 255) // 256) * ((N + bn - 1) // bn)
+            for s in (2, 3, 4, 5, 6, 8):
+                if nk // s >= 8 and tiles * s <= 1024:
+                    c.append((2, bn, s))
+    return c
+
+
+def tune_gemm(M: int, N: int, K: int, a_kmajor: bool, b_kmajor: bool, epi: int = L.EPI_NONE, device="cuda", verbose=False):
+    key = (M, N, K, a_kmajor, b_kmajor, epi)
+    if key in _done:
+        return _done[key]
+    lib = L.lib()
+    g = torch.Generator(device=device).manual_seed(0)
+    a = torch.randn(M * K, device=device, generator=g).to(torch.bfloat16)
+    b = torch.randn(N * K, device=device, generator=g).to(torch.bfloat16)
+    aux = torch.randn(M * N, device=device, generator=g).to(torch.bfloat16) if epi in (L.EPI_ADD, L.EPI_GELU_BWD) else None
+    out = torch.empty(M * N, device=device, dtype=torch.bfloat16)
+    results = []
+    for (variant, bn, splits) in candidates(M, N, K, epi):
+        L.check(lib.obte_gemm_plan_set(int(a_kmajor), int(b_kmajor), epi, M, N, K, variant, bn, splits), "obte_gemm_plan_set")
+        results.append((_time_once(a, b, M, N, K, a_kmajor, b_kmajor, epi, aux, out), variant, bn, splits))
+    results.sort()
+    t, variant, bn, splits = results[0]
+    L.check(lib.obte_gemm_plan_set(int(a_kmajor), int(b_kmajor), epi, M, N, K, variant, bn, splits), "obte_gemm_plan_set")
+    _done[key] = (variant, bn, splits, t)
+    if verbose:
+        tf = 2.0 * M * N * K / (t * 1e-3) / 1e12
+        print(f"tune M={M} N={N} K={K} {'k' if a_kmajor else 'm'}{'k' if b_kmajor else 'n'} epi={epi}: "
+              f"structure {variant} bn={bn} splits={splits}  {t * 1e3:.1f} us  {tf:.0f} TFLOP/s   "
+              f"(others: {[(v, n, s, round(x * 1e3)) for x, v, n, s in results[1:4]]})", flush=True)
+    return _done[key]
+
+
+def model_gemm_shapes(rows: int, n_embd: int, vocab: int):
+    """Every GEMM of one training micro-step: (M, N, K, a_kmajor, b_kmajor, epilogue)."""
+    M, C, V = rows, n_embd, vocab
+    E = L
+    return [
+        (M, 3 * C, C, True, True, E.EPI_NONE), (M, C, C, True, True, E.EPI_ADD), (M, 4 * C, C, True, True, E.EPI_GELU),
+        (M, C, 4 * C, True, True, E.EPI_ADD), (M, V, C, True, True, E.EPI_NONE),
+        (M, 4 * C, C, True, False, E.EPI_GELU_BWD), (M, C, 4 * C, True, False, E.EPI_NONE), (M, C, C, True, False, E.EPI_NONE),
+        (M, C, 3 * C, True, False, E.EPI_NONE), (M, C, V, True, False, E.EPI_NONE),
+        (C, 4 * C, M, False, False, E.EPI_NONE), (4 * C, C, M, False, False, E.EPI_NONE), (C, C, M, False, False, E.EPI_NONE),
+        (3 * C, C, M, False, False, E.EPI_NONE), (V, C, M, False, False, E.EPI_NONE),
+    ]
+
+
+def tune_model_shapes(rows: int, n_embd: int, vocab: int, device="cuda", verbose=False):
+    for (M, N, K, ak, bk, epi) in model_gemm_shapes(rows, n_embd, vocab):
+        tune_gemm(M, N, K, ak, bk, epi, device=device, verbose=verbose)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
