@@ -214,7 +214,7 @@ def test_loss_curve_tracks_oracle_step_for_step():
     for s in range(steps):
         np.random.seed(100)
         losses.append(step(ids.to(DEV))["loss"].item())
-        np.random.seed(100 + s)
+        np.random.seed(100)
         ref_losses.append(ref_step(ids)["loss"].item())
     assert ref_losses[-1] < ref_losses[0], ref_losses          # it actually trains
     for a, b in zip(losses, ref_losses):
