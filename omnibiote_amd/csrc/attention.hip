@@ -60,30 +60,39 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int krow0, int dt, i
     return join8(lo, hi);
 }
 
-// Global -> registers -> LDS staging of a ROWS x D tile by 256 threads (rows >= nvalid read as zero).
+// Global -> LDS staging of a ROWS x D tile by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPR round trip).
+// The DMA writes LDS linearly (wave base + lane*16), so the swizzle is applied to the SOURCE chunk each lane fetches:
+// LDS position `pos` of row r holds logical chunk pos ^ X(r) — exactly what swz<D>() reads back.  The descriptor ends
+// at the end of this batch element's rows, so rows past T arrive as zeros.  256 threads = 4 waves; wave w issues
+// pieces w, w+4, ...  Completion: the issuing wave's s_waitcnt vmcnt(0), then the workgroup barrier.
 template <int D, int ROWS>
-struct TileStage {
-    static constexpr int CPR = D / 8;                 // 16-B chunks per row
-    static constexpr int N = ROWS * CPR / 256;        // chunks per thread
-    bf16x8 r[N];
-    __device__ __forceinline__ void load(const bf16* g, int64_t row_stride, int nvalid, int tid) {
+struct TileDma {
+    static constexpr int PIECES = ROWS * 2 * D / 1024;   // 1-KiB pieces in the tile
+    static constexpr int NP = PIECES / 4;                 // per wave
+    static constexpr int RPP = 1024 / (2 * D);            // rows per piece: 4 (D=128) or 8 (D=64)
+    static constexpr int CPR = D / 8;                     // chunks per row
+    int voff[NP];
+    __device__ __forceinline__ void init(int wave, int lane, int64_t row_stride) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int cid = tid + 256 * i;
-            const int row = cid / CPR, ch = cid % CPR;
-            bf16x8 v = {};
-            if (row < nvalid) v = *reinterpret_cast<const bf16x8*>(g + (int64_t)row * row_stride + ch * 8);
-            r[i] = v;
+        for (int i = 0; i < NP; ++i) {
+            const int piece = wave + 4 * i;
+            const int row = piece * RPP + lane / CPR;
+            const int pos = lane % CPR;
+            const int x = (D == 128) ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+            voff[i] = (int)((row * row_stride + (pos ^ x) * 8) * 2);
         }
     }
-    __device__ __forceinline__ void store(char* tile, int tid) const {
+    // g: address of the tile's first row (head column applied); bytes_left: bytes from g to the end of the rows that
+    // may be read (the batch element's last row)
+    __device__ __forceinline__ void issue(const bf16* g, int64_t bytes_left, char* tile, int wave) const {
+        __amdgpu_buffer_rsrc_t rsrc = make_rsrc(g, bytes_left);
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int cid = tid + 256 * i;
-            *reinterpret_cast<bf16x8*>(tile + swz<D>(cid / CPR, cid % CPR)) = r[i];
-        }
+        for (int i = 0; i < NP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(tile + (wave + 4 * i) * 1024), 16, voff[i], 0, 0, 0);
     }
 };
+
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -161,22 +170,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     const float scale2 = p.scale * LOG2E;
 
-    TileStage<D, 64> sk, sv;
-    if (t_begin < t_end) {
-        sk.load(kbase + (int64_t)t_begin * 64 * ld, ld, T - t_begin * 64, tid);
-        sv.load(vbase + (int64_t)t_begin * 64 * ld, ld, T - t_begin * 64, tid);
-        sk.store(smem, tid);
-        sv.store(smem + TB, tid);
-    }
+    TileDma<D, 64> dma;
+    dma.init(wave, lane, ld);
+    auto issue_kv = [&](int t, int stage) {
+        const int64_t row0 = (int64_t)t * 64;
+        const int64_t rows_left = ((int64_t)T - row0) * ld;
+        char* st = smem + stage * 2 * TB;
+        dma.issue(kbase + row0 * ld, (rows_left - (C + hd * D)) * 2, st, wave);
+        dma.issue(vbase + row0 * ld, (rows_left - (2 * C + hd * D)) * 2, st + TB, wave);
+    };
+    if (t_begin < t_end) issue_kv(t_begin, 0);
+    dma_wait_all();
     __syncthreads();
 
     for (int t = t_begin; t < t_end; ++t) {
         const int cur = (t - t_begin) & 1;
         const bool more = t + 1 < t_end;
-        if (more) {
-            sk.load(kbase + (int64_t)(t + 1) * 64 * ld, ld, T - (t + 1) * 64, tid);
-            sv.load(vbase + (int64_t)(t + 1) * 64 * ld, ld, T - (t + 1) * 64, tid);
-        }
+        if (more) issue_kv(t + 1, cur ^ 1);   // the stage every wave finished reading before the last barrier
         const char* Kt = smem + cur * 2 * TB;
         const char* Vt = Kt + TB;
         const int key0 = t * 64;
@@ -243,10 +253,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
             for (int dt = 0; dt < ND; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Vt, 16 * kk, dt, lane), pf, o[dt], 0, 0, 0);
         }
-        if (more) {
-            sk.store(smem + (cur ^ 1) * 2 * TB, tid);
-            sv.store(smem + (cur ^ 1) * 2 * TB + TB, tid);
-        }
+        dma_wait_all();
         __syncthreads();
     }
 
@@ -311,7 +318,7 @@ __device__ __forceinline__ void rope_inv4(float (&g)[4], const float* cos_t, con
 //   S^T = K Q^T ; P^T = exp(S^T*scale + mask - lse) ; dP^T = V dO^T ; dS^T = P^T (dP^T - delta) ; dQ^T += K^T dS^T
 // ==========================================================================================================
 template <int D, int MODE>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TB = 64 * 2 * D;
     constexpr int NS = D / 16, ND = D / 32;
@@ -360,58 +367,54 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
     const float scale2 = p.scale * LOG2E;
 
-    TileStage<D, 64> sk, sv;
-    if (t_begin < t_end) {
-        sk.load(kbase + (int64_t)t_begin * 64 * ld, ld, T - t_begin * 64, tid);
-        sv.load(vbase + (int64_t)t_begin * 64 * ld, ld, T - t_begin * 64, tid);
-        sk.store(smem, tid);
-        sv.store(smem + TB, tid);
-    }
+    TileDma<D, 64> dma;
+    dma.init(wave, lane, ld);
+    auto issue_kv = [&](int t, int stage) {
+        const int64_t row0 = (int64_t)t * 64;
+        const int64_t rows_left = ((int64_t)T - row0) * ld;
+        char* st = smem + stage * 2 * TB;
+        dma.issue(kbase + row0 * ld, (rows_left - (C + hd * D)) * 2, st, wave);
+        dma.issue(vbase + row0 * ld, (rows_left - (2 * C + hd * D)) * 2, st + TB, wave);
+    };
+    if (t_begin < t_end) issue_kv(t_begin, 0);
+    dma_wait_all();
     __syncthreads();
 
     for (int t = t_begin; t < t_end; ++t) {
         const int cur = (t - t_begin) & 1;
-        const bool more = t + 1 < t_end;
-        if (more) {
-            sk.load(kbase + (int64_t)(t + 1) * 64 * ld, ld, T - (t + 1) * 64, tid);
-            sv.load(vbase + (int64_t)(t + 1) * 64 * ld, ld, T - (t + 1) * 64, tid);
-        }
+        if (t + 1 < t_end) issue_kv(t + 1, cur ^ 1);
         const char* Kt = smem + cur * 2 * TB;
         const char* Vt = Kt + TB;
         const int key0 = t * 64;
-
-        f32x16 sc[2], dp[2];
+        // the 64-key tile is processed as two 32-key halves so that only one score/dP accumulator pair is live
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sc[0][r] = 0.f; sc[1][r] = 0.f; dp[0][r] = 0.f; dp[1][r] = 0.f; }
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x16 sc, dp;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 0, s, lane), qf[s], sc[0], 0, 0, 0);
-            sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 32, s, lane), qf[s], sc[1], 0, 0, 0);
-            dp[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vt, 0, s, lane), dof[s], dp[0], 0, 0, 0);
-            dp[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vt, 32, s, lane), dof[s], dp[1], 0, 0, 0);
-        }
+            for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+            for (int s = 0; s < NS; ++s) {
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 32 * mt, s, lane), qf[s], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vt, 32 * mt, s, lane), dof[s], dp, 0, 0, 0);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = key0 + 32 * mt + acc_row(r, h);
-                float x = sc[mt][r] * scale2 - lse2;
+                float x = sc[r] * scale2 - lse2;
                 if (MODE == MASK_DENSE) { if (key < T) x += bf2f(mrow[key]) * LOG2E; }
                 float pv = fast_exp2(x);
                 if (key < ks || key >= ke) pv = 0.f;
-                sc[mt][r] = pv * (dp[mt][r] - dl);   // dS^T (without the scale factor)
+                sc[r] = pv * (dp[r] - dl);   // dS^T (without the scale factor)
             }
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const bf16x8 dsf = pack8(sc[kk >> 1], 8 * (kk & 1));
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 dsf = pack8(sc, 8 * kk);
 #pragma unroll
-            for (int dt = 0; dt < ND; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Kt, 16 * kk, dt, lane), dsf, dq[dt], 0, 0, 0);
+                for (int dt = 0; dt < ND; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Kt, 32 * mt + 16 * kk, dt, lane), dsf, dq[dt], 0, 0, 0);
+            }
         }
-        if (more) {
-            sk.store(smem + (cur ^ 1) * 2 * TB, tid);
-            sv.store(smem + (cur ^ 1) * 2 * TB + TB, tid);
-        }
+        dma_wait_all();
         __syncthreads();
     }
 
@@ -441,11 +444,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(AttnParams p) {
 //   dV^T += dO^T P ; dK^T += Q^T dS
 // ==========================================================================================================
 template <int D, int MODE>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QB = 32 * 2 * D;  // bytes of one 32-row tile
     constexpr int NS = D / 16, ND = D / 32;
     constexpr int STAGE = 2 * QB + 256;  // Q tile, dO tile, 32 lse2 + 32 delta floats
+    constexpr int VB = 128 * 2 * D;      // the workgroup's own V rows, kept in LDS for the whole kernel (B operand of dP)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
@@ -459,12 +463,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams p) {
     const int key_c = k_ok ? key : T - 1;
 
     const bf16* kptr = p.qkv + (b * T + key_c) * ld + C + hd * D;
-    const bf16* vptr = kptr + C;
-    bf16x8 kf[NS], vf[NS];
+    bf16x8 kf[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        kf[s] = *reinterpret_cast<const bf16x8*>(kptr + 16 * s + 8 * h);
-        vf[s] = *reinterpret_cast<const bf16x8*>(vptr + 16 * s + 8 * h);
+    for (int s = 0; s < NS; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(kptr + 16 * s + 8 * h);
+    char* Vblk = smem + 2 * STAGE;
+    {
+        TileDma<D, 128> dmv;
+        dmv.init(wave, lane, ld);
+        const int64_t row0 = (int64_t)blockIdx.x * 128;
+        dmv.issue(p.qkv + (b * T + row0) * ld + 2 * C + hd * D, (((int64_t)T - row0) * ld - (2 * C + hd * D)) * 2, Vblk, wave);
     }
     // by symmetry of the mask, the queries that see this key are the keys this position sees as a query
     int qs = 0, qe = T;
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams p) {
     }
     if (!k_ok) { qs = 0; qe = 0; }
     int lo = k_ok ? qs : T, hi = k_ok ? qe : 0;
-    if (MODE == MASK_RANGES) block_minmax(lo, hi, reinterpret_cast<int*>(smem + 2 * STAGE), wave, lane);
+    if (MODE == MASK_RANGES) block_minmax(lo, hi, reinterpret_cast<int*>(smem + 2 * STAGE + VB), wave, lane);
     else { lo = 0; hi = T; }
     const int t_begin = lo / 32;
     const int t_end = hi > lo ? (hi + 31) / 32 : t_begin;
@@ -493,7 +500,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
     const float scale2 = p.scale * LOG2E;
 
-    TileStage<D, 32> sq, sd;
+    TileDma<D, 32> dmq, dmd;
+    dmq.init(wave, lane, ld);
+    dmd.init(wave, lane, C);
+    auto issue_qd = [&](int t, char* stage) {
+        const int64_t row0 = (int64_t)t * 32;
+        dmq.issue(qbase + row0 * ld, (((int64_t)T - row0) * ld - hd * D) * 2, stage, wave);
+        dmd.issue(dobase + row0 * C, (((int64_t)T - row0) * C - hd * D) * 2, stage + QB, wave);
+    };
     float st_l = 0.f;  // threads 0..31: lse2 of row tid ; 32..63: delta of row tid-32
     auto load_stats = [&](int q0) {
         if (tid < 64) {
@@ -508,21 +522,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams p) {
         if (tid < 64) reinterpret_cast<float*>(stage + 2 * QB)[tid] = st_l;
     };
     if (t_begin < t_end) {
-        sq.load(qbase + (int64_t)t_begin * 32 * ld, ld, T - t_begin * 32, tid);
-        sd.load(dobase + (int64_t)t_begin * 32 * C, C, T - t_begin * 32, tid);
+        issue_qd(t_begin, smem);
         load_stats(t_begin * 32);
-        sq.store(smem, tid);
-        sd.store(smem + QB, tid);
         store_stats(smem);
     }
+    dma_wait_all();
     __syncthreads();
 
     for (int t = t_begin; t < t_end; ++t) {
         const int cur = (t - t_begin) & 1;
         const bool more = t + 1 < t_end;
         if (more) {
-            sq.load(qbase + (int64_t)(t + 1) * 32 * ld, ld, T - (t + 1) * 32, tid);
-            sd.load(dobase + (int64_t)(t + 1) * 32 * C, C, T - (t + 1) * 32, tid);
+            issue_qd(t + 1, smem + (cur ^ 1) * STAGE);
             load_stats((t + 1) * 32);
         }
         const char* Qt = smem + cur * STAGE;
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams p) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Qt, 0, s, lane), kf[s], sc, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Dt, 0, s, lane), vf[s], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Dt, 0, s, lane), row_frag<D>(Vblk, 32 * wave, s, lane), dp, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -564,12 +575,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(AttnParams p) {
                 dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Qt, 16 * kk, dt, lane), dsf, dk[dt], 0, 0, 0);
             }
         }
-        if (more) {
-            char* nxt = smem + (cur ^ 1) * STAGE;
-            sq.store(nxt, tid);
-            sd.store(nxt + QB, tid);
-            store_stats(nxt);
-        }
+        if (more) store_stats(smem + (cur ^ 1) * STAGE);
+        dma_wait_all();
         __syncthreads();
     }
 
@@ -638,7 +645,7 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
         OBTE_CHECK_LAUNCH("obte_attn_bwd(dq)");
     }
     {
-        const int smem = 2 * (2 * 32 * 2 * D + 256) + 64;
+        const int smem = 2 * (2 * 32 * 2 * D + 256) + 128 * 2 * D + 64;
         const dim3 grid((unsigned)cdiv64(p.T, 128), p.H, (unsigned)p.B), block(256);
 #define GO(M)                                                                          \
     do {                                                                               \

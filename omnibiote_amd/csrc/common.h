@@ -78,12 +78,27 @@ __device__ __forceinline__ bf16x8 join8(bf16x4 a, bf16x4 b) {
 }
 
 // gelu_erf with the reference's constant 1.41421 (training/model.py:25) and its derivative.
+// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, below fp32 resolution of the bf16-rounded results),
+// branch-free: one v_rcp_f32, one v_exp_f32 and five FMAs — the ocml erff is branchy and several times longer, and
+// the GEMM epilogues that call this are not hidden behind MFMA work.  The exp(-u^2) is shared with the derivative.
 #define OBTE_GELU_C 1.41421f
-__device__ __forceinline__ float gelu_ref(float x) { return x * 0.5f * (1.0f + erff(x / OBTE_GELU_C)); }
+__device__ __forceinline__ void erf_and_gauss(float u, float& erf_u, float& gauss) {
+    const float au = fabsf(u);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * au);
+    gauss = __expf(-u * u);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    erf_u = copysignf(1.0f - poly * gauss, u);
+}
+__device__ __forceinline__ float gelu_ref(float x) {
+    float e, g;
+    erf_and_gauss(x * (1.0f / OBTE_GELU_C), e, g);
+    return x * 0.5f * (1.0f + e);
+}
 __device__ __forceinline__ float gelu_ref_grad(float x) {
-    const float u = x / OBTE_GELU_C;
+    float e, g;
+    erf_and_gauss(x * (1.0f / OBTE_GELU_C), e, g);
     // d/dx [0.5 x (1 + erf(x/c))] = 0.5 (1 + erf(u)) + x * (1/(c*sqrt(pi))) * exp(-u^2)
-    return 0.5f * (1.0f + erff(u)) + x * (0.5641895835477563f / OBTE_GELU_C) * __expf(-u * u);
+    return 0.5f * (1.0f + e) + x * (0.5641895835477563f / OBTE_GELU_C) * g;
 }
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
