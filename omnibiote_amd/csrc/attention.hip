@@ -603,6 +603,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
     }
 }
 
+// Explicit instantiations (implicit instantiation alone left some host stubs undefined with hipcc / ROCm 7.2).
+#define OBTE_INST_ATTN(D, M)                                                \
+    template __global__ void attn_fwd_kernel<D, M>(AttnParams);             \
+    template __global__ void attn_bwd_dq_kernel<D, M>(AttnParams);          \
+    template __global__ void attn_bwd_dkdv_kernel<D, M>(AttnParams);
+OBTE_INST_ATTN(64, 0) OBTE_INST_ATTN(64, 1) OBTE_INST_ATTN(64, 2)
+OBTE_INST_ATTN(128, 0) OBTE_INST_ATTN(128, 1) OBTE_INST_ATTN(128, 2)
+#undef OBTE_INST_ATTN
+
 template <typename K>
 void set_smem(K kern, int bytes) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
