@@ -60,6 +60,33 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int krow0, int dt, i
     return join8(lo, hi);
 }
 
+// Global -> registers -> LDS staging of a ROWS x D tile by 256 threads (rows >= nvalid read as zero).  Used by the
+// forward kernel: issuing the loads before the tile's MFMA work and writing LDS after it measured 19 % faster there
+// than LDS-DMA (55 vs 66 us at B8/H8/T1024); the backward kernels need the registers more than the overlap.
+template <int D, int ROWS>
+struct TileStage {
+    static constexpr int CPR = D / 8;                 // 16-B chunks per row
+    static constexpr int N = ROWS * CPR / 256;        // chunks per thread
+    bf16x8 r[N];
+    __device__ __forceinline__ void load(const bf16* g, int64_t row_stride, int nvalid, int tid) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int cid = tid + 256 * i;
+            const int row = cid / CPR, ch = cid % CPR;
+            bf16x8 v = {};
+            if (row < nvalid) v = *reinterpret_cast<const bf16x8*>(g + (int64_t)row * row_stride + ch * 8);
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(char* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int cid = tid + 256 * i;
+            *reinterpret_cast<bf16x8*>(tile + swz<D>(cid / CPR, cid % CPR)) = r[i];
+        }
+    }
+};
+
 // Global -> LDS staging of a ROWS x D tile by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPR round trip).
 // The DMA writes LDS linearly (wave base + lane*16), so the swizzle is applied to the SOURCE chunk each lane fetches:
 // LDS position `pos` of row r holds logical chunk pos ^ X(r) — exactly what swz<D>() reads back.  The descriptor ends
@@ -170,23 +197,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     const float scale2 = p.scale * LOG2E;
 
-    TileDma<D, 64> dma;
-    dma.init(wave, lane, ld);
-    auto issue_kv = [&](int t, int stage) {
-        const int64_t row0 = (int64_t)t * 64;
-        const int64_t rows_left = ((int64_t)T - row0) * ld;
-        char* st = smem + stage * 2 * TB;
-        dma.issue(kbase + row0 * ld, (rows_left - (C + hd * D)) * 2, st, wave);
-        dma.issue(vbase + row0 * ld, (rows_left - (2 * C + hd * D)) * 2, st + TB, wave);
-    };
-    if (t_begin < t_end) issue_kv(t_begin, 0);
-    dma_wait_all();
+    TileStage<D, 64> sk, sv;
+    if (t_begin < t_end) {
+        sk.load(kbase + (int64_t)t_begin * 64 * ld, ld, T - t_begin * 64, tid);
+        sv.load(vbase + (int64_t)t_begin * 64 * ld, ld, T - t_begin * 64, tid);
+        sk.store(smem, tid);
+        sv.store(smem + TB, tid);
+    }
     __syncthreads();
 
     for (int t = t_begin; t < t_end; ++t) {
         const int cur = (t - t_begin) & 1;
         const bool more = t + 1 < t_end;
-        if (more) issue_kv(t + 1, cur ^ 1);   // the stage every wave finished reading before the last barrier
+        if (more) {   // issue early: the loads fly under this tile's MFMA work, the LDS write follows it
+            sk.load(kbase + (int64_t)(t + 1) * 64 * ld, ld, T - (t + 1) * 64, tid);
+            sv.load(vbase + (int64_t)(t + 1) * 64 * ld, ld, T - (t + 1) * 64, tid);
+        }
         const char* Kt = smem + cur * 2 * TB;
         const char* Vt = Kt + TB;
         const int key0 = t * 64;
@@ -253,7 +279,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
             for (int dt = 0; dt < ND; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Vt, 16 * kk, dt, lane), pf, o[dt], 0, 0, 0);
         }
-        dma_wait_all();
+        if (more) {
+            sk.store(smem + (cur ^ 1) * 2 * TB, tid);
+            sv.store(smem + (cur ^ 1) * 2 * TB + TB, tid);
+        }
         __syncthreads();
     }
 
