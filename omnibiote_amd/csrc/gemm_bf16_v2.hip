@@ -168,19 +168,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
         }
         const char* ta = smem + stage * STAGE_BYTES;
         const char* tb = ta + A_TILE;
+        // Fragment double buffering: the LDS reads of k-step 1 are issued (all of them, back to back) before the
+        // MFMAs of k-step 0, so their latency runs under 32 (or 16) MFMAs instead of in front of every group of four.
+        // sched_barrier pins the order; left alone, hipcc sinks each ds_read to just before its first use.
+        bf16x8 af[2][4], bfr[2][NJ];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[0][i] = load_frag<A_KMAJOR, BM>(ta, wm * 64 + i * 16, 0, lane);
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) bfr[0][i] = load_frag<B_KMAJOR, BN>(tb, wn * (BN / 2) + i * 16, 0, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[1][i] = load_frag<A_KMAJOR, BM>(ta, wm * 64 + i * 16, 1, lane);
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) bfr[1][i] = load_frag<B_KMAJOR, BN>(tb, wn * (BN / 2) + i * 16, 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 af[4], bfr[NJ];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KMAJOR, BM>(ta, wm * 64 + i * 16, s, lane);
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) bfr[i] = load_frag<B_KMAJOR, BN>(tb, wn * (BN / 2) + i * 16, s, lane);
 #pragma unroll
             for (int ni = 0; ni < NJ; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     // operands swapped: the accumulator holds C^T (row = n, col = m)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][ni], af[s][mi], acc[ni][mi], 0, 0, 0);
         }
         if (CF::NSTAGE == 3) stage = stage == 2 ? 0 : stage + 1;
         else stage ^= 1;
