@@ -150,49 +150,63 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
         dma_tile<NPB>(p.b + bo, p.b_elems - bo, voff_b, st + A_TILE, wave);
     };
 
-    if (nk > 0) issue(0, 0);
-    if (CF::NSTAGE == 3 && nk > 1) issue(1, 1);
-    int stage = 0;
-    for (int t = 0; t < nk; ++t) {
-        if (CF::NSTAGE == 3) {
-            // tile t has landed once at most the six pieces of tile t+1 are still in flight
-            if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            // every wave has finished reading stage (t-1)%3 before it reached this barrier: refill it with tile t+2
-            if (t + 2 < nk) issue(t + 2, stage == 0 ? 2 : stage - 1);
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (t + 1 < nk) issue(t + 1, stage ^ 1);   // the stage read during step t-1
-        }
-        const char* ta = smem + stage * STAGE_BYTES;
+    // ---- main loop, software pipelined over half K-tiles -------------------------------------------------------
+    // Each K-tile (64) is two MFMA k-steps; fragments are double-buffered in registers (F0: k-step 0, F1: k-step 1).
+    //   step t:  [3-stage ring: issue DMA of tile t+2]  read F1(t) | MFMA F0(t) | wait tile t+1, barrier |
+    //            read F0(t+1)  [2-stage ring: issue DMA of tile t+2]  | MFMA F1(t)
+    // so every LDS fragment read and every DMA issue runs under 32 (or 16) MFMAs of the same wave, there is one
+    // barrier per K-tile, and the DMA waits are counted (3-stage: the six pieces of tile t+2 stay in flight).
+    // sched_barrier pins this order; left alone hipcc sinks each ds_read to just before its first use.
+    auto stage_of = [&](int t) { return CF::NSTAGE == 3 ? t % 3 : (t & 1); };
+    auto load_frags = [&](int t, int ks, bf16x8 (&af)[4], bf16x8 (&bfr)[NJ]) {
+        const char* ta = smem + stage_of(t) * STAGE_BYTES;
         const char* tb = ta + A_TILE;
-        // Fragment double buffering: the LDS reads of k-step 1 are issued (all of them, back to back) before the
-        // MFMAs of k-step 0, so their latency runs under 32 (or 16) MFMAs instead of in front of every group of four.
-        // sched_barrier pins the order; left alone, hipcc sinks each ds_read to just before its first use.
-        bf16x8 af[2][4], bfr[2][NJ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[0][i] = load_frag<A_KMAJOR, BM>(ta, wm * 64 + i * 16, 0, lane);
+        for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KMAJOR, BM>(ta, wm * 64 + i * 16, ks, lane);
 #pragma unroll
-        for (int i = 0; i < NJ; ++i) bfr[0][i] = load_frag<B_KMAJOR, BN>(tb, wn * (BN / 2) + i * 16, 0, lane);
+        for (int i = 0; i < NJ; ++i) bfr[i] = load_frag<B_KMAJOR, BN>(tb, wn * (BN / 2) + i * 16, ks, lane);
+    };
+    auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[NJ]) {
+#pragma unroll
+        for (int ni = 0; ni < NJ; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                // operands swapped: the accumulator holds C^T (row = n, col = m)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    };
+
+    bf16x8 a0[4], b0[NJ], a1[4], b1[NJ];
+    if (nk > 0) {
+        issue(0, 0);
+        if (nk > 1) issue(1, 1);
+        if (CF::NSTAGE == 3 && nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (CF::NSTAGE == 2 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NPB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags(0, 0, a0, b0);
+    }
+    for (int t = 0; t + 1 < nk; ++t) {
+        if (CF::NSTAGE == 3 && t + 2 < nk) issue(t + 2, (t + 2) % 3);   // stage of tile t-1: free since the last barrier
+        load_frags(t, 1, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[1][i] = load_frag<A_KMAJOR, BM>(ta, wm * 64 + i * 16, 1, lane);
-#pragma unroll
-        for (int i = 0; i < NJ; ++i) bfr[1][i] = load_frag<B_KMAJOR, BN>(tb, wn * (BN / 2) + i * 16, 1, lane);
+        mma(a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#pragma unroll
-            for (int ni = 0; ni < NJ; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    // operands swapped: the accumulator holds C^T (row = n, col = m)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s][ni], af[s][mi], acc[ni][mi], 0, 0, 0);
-        }
-        if (CF::NSTAGE == 3) stage = stage == 2 ? 0 : stage + 1;
-        else stage ^= 1;
+        // the builtin form (not inline asm) so that hipcc's own wait bookkeeping knows F1 has landed and does not
+        // make MFMA F1 wait behind the F0(t+1) reads issued below.  simm16: vmcnt[3:0], expcnt 7, lgkmcnt 0.
+        if (CF::NSTAGE == 3 && t + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0076);   // vmcnt(6) lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0x0070);                                  // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();   // tile t+1 landed for everyone; everyone holds tile t's fragments in registers
+        load_frags(t + 1, 0, a0, b0);
+        if (CF::NSTAGE == 2 && t + 2 < nk) issue(t + 2, t & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nk > 0) {   // last K-tile: nothing left to fetch
+        load_frags(nk - 1, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        mma(a1, b1);
     }
     __syncthreads();  // all fragment reads done (and no DMA outstanding): LDS becomes the epilogue staging area
 
