@@ -124,32 +124,52 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         dma_tile(p.b + bo, p.b_elems - bo, voff_b, st + TILE_BYTES, wave);
     };
 
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) issue(t + 1, cur ^ 1);
-        const char* ta = smem + cur * STAGE_BYTES;
+    // ---- main loop, software pipelined over half K-tiles (same scheme as gemm_bf16_v2.hip) ---------------------
+    //   step t:  read F1(t) | MFMA F0(t) | wait tile t+1, barrier | read F0(t+1), issue DMA of tile t+2 | MFMA F1(t)
+    auto load_frags = [&](int t, int ks, bf16x8 (&af)[4], bf16x8 (&bfr)[4]) {
+        const char* ta = smem + (t & 1) * STAGE_BYTES;
         const char* tb = ta + TILE_BYTES;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 af[4], bfr[4];
+        for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KMAJOR>(ta, wm * 64 + i * 16, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KMAJOR>(ta, wm * 64 + i * 16, s, lane);
+        for (int i = 0; i < 4; ++i) bfr[i] = load_frag<B_KMAJOR>(tb, wn * 64 + i * 16, ks, lane);
+    };
+    auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[4]) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bfr[i] = load_frag<B_KMAJOR>(tb, wn * 64 + i * 16, s, lane);
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    // operands swapped: the accumulator holds C^T (row = n, col = m)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
-        }
+            for (int mi = 0; mi < 4; ++mi)
+                // operands swapped: the accumulator holds C^T (row = n, col = m)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    };
+    bf16x8 a0[4], b0[4], a1[4], b1[4];
+    issue(0, 0);
+    if (nk > 1) {
+        issue(1, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 landed; the 8 pieces of tile 1 stay in flight
+    } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, 0, a0, b0);
+    for (int t = 0; t + 1 < nk; ++t) {
+        load_frags(t, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): tile t+1 landed, F1(t) in registers
+        __builtin_amdgcn_s_barrier();
+        load_frags(t + 1, 0, a0, b0);
+        if (t + 2 < nk) issue(t + 2, t & 1);  // the stage every wave has just finished reading
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    load_frags(nk - 1, 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0);
+    mma(a1, b1);
+    __syncthreads();
 
     // ---- epilogue: acc -> bf16 -> LDS (per-wave region) -> 16-B row-contiguous stores ---------------------
     char* stg = smem + wave * EPI_WAVE_BYTES;
