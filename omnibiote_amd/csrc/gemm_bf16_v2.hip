@@ -150,32 +150,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
         dma_tile<NPB>(p.b + bo, p.b_elems - bo, voff_b, st + A_TILE, wave);
     };
 
-    // L2 prefetch (2-stage ring only): the LDS ring can hold just one K-tile in flight, so a tile that misses L2
-    // costs its full HBM latency inside the step that waits for it.  Each thread therefore touches one 128-B line of
-    // tile t+3 with a 4-byte LDS-DMA into a dump area when tile t+2's DMA is issued; by the time that tile's DMA runs,
-    // a step later, its lines are in L2.  (An ordinary VGPR load cannot be used: with LDS-DMA in flight hipcc waits
-    // vmcnt(0) at its use and drains the ring.)  The step's wait becomes vmcnt(1): everything but this piece.
-    constexpr bool PF = CF::NSTAGE == 2;
-    // waves 0-3 touch the 256 lines of the A tile, waves 4-7 those of the B tile: the operand choice is wave-uniform,
-    // so the descriptor stays in SGPRs (a per-lane choice makes hipcc wrap the load in a waterfall loop)
-    const bool pf_is_a = wave < 4;
-    int pf_voff = 0;
-    if (PF) {
-        const int r = (wave & 3) * 64 + lane;   // line index inside the tile
-        if (pf_is_a) pf_voff = A_KMAJOR ? (int)(r * p.lda * 2) : (int)(((r >> 2) * p.lda + (r & 3) * 64) * 2);
-        else pf_voff = B_KMAJOR ? (int)(r * p.ldb * 2) : (int)(((r / (BN / 64)) * p.ldb + (r % (BN / 64)) * 64) * 2);
-    }
-    char* pf_dump = smem + CF::SMEM + wave * 256;   // 8 x 256 B behind the ring
-    auto prefetch = [&](int t) {
-        const int64_t k0 = (int64_t)(kt0 + t) * BKT;
-        const int64_t ao = A_KMAJOR ? (m0 * p.lda + k0) : (k0 * p.lda + m0);
-        const int64_t bo = B_KMAJOR ? (n0 * p.ldb + k0) : (k0 * p.ldb + n0);
-        const bf16* org = pf_is_a ? p.a + ao : p.b + bo;
-        const int64_t left = pf_is_a ? p.a_elems - ao : p.b_elems - bo;
-        __amdgpu_buffer_rsrc_t rsrc = make_rsrc(org, left * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(pf_dump), 4, pf_voff, 0, 0, 0);
-    };
-
     // ---- main loop, software pipelined over half K-tiles -------------------------------------------------------
     // Each K-tile (64) is two MFMA k-steps; fragments are double-buffered in registers (F0: k-step 0, F1: k-step 1).
     //   step t:  [3-stage ring: issue DMA of tile t+2]  read F1(t) | MFMA F0(t) | wait tile t+1, barrier |
@@ -205,9 +179,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
     if (nk > 0) {
         issue(0, 0);
         if (nk > 1) issue(1, 1);
-        if (PF && nk > 2) prefetch(2);
         if (CF::NSTAGE == 3 && nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (CF::NSTAGE == 2 && nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NPB + 1) : "memory");
         else if (CF::NSTAGE == 2 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NPB) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -222,12 +194,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
         // the builtin form (not inline asm) so that hipcc's own wait bookkeeping knows F1 has landed and does not
         // make MFMA F1 wait behind the F0(t+1) reads issued below.  simm16: vmcnt[3:0], expcnt 7, lgkmcnt 0.
         if (CF::NSTAGE == 3 && t + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0076);   // vmcnt(6) lgkmcnt(0)
-        else if (PF && t + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0071);            // vmcnt(1) lgkmcnt(0): all but the newest piece
         else __builtin_amdgcn_s_waitcnt(0x0070);                                  // vmcnt(0) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();   // tile t+1 landed for everyone; everyone holds tile t's fragments in registers
         load_frags(t + 1, 0, a0, b0);
         if (CF::NSTAGE == 2 && t + 2 < nk) issue(t + 2, t & 1);
-        if (PF && t + 3 < nk) prefetch(t + 3);
         __builtin_amdgcn_sched_barrier(0);
         mma(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
@@ -349,10 +319,10 @@ template <bool AK, bool BK, int EPI, bool SPLIT, int BN>
 int launch(const GemmParams& p, hipStream_t st) {
     static bool attr_set = false;  // idempotent; a race only repeats the call
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<AK, BK, EPI, SPLIT, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<BN>::SMEM + 2048);
+        (void)hipFuncSetAttribute((const void*)gemm_v2_kernel<AK, BK, EPI, SPLIT, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<BN>::SMEM);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_v2_kernel<AK, BK, EPI, SPLIT, BN>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(NTHREADS), Cfg<BN>::SMEM + 2048, st, p);
+    hipLaunchKernelGGL((gemm_v2_kernel<AK, BK, EPI, SPLIT, BN>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(NTHREADS), Cfg<BN>::SMEM, st, p);
     OBTE_CHECK_LAUNCH("obte_gemm_bf16");
     return OBTE_OK;
 }
