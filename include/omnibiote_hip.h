@@ -154,6 +154,17 @@ int obte_adamw_bf16(obte_bf16* p, const obte_bf16* g, obte_bf16* m, obte_bf16* v
                     const float* clip_coef, obte_stream s);
 /* sum of squares of a bf16 tensor accumulated into out[0] (fp32, atomics) — for clip_grad_norm_. */
 int obte_sumsq_bf16(const obte_bf16* g, int64_t n, float* out, obte_stream s);
+/* Multi-tensor forms: one launch covers up to OBTE_MT_MAX tensors (the optimizer step of the small config touches
+ * 67 tensors, most of them 1 K-element LayerNorm weights: per-tensor launches cost more than the arithmetic).
+ * Each tensor's n must be a multiple of 8. */
+#define OBTE_MT_MAX 32
+typedef struct {
+    obte_bf16* p[OBTE_MT_MAX]; const obte_bf16* g[OBTE_MT_MAX]; obte_bf16* m[OBTE_MT_MAX]; obte_bf16* v[OBTE_MT_MAX];
+    int64_t n[OBTE_MT_MAX]; float lr[OBTE_MT_MAX]; float weight_decay[OBTE_MT_MAX]; int32_t step[OBTE_MT_MAX];
+    int32_t count;
+} obte_mt_args;
+int obte_adamw_multi_bf16(const obte_mt_args* t, float beta1, float beta2, float eps, const float* clip_coef, obte_stream s);
+int obte_sumsq_multi_bf16(const obte_mt_args* t, float* out, obte_stream s);
 
 /* ---- whole transformer block (training/model.py:170-181), forward and backward, dropout 0 --------------------
  * One host call enqueues every kernel of the block, so Python crosses the boundary once per block and pass.

@@ -47,6 +47,15 @@ class BlockDesc(C.Structure):
                 ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64)]
 
 
+MT_MAX = 32
+
+
+class MtArgs(C.Structure):
+    _fields_ = [("p", C.c_void_p * MT_MAX), ("g", C.c_void_p * MT_MAX), ("m", C.c_void_p * MT_MAX), ("v", C.c_void_p * MT_MAX),
+                ("n", C.c_int64 * MT_MAX), ("lr", C.c_float * MT_MAX), ("weight_decay", C.c_float * MT_MAX),
+                ("step", C.c_int32 * MT_MAX), ("count", C.c_int32)]
+
+
 EPI_NONE, EPI_GELU, EPI_ADD, EPI_GELU_BWD = 0, 1, 2, 3
 
 # name -> (restype, argtypes); every symbol include/omnibiote_hip.h declares
@@ -73,6 +82,8 @@ SYMBOLS = {
     "obte_masked_ce_fwd_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int64, C.c_int64, c_stream]),
     "obte_adamw_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int32, C.c_void_p, c_stream]),
     "obte_sumsq_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, c_stream]),
+    "obte_adamw_multi_bf16": (C.c_int, [C.POINTER(MtArgs), C.c_float, C.c_float, C.c_float, C.c_void_p, c_stream]),
+    "obte_sumsq_multi_bf16": (C.c_int, [C.POINTER(MtArgs), C.c_void_p, c_stream]),
     "obte_block_act_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "obte_block_bwd_ws_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "obte_block_fwd": (C.c_int, [C.POINTER(BlockDesc), C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),

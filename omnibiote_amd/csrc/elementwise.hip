@@ -240,6 +240,81 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const bf16* __restrict__ g, 
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// ---- multi-tensor forms: workgroup b serves chunk (b - first[t]) of tensor t; chunks of 16384 elements -----------
+constexpr int MT_CHUNK = 16384;
+struct MtTable {
+    bf16* p[OBTE_MT_MAX]; const bf16* g[OBTE_MT_MAX]; bf16* m[OBTE_MT_MAX]; bf16* v[OBTE_MT_MAX];
+    int64_t n[OBTE_MT_MAX]; float lr[OBTE_MT_MAX]; float wd[OBTE_MT_MAX]; float bc1[OBTE_MT_MAX]; float bc2s[OBTE_MT_MAX];
+    int first[OBTE_MT_MAX + 1];
+    int count;
+};
+
+__device__ __forceinline__ int mt_find(const MtTable& t, int b) {
+    int i = 0;
+    while (i + 1 < t.count && b >= t.first[i + 1]) ++i;
+    return i;
+}
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(MtTable t, float b1, float b2, float eps, const float* __restrict__ clip) {
+    const int ti = mt_find(t, blockIdx.x);
+    const int64_t base = (int64_t)(blockIdx.x - t.first[ti]) * MT_CHUNK;
+    const int64_t end = min(base + (int64_t)MT_CHUNK, t.n[ti]);
+    const float cc = clip ? clip[0] : 1.0f;
+    const float lr = t.lr[ti], wd = t.wd[ti], bc1 = t.bc1[ti], bc2s = t.bc2s[ti];
+    bf16* p = t.p[ti]; const bf16* g = t.g[ti]; bf16* m = t.m[ti]; bf16* v = t.v[ti];
+    for (int64_t i = base + threadIdx.x * 8; i < end; i += 256 * 8) {
+        bf16x8 pp = *reinterpret_cast<bf16x8*>(p + i), mm = *reinterpret_cast<bf16x8*>(m + i), vv = *reinterpret_cast<bf16x8*>(v + i);
+        const bf16x8 gg = *reinterpret_cast<const bf16x8*>(g + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gj = bf2f(gg[j]) * cc;
+            float pj = bf2f(pp[j]) * (1.0f - lr * wd);
+            const float mj = bf2f(mm[j]) + (gj - bf2f(mm[j])) * (1.0f - b1);
+            const float vj = bf2f(vv[j]) * b2 + gj * gj * (1.0f - b2);
+            pj -= (lr / bc1) * (mj / (sqrtf(vj) / bc2s + eps));
+            pp[j] = f2bf(pj); mm[j] = f2bf(mj); vv[j] = f2bf(vj);
+        }
+        *reinterpret_cast<bf16x8*>(p + i) = pp; *reinterpret_cast<bf16x8*>(m + i) = mm; *reinterpret_cast<bf16x8*>(v + i) = vv;
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_multi_kernel(MtTable t, float* __restrict__ out) {
+    __shared__ float red[4];
+    const int ti = mt_find(t, blockIdx.x);
+    const int64_t base = (int64_t)(blockIdx.x - t.first[ti]) * MT_CHUNK;
+    const int64_t end = min(base + (int64_t)MT_CHUNK, t.n[ti]);
+    const bf16* g = t.g[ti];
+    float s = 0.f;
+    for (int64_t i = base + threadIdx.x * 8; i < end; i += 256 * 8) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(g + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = bf2f(v[j]); s += f * f; }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+int mt_build(const obte_mt_args* a, float beta1, float beta2, MtTable* t, const char* who, bool need_state) {
+    OBTE_REQUIRE(a && a->count >= 1 && a->count <= OBTE_MT_MAX, "%s: count must be 1..%d", who, OBTE_MT_MAX);
+    t->count = a->count;
+    int blocks = 0;
+    for (int i = 0; i < a->count; ++i) {
+        OBTE_REQUIRE(a->g[i] && a->n[i] > 0 && a->n[i] % 8 == 0, "%s: tensor %d: null gradient or n not a multiple of 8", who, i);
+        if (need_state) OBTE_REQUIRE(a->p[i] && a->m[i] && a->v[i] && a->step[i] >= 1, "%s: tensor %d: null state or step < 1", who, i);
+        t->p[i] = (bf16*)a->p[i]; t->g[i] = (const bf16*)a->g[i]; t->m[i] = (bf16*)a->m[i]; t->v[i] = (bf16*)a->v[i];
+        t->n[i] = a->n[i]; t->lr[i] = a->lr[i]; t->wd[i] = a->weight_decay[i];
+        const int st = a->step[i] < 1 ? 1 : a->step[i];
+        t->bc1[i] = 1.0f - powf(beta1, (float)st);
+        t->bc2s[i] = sqrtf(1.0f - powf(beta2, (float)st));
+        t->first[i] = blocks;
+        blocks += (int)cdiv64(a->n[i], MT_CHUNK);
+    }
+    t->first[a->count] = blocks;
+    return blocks;
+}
+
 inline unsigned stream_grid(int64_t work_items, int per_block) {
     int64_t b = cdiv64(work_items, per_block);
     return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -327,5 +402,24 @@ extern "C" int obte_sumsq_bf16(const obte_bf16* g, int64_t n, float* out, obte_s
     OBTE_REQUIRE(n > 0 && n % 8 == 0, "obte_sumsq_bf16: n must be a positive multiple of 8");
     hipLaunchKernelGGL(sumsq_kernel, dim3(stream_grid(n / 8, 256)), dim3(256), 0, (hipStream_t)s, (const bf16*)g, n / 8, out);
     OBTE_CHECK_LAUNCH("obte_sumsq_bf16");
+    return OBTE_OK;
+}
+
+extern "C" int obte_adamw_multi_bf16(const obte_mt_args* a, float beta1, float beta2, float eps, const float* clip_coef, obte_stream s) {
+    MtTable t;
+    const int blocks = mt_build(a, beta1, beta2, &t, "obte_adamw_multi_bf16", true);
+    if (blocks < 0) return blocks;
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, t, beta1, beta2, eps, clip_coef);
+    OBTE_CHECK_LAUNCH("obte_adamw_multi_bf16");
+    return OBTE_OK;
+}
+
+extern "C" int obte_sumsq_multi_bf16(const obte_mt_args* a, float* out, obte_stream s) {
+    OBTE_REQUIRE(out, "obte_sumsq_multi_bf16: null output");
+    MtTable t;
+    const int blocks = mt_build(a, 0.9f, 0.999f, &t, "obte_sumsq_multi_bf16", false);
+    if (blocks < 0) return blocks;
+    hipLaunchKernelGGL(sumsq_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, t, out);
+    OBTE_CHECK_LAUNCH("obte_sumsq_multi_bf16");
     return OBTE_OK;
 }

@@ -23,6 +23,7 @@
 // Split-K (for weight gradients whose output has fewer tiles than the chip has CUs): each split writes an fp32
 // partial tile to a slab; a second kernel sums the splits in a fixed order (bitwise reproducible) and rounds once.
 #include "common.h"
+#include <string.h>
 
 int obte_gemm_bf16_v1(const obte_gemm_args* g, obte_stream s);
 
@@ -465,6 +466,11 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     p.M = g->M; p.N = g->N; p.K = g->K; p.lda = g->lda; p.ldb = g->ldb; p.ldd = g->ldd;
     p.a_elems = (g->a_kmajor ? g->M : g->K) * g->lda;
     p.b_elems = (g->b_kmajor ? g->N : g->K) * g->ldb;
+    {   // timing-only diagnostic: zero-record descriptors drop every LDS-DMA (results are wrong; never set in production)
+        static int noload = -1;
+        if (noload < 0) { const char* e = getenv("OBTE_GEMM_DEBUG"); noload = (e && !strcmp(e, "noload")) ? 1 : 0; }
+        if (noload) { p.a_elems = 0; p.b_elems = 0; }
+    }
     const int64_t tm = cdiv64(g->M, BM), tn = cdiv64(g->N, pl.bn);
     OBTE_REQUIRE(tm * tn < (1ll << 26), "obte_gemm_bf16: too many tiles");
     p.tiles_m = (int)tm; p.tiles_n = (int)tn;

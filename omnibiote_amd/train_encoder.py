@@ -95,32 +95,45 @@ class FusedAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, max_norm: Optional[float] = None):
+        """Multi-tensor launches: <= 32 tensors per kernel (per parameter group, since betas/eps are per group)."""
+        import ctypes as C
+        from . import _lib as L
         from . import ops
-        params = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
-        if not params:
+        lib = L.lib()
+        stream = torch.cuda.current_stream().cuda_stream
+        batches = []   # (MtArgs, betas, eps)
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            for i in range(0, len(ps), L.MT_MAX):
+                chunk = ps[i:i + L.MT_MAX]
+                a = L.MtArgs()
+                a.count = len(chunk)
+                for j, p in enumerate(chunk):
+                    st = self.state[p]
+                    if not st:
+                        st["step"] = 0
+                        st["exp_avg"] = torch.zeros_like(p)
+                        st["exp_avg_sq"] = torch.zeros_like(p)
+                    st["step"] += 1
+                    if p.dtype != torch.bfloat16 or p.numel() % 8 or not p.is_cuda:
+                        raise RuntimeError("FusedAdamW needs bf16 GPU parameters with numel % 8 == 0")
+                    a.p[j], a.g[j], a.m[j], a.v[j] = p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                    a.n[j], a.lr[j], a.weight_decay[j], a.step[j] = p.numel(), float(group["lr"]), float(group["weight_decay"]), st["step"]
+                batches.append((a, group["betas"], group["eps"]))
+        if not batches:
             return None
-        dev = params[0].device
         clip = None
         if max_norm is not None:
+            dev = torch.device("cuda", torch.cuda.current_device())
             if self._norm_sq is None or self._norm_sq.device != dev:
                 self._norm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
             self._norm_sq.zero_()
-            for p in params:
-                ops.sumsq_(p.grad, self._norm_sq)
+            for a, _, _ in batches:
+                L.check(lib.obte_sumsq_multi_bf16(C.byref(a), self._norm_sq.data_ptr(), stream), "obte_sumsq_multi_bf16")
             clip = torch.clamp(max_norm / (self._norm_sq.sqrt() + 1e-6), max=1.0)
-        for group in self.param_groups:
-            b1, b2 = group["betas"]
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p)
-                    st["exp_avg_sq"] = torch.zeros_like(p)
-                st["step"] += 1
-                ops.adamw_step_(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), b1, b2,
-                                group["eps"], group["weight_decay"], st["step"], clip)
+        for a, (b1, b2), eps in batches:
+            L.check(lib.obte_adamw_multi_bf16(C.byref(a), b1, b2, eps, None if clip is None else clip.data_ptr(), stream),
+                    "obte_adamw_multi_bf16")
         return None if clip is None else self._norm_sq
 
 

@@ -432,3 +432,36 @@ def test_gemm_both_tile_widths(monkeypatch, bn):
     close(d, acc, atol=0.03, what="gelu pre")
     close(d2, R.gelu_erf(d.float().cpu()), atol=1e-3, rtol=2.0 ** -8, what="gelu act")
     close(o.linear_fwd(x.to(DEV), w.to(DEV), alpha=1 / 42.0), acc / 42.0, atol=2e-3, what="alpha")
+
+
+def test_multi_tensor_adamw_matches_single_tensor_kernel():
+    """The multi-tensor launch (<= 32 tensors per kernel, per-tensor lr / weight decay / step) must reproduce the
+    single-tensor kernel bit for bit, and the multi-tensor sum of squares must equal the sum of the single ones."""
+    import ctypes as C
+    from omnibiote_amd import _lib as LL
+    sizes = [8, 1024, 16384, 16392, 50000 * 8, 1024, 24]
+    lrs = [1e-2, 2e-3, 5e-4, 1e-2, 3e-3, 1e-2, 7e-3]
+    wds = [0.0, 1e-2, 0.4, 1e-2, 1e-2, 0.1, 1e-2]
+    steps = [1, 2, 3, 4, 5, 6, 7]
+    b1, b2, eps, clip = 0.9, 0.999, 1e-8, 0.7
+    P = [rnd(n, seed=10 + i).to(DEV) for i, n in enumerate(sizes)]
+    G = [rnd(n, seed=30 + i, scale=0.1).to(DEV) for i, n in enumerate(sizes)]
+    Mo = [rnd(n, seed=50 + i, scale=0.01).to(DEV) for i, n in enumerate(sizes)]
+    Vo = [(rnd(n, seed=70 + i, scale=0.01).float() ** 2).to(BF).to(DEV) for i, n in enumerate(sizes)]
+    cc = torch.tensor([clip], device=DEV)
+    ref = [(p.clone(), m.clone(), v.clone()) for p, m, v in zip(P, Mo, Vo)]
+    for (p, m, v), g, lr, wd, st in zip(ref, G, lrs, wds, steps):
+        ops().adamw_step_(p, g, m, v, lr, b1, b2, eps, wd, st, cc)
+    a = LL.MtArgs()
+    a.count = len(sizes)
+    for j in range(len(sizes)):
+        a.p[j], a.g[j], a.m[j], a.v[j] = P[j].data_ptr(), G[j].data_ptr(), Mo[j].data_ptr(), Vo[j].data_ptr()
+        a.n[j], a.lr[j], a.weight_decay[j], a.step[j] = sizes[j], lrs[j], wds[j], steps[j]
+    stream = torch.cuda.current_stream().cuda_stream
+    tot = torch.zeros(1, device=DEV)
+    LL.check(LL.lib().obte_sumsq_multi_bf16(C.byref(a), tot.data_ptr(), stream))
+    LL.check(LL.lib().obte_adamw_multi_bf16(C.byref(a), b1, b2, eps, cc.data_ptr(), stream))
+    for (p, m, v), pp, mm, vv in zip(ref, P, Mo, Vo):
+        assert torch.equal(p, pp) and torch.equal(m, mm) and torch.equal(v, vv)
+    want = sum((g.float() ** 2).sum().item() for g in G)
+    assert abs(tot.item() - want) <= 1e-4 * want
