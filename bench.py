@@ -167,7 +167,11 @@ def main():
     n_params = m.get_num_params()
     from omnibiote_amd import tune
     tune.tune_model_shapes(a.mini_batch_size * cfg["ctx_len"], cfg["n_embd"], 2 ** 16, device=dev, verbose=(rank == 0 and bool(a.shapes_out)))
-    model = TE.wrap_ddp(m, local) if world > 1 else m
+    force_ddp = os.environ.get("OBTE_FORCE_DDP") == "1"   # rehearse the N>1 code path on one GPU
+    if force_ddp and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    model = TE.wrap_ddp(m, local) if (world > 1 or force_ddp) else m
     total_iters = 1000
     opt, sched = TE.build_optimizer(m, h, total_iters)
     step = TE.TrainStep(model, opt, sched, mini_batch_size=a.mini_batch_size, n_head=cfg["n_head"])
