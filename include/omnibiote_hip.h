@@ -64,7 +64,8 @@ int obte_layernorm_bwd(const obte_bf16* dy, const obte_bf16* x, const obte_bf16*
 enum {
     OBTE_EPI_NONE = 0,      /* d = bf16(alpha*acc) */
     OBTE_EPI_GELU = 1,      /* d = bf16(acc) ; d2 = bf16(gelu_erf_1.41421(d))   (model.py:23-25,163-165) */
-    OBTE_EPI_ADD = 2,       /* d = bf16(aux + bf16(acc))    residual add (model.py:179-180) */
+    OBTE_EPI_ADD = 2,       /* d = bf16(aux + bf16(alpha*acc))  residual add (model.py:179-180); aux may alias d
+                               (gradient accumulation in place) */
     OBTE_EPI_GELU_BWD = 3   /* d = bf16(bf16(acc) * gelu'(aux))  aux = pre-activation */
 };
 typedef struct {
@@ -81,7 +82,7 @@ int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s);
 /* Same, with a caller-owned scratch buffer that enables split-K (fp32 partial tiles summed in a fixed order by a
  * second kernel) when the output has too few tiles to fill 256 CUs — the weight-gradient shapes.
  * obte_gemm_workspace_bytes returns the size that lets the library split as it prefers (0 = no split wanted);
- * a NULL or smaller workspace simply disables the split.  Split-K needs epilogue NONE and ldd == N. */
+ * a NULL or smaller workspace simply disables the split.  Split-K needs epilogue NONE or ADD and ldd == N. */
 int64_t obte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64_t workspace_bytes, obte_stream s);
 /* Tuned plans.  The library holds two GEMM structures (1: 128x128 tiles, two workgroups per CU; 2: 256x128 or
@@ -136,6 +137,9 @@ int obte_embedding_fwd(const int64_t* idx, const obte_bf16* wte, obte_bf16* out,
 int64_t obte_embedding_bwd_ws_bytes(int64_t rows, int cols);
 int obte_embedding_bwd(const int64_t* idx, const int32_t* order, const obte_bf16* dout, obte_bf16* dwte,
                        void* ws, int64_t rows, int cols, int64_t vocab, obte_stream s);
+/* accumulate != 0: dwte holds an existing gradient; only the touched rows are read-modified-written (no memset). */
+int obte_embedding_bwd_acc(const int64_t* idx, const int32_t* order, const obte_bf16* dout, obte_bf16* dwte,
+                           void* ws, int64_t rows, int cols, int64_t vocab, int accumulate, obte_stream s);
 
 /* ---- masked-LM cross entropy, forward + backward in one pass (training/train_encoder.py:301-305) -------------
  * loss_sum[0] += sum over rows with mlm_mask!=0 of (logsumexp(logits[r]) - logits[r,target[r]]) * row_scale
@@ -182,6 +186,14 @@ int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte_bf16* y, v
 int obte_block_bwd(const obte_block_desc* d, const obte_bf16* x, const obte_bf16* dy, const void* act, void* ws,
                    obte_bf16* dx, obte_bf16* dln1_w, obte_bf16* dattn_w, obte_bf16* dproj_w, obte_bf16* dln2_w,
                    obte_bf16* dfc_w, obte_bf16* dmlp_w, obte_stream s);
+
+/* Same as obte_block_bwd; with accumulate_matrices != 0 the four weight-matrix gradients are ADDED to the contents of
+ * d*_w (bf16(old + bf16(new)), what autograd's accumulation would produce) instead of overwriting them — gradient
+ * accumulation over micro-batches without the separate read-modify-write pass.  The LayerNorm gradients are still
+ * overwritten. */
+int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, const obte_bf16* dy, const void* act, void* ws,
+                       obte_bf16* dx, obte_bf16* dln1_w, obte_bf16* dattn_w, obte_bf16* dproj_w, obte_bf16* dln2_w,
+                       obte_bf16* dfc_w, obte_bf16* dmlp_w, int accumulate_matrices, obte_stream s);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,7 @@ SYMBOLS = {
     "obte_embedding_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int64, c_stream]),
     "obte_embedding_bwd_ws_bytes": (C.c_int64, [C.c_int64, C.c_int]),
     "obte_embedding_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int64, c_stream]),
+    "obte_embedding_bwd_acc": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int64, C.c_int, c_stream]),
     "obte_masked_ce_fwd_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int64, C.c_int64, c_stream]),
     "obte_adamw_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int32, C.c_void_p, c_stream]),
     "obte_sumsq_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, c_stream]),
@@ -88,6 +89,7 @@ SYMBOLS = {
     "obte_block_bwd_ws_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "obte_block_fwd": (C.c_int, [C.POINTER(BlockDesc), C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
     "obte_block_bwd": (C.c_int, [C.POINTER(BlockDesc)] + [C.c_void_p] * 11 + [c_stream]),
+    "obte_block_bwd_acc": (C.c_int, [C.POINTER(BlockDesc)] + [C.c_void_p] * 11 + [C.c_int, c_stream]),
 }
 
 _lib = None

@@ -113,9 +113,20 @@ extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte
     return OBTE_OK;
 }
 
+extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, const obte_bf16* dy, const void* act, void* ws,
+                                  obte_bf16* dx, obte_bf16* dln1_w, obte_bf16* dattn_w, obte_bf16* dproj_w, obte_bf16* dln2_w,
+                                  obte_bf16* dfc_w, obte_bf16* dmlp_w, int accumulate_matrices, obte_stream s);
+
 extern "C" int obte_block_bwd(const obte_block_desc* d, const obte_bf16* x, const obte_bf16* dy, const void* act, void* ws,
                               obte_bf16* dx, obte_bf16* dln1_w, obte_bf16* dattn_w, obte_bf16* dproj_w, obte_bf16* dln2_w,
                               obte_bf16* dfc_w, obte_bf16* dmlp_w, obte_stream s) {
+    return obte_block_bwd_acc(d, x, dy, act, ws, dx, dln1_w, dattn_w, dproj_w, dln2_w, dfc_w, dmlp_w, 0, s);
+}
+
+extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, const obte_bf16* dy, const void* act, void* ws,
+                                  obte_bf16* dx, obte_bf16* dln1_w, obte_bf16* dattn_w, obte_bf16* dproj_w, obte_bf16* dln2_w,
+                                  obte_bf16* dfc_w, obte_bf16* dmlp_w, int accumulate_matrices, obte_stream s) {
+    const int wepi = accumulate_matrices ? OBTE_EPI_ADD : OBTE_EPI_NONE;   // dW += ... straight into the .grad buffers
     TRY(check_desc("obte_block_bwd", d));
     OBTE_REQUIRE(x && dy && act && ws && dx && dln1_w && dattn_w && dproj_w && dln2_w && dfc_w && dmlp_w, "obte_block_bwd: null pointer");
     const int C = d->n_embd, H = d->n_head, hs = C / H;
@@ -136,13 +147,13 @@ extern "C" int obte_block_bwd(const obte_block_desc* d, const obte_bf16* x, cons
 
     // MLP: out = x1 + hact W_mlp^T
     TRY(gemm(dy, d->mlp_w, dhpre, M, 4 * C, C, C, 4 * C, 1, 0, OBTE_EPI_GELU_BWD, hpre, nullptr, s));          // dhpre = (dy W_mlp) * gelu'(hpre)
-    TRY(gemm(dy, hact, dmlp_w, C, 4 * C, M, C, 4 * C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_mlp = dy^T hact
+    TRY(gemm(dy, hact, dmlp_w, C, 4 * C, M, C, 4 * C, 0, 0, wepi, accumulate_matrices ? dmlp_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_mlp = dy^T hact
     TRY(gemm(dhpre, d->fc_w, dh, M, C, 4 * C, 4 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh2 = dhpre W_fc
-    TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, M, 4 * C, C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_fc = dhpre^T h2
+    TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, M, 4 * C, C, 0, 0, wepi, accumulate_matrices ? dfc_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_fc = dhpre^T h2
     TRY(obte_layernorm_bwd(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, lnws, M, C, s));                     // dx1 = dy + LN2'(dh2)
     // attention: x1 = x + y W_proj^T
     TRY(gemm(dx1, d->proj_w, dyattn, M, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));                  // dy_attn = dx1 W_proj
-    TRY(gemm(dx1, yat, dproj_w, C, C, M, C, C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s, gws, W.gemmws_bytes));                       // dW_proj = dx1^T y
+    TRY(gemm(dx1, yat, dproj_w, C, C, M, C, C, 0, 0, wepi, accumulate_matrices ? dproj_w : nullptr, nullptr, s, gws, W.gemmws_bytes));                       // dW_proj = dx1^T y
     obte_attn_bwd_args ab = {};
     ab.qkv = qkv; ab.o = yat; ab.d_o = dyattn; ab.lse = lse; ab.delta = delta; ab.dqkv = dqkv;
     ab.rope_cos = d->rope_cos; ab.rope_sin = d->rope_sin;
@@ -150,7 +161,7 @@ extern "C" int obte_block_bwd(const obte_block_desc* d, const obte_bf16* x, cons
     ab.B = d->B; ab.T = d->T; ab.n_head = H; ab.head_dim = hs; ab.scale = 8.0f / (float)C;
     TRY(obte_attn_bwd(&ab, s));
     TRY(gemm(dqkv, d->attn_w, dh, M, C, 3 * C, 3 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh1 = dqkv W_attn
-    TRY(gemm(dqkv, h1, dattn_w, 3 * C, C, M, 3 * C, C, 0, 0, OBTE_EPI_NONE, nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_attn = dqkv^T h1
+    TRY(gemm(dqkv, h1, dattn_w, 3 * C, C, M, 3 * C, C, 0, 0, wepi, accumulate_matrices ? dattn_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_attn = dqkv^T h1
     TRY(obte_layernorm_bwd(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, lnws, M, C, s));                      // dx = dx1 + LN1'(dh1)
     return OBTE_OK;
 }

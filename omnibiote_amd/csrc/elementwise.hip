@@ -61,6 +61,21 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 // ---------------------------------------------------------------------------------------------------------
 constexpr int EMB_CHUNK = 32;
 
+// ACC: add to the existing row instead of overwriting it (each touched row is written by exactly one thread-set).
+template <bool ACC>
+__device__ __forceinline__ void embed_store_row(bf16* dst, const float (&acc)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
+    if (ACC) {
+        const bf16x8 old = *reinterpret_cast<const bf16x8*>(dst);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(old[j]) + bf2f(o[j]));
+    }
+    *reinterpret_cast<bf16x8*>(dst) = o;
+}
+
+template <bool ACC>
 __global__ __launch_bounds__(128) void embed_bwd_chunk_kernel(const int64_t* __restrict__ idx, const int32_t* __restrict__ order,
                                                                const bf16* __restrict__ dout, bf16* __restrict__ dwte,
                                                                float* __restrict__ slab, int64_t rows, int cols) {
@@ -96,10 +111,7 @@ __global__ __launch_bounds__(128) void embed_bwd_chunk_kernel(const int64_t* __r
                     *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0], acc[1], acc[2], acc[3]};
                     *reinterpret_cast<f32x4*>(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
                 } else {
-                    bf16x8 o;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
-                    *reinterpret_cast<bf16x8*>(dwte + s_tok[i + 1] * cols + col) = o;
+                    embed_store_row<ACC>(dwte + s_tok[i + 1] * cols + col, acc);
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] = 0.f;
@@ -109,6 +121,7 @@ __global__ __launch_bounds__(128) void embed_bwd_chunk_kernel(const int64_t* __r
     }
 }
 
+template <bool ACC>
 __global__ __launch_bounds__(128) void embed_bwd_span_kernel(const int64_t* __restrict__ idx, const int32_t* __restrict__ order,
                                                               bf16* __restrict__ dwte, const float* __restrict__ slab,
                                                               int64_t rows, int cols, int64_t nchunks) {
@@ -135,10 +148,7 @@ __global__ __launch_bounds__(128) void embed_bwd_span_kernel(const int64_t* __re
             for (int j = 0; j < 8; ++j) acc[j] += s2[j];
             if (idx[order[q1 - 1]] != last) break;  // the run ended inside chunk cc
         }
-        bf16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
-        *reinterpret_cast<bf16x8*>(dwte + last * cols + col) = o;
+        embed_store_row<ACC>(dwte + last * cols + col, acc);
     }
 }
 
@@ -352,24 +362,37 @@ extern "C" int64_t obte_embedding_bwd_ws_bytes(int64_t rows, int cols) {
     return cdiv64(rows, EMB_CHUNK) * 2 * (int64_t)cols * (int64_t)sizeof(float);
 }
 
-extern "C" int obte_embedding_bwd(const int64_t* idx, const int32_t* order, const obte_bf16* dout, obte_bf16* dwte,
-                                  void* ws, int64_t rows, int cols, int64_t vocab, obte_stream s) {
+extern "C" int obte_embedding_bwd_acc(const int64_t* idx, const int32_t* order, const obte_bf16* dout, obte_bf16* dwte,
+                                      void* ws, int64_t rows, int cols, int64_t vocab, int accumulate, obte_stream s) {
     OBTE_REQUIRE(idx && order && dout && dwte && ws, "obte_embedding_bwd: null pointer");
     OBTE_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && vocab > 0, "obte_embedding_bwd: bad shape");
     OBTE_REQUIRE(rows < (1ll << 31), "obte_embedding_bwd: too many rows");
     hipStream_t st = (hipStream_t)s;
-    if (hipMemsetAsync(dwte, 0, (size_t)vocab * cols * sizeof(obte_bf16), st) != hipSuccess) {
+    if (!accumulate && hipMemsetAsync(dwte, 0, (size_t)vocab * cols * sizeof(obte_bf16), st) != hipSuccess) {
         obte_set_error("obte_embedding_bwd: memset failed");
         return OBTE_ELAUNCH;
     }
     const int64_t nchunks = cdiv64(rows, EMB_CHUNK);
-    hipLaunchKernelGGL(embed_bwd_chunk_kernel, dim3((unsigned)nchunks), dim3(128), 0, st, idx, order, (const bf16*)dout,
-                       (bf16*)dwte, (float*)ws, rows, cols);
+    if (accumulate)
+        hipLaunchKernelGGL(embed_bwd_chunk_kernel<true>, dim3((unsigned)nchunks), dim3(128), 0, st, idx, order, (const bf16*)dout,
+                           (bf16*)dwte, (float*)ws, rows, cols);
+    else
+        hipLaunchKernelGGL(embed_bwd_chunk_kernel<false>, dim3((unsigned)nchunks), dim3(128), 0, st, idx, order, (const bf16*)dout,
+                           (bf16*)dwte, (float*)ws, rows, cols);
     OBTE_CHECK_LAUNCH("obte_embedding_bwd(chunk)");
-    hipLaunchKernelGGL(embed_bwd_span_kernel, dim3((unsigned)nchunks), dim3(128), 0, st, idx, order, (bf16*)dwte,
-                       (const float*)ws, rows, cols, nchunks);
+    if (accumulate)
+        hipLaunchKernelGGL(embed_bwd_span_kernel<true>, dim3((unsigned)nchunks), dim3(128), 0, st, idx, order, (bf16*)dwte,
+                           (const float*)ws, rows, cols, nchunks);
+    else
+        hipLaunchKernelGGL(embed_bwd_span_kernel<false>, dim3((unsigned)nchunks), dim3(128), 0, st, idx, order, (bf16*)dwte,
+                           (const float*)ws, rows, cols, nchunks);
     OBTE_CHECK_LAUNCH("obte_embedding_bwd(span)");
     return OBTE_OK;
+}
+
+extern "C" int obte_embedding_bwd(const int64_t* idx, const int32_t* order, const obte_bf16* dout, obte_bf16* dwte,
+                                  void* ws, int64_t rows, int cols, int64_t vocab, obte_stream s) {
+    return obte_embedding_bwd_acc(idx, order, dout, dwte, ws, rows, cols, vocab, 0, s);
 }
 
 extern "C" int obte_masked_ce_fwd_bwd(const obte_bf16* logits, const int64_t* target, const uint8_t* mlm_mask,

@@ -253,7 +253,7 @@ int obte_gemm_bf16_v1(const obte_gemm_args* g, obte_stream s) {
     OBTE_REQUIRE(g->lda <= 1 << 20 && g->ldb <= 1 << 20, "obte_gemm_bf16: leading dimension too large");
     if (g->epilogue == OBTE_EPI_ADD || g->epilogue == OBTE_EPI_GELU_BWD) OBTE_REQUIRE(g->aux, "obte_gemm_bf16: epilogue needs aux");
     if (g->epilogue == OBTE_EPI_GELU) OBTE_REQUIRE(g->d2, "obte_gemm_bf16: GELU epilogue needs d2");
-    if (g->epilogue != OBTE_EPI_NONE) OBTE_REQUIRE(g->alpha == 1.0f, "obte_gemm_bf16: alpha != 1 only with EPI_NONE");
+    if (g->epilogue != OBTE_EPI_NONE && g->epilogue != OBTE_EPI_ADD) OBTE_REQUIRE(g->alpha == 1.0f, "obte_gemm_bf16: alpha != 1 only with EPI_NONE / EPI_ADD");
     GemmParams p;
     p.a = (const bf16*)g->a; p.b = (const bf16*)g->b; p.d = (bf16*)g->d; p.aux = (const bf16*)g->aux; p.d2 = (bf16*)g->d2;
     p.M = g->M; p.N = g->N; p.K = g->K; p.lda = g->lda; p.ldb = g->ldb; p.ldd = g->ldd;

@@ -301,8 +301,8 @@ OBTE_INST(false, false, 256)
 #undef OBTE_INST
 
 // d[m][n] = bf16(alpha * sum_s slab[s][m][n]) in split order
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, bf16* __restrict__ d, int64_t MN4,
-                                                             int64_t MN, int splits, float alpha) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, bf16* __restrict__ d, const bf16* aux,
+                                                             int64_t MN4, int64_t MN, int splits, float alpha) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < MN4; i += (int64_t)gridDim.x * 256) {
         f32x4 s = *reinterpret_cast<const f32x4*>(slab + i * 4);
         for (int k = 1; k < splits; ++k) {
@@ -312,6 +312,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         bf16x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = f2bf(s[j] * alpha);
+        if (aux) {   // EPI_ADD: d = bf16(aux + bf16(acc)); aux may alias d (each element is read, then written, by one thread)
+            const bf16x4 r = *reinterpret_cast<const bf16x4*>(aux + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = f2bf(bf2f(r[j]) + bf2f(o[j]));
+        }
         *reinterpret_cast<bf16x4*>(d + i * 4) = o;
     }
 }
@@ -394,6 +399,8 @@ static std::map<PlanKey, Plan> g_plans;
 static bool lookup_plan(const obte_gemm_args* g, Plan* out) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
     auto it = g_plans.find(PlanKey((g->a_kmajor ? 2 : 0) + (g->b_kmajor ? 1 : 0), g->epilogue, g->M, g->N, g->K));
+    if (it == g_plans.end() && g->epilogue == OBTE_EPI_ADD)   // accumulate-into-grad reuses the plan tuned for the plain form
+        it = g_plans.find(PlanKey((g->a_kmajor ? 2 : 0) + (g->b_kmajor ? 1 : 0), OBTE_EPI_NONE, g->M, g->N, g->K));
     if (it == g_plans.end()) return false;
     *out = it->second;
     return true;
@@ -447,11 +454,11 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     OBTE_REQUIRE(g->lda <= 1 << 20 && g->ldb <= 1 << 20, "obte_gemm_bf16: leading dimension too large");
     if (g->epilogue == OBTE_EPI_ADD || g->epilogue == OBTE_EPI_GELU_BWD) OBTE_REQUIRE(g->aux, "obte_gemm_bf16: epilogue needs aux");
     if (g->epilogue == OBTE_EPI_GELU) OBTE_REQUIRE(g->d2, "obte_gemm_bf16: GELU epilogue needs d2");
-    if (g->epilogue != OBTE_EPI_NONE) OBTE_REQUIRE(g->alpha == 1.0f, "obte_gemm_bf16: alpha != 1 only with EPI_NONE");
+    if (g->epilogue != OBTE_EPI_NONE && g->epilogue != OBTE_EPI_ADD) OBTE_REQUIRE(g->alpha == 1.0f, "obte_gemm_bf16: alpha != 1 only with EPI_NONE / EPI_ADD");
     hipStream_t st = (hipStream_t)s;
     const int prof = obte_prof_begin(st, (g->a_kmajor ? 8 : 0) + (g->b_kmajor ? 4 : 0) + g->epilogue, g->M, g->N, g->K);
     int rc;
-    const bool can_split = workspace && g->epilogue == OBTE_EPI_NONE && g->ldd == g->N;
+    const bool can_split = workspace && (g->epilogue == OBTE_EPI_NONE || g->epilogue == OBTE_EPI_ADD) && g->ldd == g->N;
     Plan pl;
     if (!lookup_plan(g, &pl)) pl = make_plan(g->M, g->N, g->K, can_split);
     if (pl.splits > 1 && (!can_split || (int64_t)pl.splits * g->M * g->N * 4 > workspace_bytes)) pl = make_plan(g->M, g->N, g->K, false);
@@ -488,7 +495,7 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
         int64_t blocks = cdiv64(mn / 4, 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)workspace, (bf16*)g->d,
-                           mn / 4, mn, p.splits, g->alpha);
+                           g->epilogue == OBTE_EPI_ADD ? (const bf16*)g->aux : (const bf16*)nullptr, mn / 4, mn, p.splits, g->alpha);
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) { obte_set_error("obte_gemm_bf16(split-K reduce): %s", hipGetErrorString(e_)); rc = OBTE_ELAUNCH; }
     }

@@ -88,6 +88,41 @@ def _require_hip(t: torch.Tensor, what: str) -> None:
     L.lib()  # raises HipLibraryError if the shared library is missing
 
 
+# ------------------------------------------------------------------------------------------ in-place grad accumulation
+# While this flag is set, the backward of the big matrices adds straight into an existing ``param.grad`` (the wgrad GEMM's
+# epilogue / the embedding scatter do the read-modify-write) and hands autograd ``None`` for them, which removes the
+# separate ``grad += new`` pass over 470 MB per micro-batch.  The arithmetic is the one autograd would do
+# (bf16(old + bf16(new))).  Only valid while nothing needs to observe per-micro-batch gradients: the harness sets it for
+# the micro-batches that run under DDP's no_sync(), never for the last one (whose AccumulateGrad hooks feed the reducer).
+_ACCUMULATE_INPLACE = False
+
+
+class accumulate_grads_inplace:
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global _ACCUMULATE_INPLACE
+        self.prev = _ACCUMULATE_INPLACE
+        _ACCUMULATE_INPLACE = self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _ACCUMULATE_INPLACE
+        _ACCUMULATE_INPLACE = self.prev
+        return False
+
+
+def _grad_slot(param):
+    """The existing bf16 gradient of ``param`` if in-place accumulation is on and applicable, else None."""
+    if not _ACCUMULATE_INPLACE:
+        return None
+    g = getattr(param, "grad", None)
+    if g is None or g.dtype != torch.bfloat16 or not g.is_contiguous() or g.shape != param.shape:
+        return None
+    return g
+
+
 # ------------------------------------------------------------------------------------------------- autograd glue
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
@@ -110,6 +145,7 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, w, alpha):
         ctx.save_for_backward(x, w)
         ctx.alpha = alpha
+        ctx.w_param = w
         x2 = x.reshape(-1, x.shape[-1])
         y = ops.linear_fwd(x2.contiguous(), w, alpha=alpha)
         return y.view(*x.shape[:-1], w.shape[0])
@@ -123,7 +159,10 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear_dgrad(dy2, w, alpha=ctx.alpha).view_as(x)
         if ctx.needs_input_grad[1]:
-            dw = ops.linear_wgrad(dy2, x2, alpha=ctx.alpha)
+            slot = _grad_slot(ctx.w_param)
+            dw = ops.linear_wgrad(dy2, x2, alpha=ctx.alpha, accumulate_into=slot)
+            if slot is not None:
+                dw = None
         return dx, dw, None
 
 
@@ -132,12 +171,13 @@ class _EmbeddingFn(torch.autograd.Function):
     def forward(ctx, idx, wte):
         ctx.save_for_backward(idx)
         ctx.vocab = wte.shape[0]
+        ctx.w_param = wte
         return ops.embedding_fwd(idx.contiguous(), wte)
 
     @staticmethod
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
-        return None, ops.embedding_bwd(idx.contiguous(), dout.contiguous(), ctx.vocab)
+        return None, ops.embedding_bwd(idx.contiguous(), dout.contiguous(), ctx.vocab, accumulate_into=_grad_slot(ctx.w_param))
 
 
 class _BlockFn(torch.autograd.Function):
@@ -150,12 +190,15 @@ class _BlockFn(torch.autograd.Function):
         y, act = ops.block_fwd(x, params, (rope_cos, rope_sin), n_head, mask)
         ctx.save_for_backward(x, act, rope_cos, rope_sin, *params)
         ctx.n_head, ctx.mask = n_head, mask
+        ctx.w_params = params
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, act, rope_cos, rope_sin, *params = ctx.saved_tensors
-        dx, grads = ops.block_bwd(x, dy.contiguous(), act, tuple(params), (rope_cos, rope_sin), ctx.n_head, ctx.mask)
+        slots = [_grad_slot(w) for w in ctx.w_params]
+        dx, grads = ops.block_bwd(x, dy.contiguous(), act, tuple(params), (rope_cos, rope_sin), ctx.n_head, ctx.mask,
+                                  accumulate_into=slots)
         return (dx, *grads, None, None, None, None)
 
 

@@ -84,7 +84,7 @@ def gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True, epilogue=L.EPI_NONE, aux=N
         _need(aux, "aux"); assert aux.numel() == M * N
     g = L.GemmArgs(_ptr(a), _ptr(b), _ptr(d), _ptr(aux), _ptr(d2), M, N, K, lda, ldb, N,
                    int(a_kmajor), int(b_kmajor), epilogue, float(alpha))
-    ws_bytes = int(L.lib().obte_gemm_workspace_bytes(M, N, K)) if (epilogue == L.EPI_NONE and M * N <= (1 << 23)) else 0
+    ws_bytes = int(L.lib().obte_gemm_workspace_bytes(M, N, K)) if (epilogue in (L.EPI_NONE, L.EPI_ADD) and M * N <= (1 << 23)) else 0
     if ws_bytes > 0:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
         L.check(L.lib().obte_gemm_bf16_ws(C.byref(g), _ptr(ws), ws_bytes, _stream()), "obte_gemm_bf16_ws")
@@ -109,11 +109,13 @@ def linear_dgrad(dy2d, w, epilogue=L.EPI_NONE, aux=None, alpha=1.0):
     return gemm(dy2d, w, M, K, N, True, False, epilogue, aux, alpha)
 
 
-def linear_wgrad(dy2d, x2d, alpha=1.0):
-    """dW = dy^T x for dy [M,N], x [M,K] -> [N,K]."""
+def linear_wgrad(dy2d, x2d, alpha=1.0, accumulate_into=None):
+    """dW = dy^T x for dy [M,N], x [M,K] -> [N,K].  accumulate_into: add into this tensor in place (alpha must be 1)."""
     M, N = dy2d.shape
     K = x2d.shape[1]
     assert x2d.shape[0] == M
+    if accumulate_into is not None:
+        return gemm(dy2d, x2d, N, K, M, False, False, L.EPI_ADD, accumulate_into, alpha, out=accumulate_into)
     return gemm(dy2d, x2d, N, K, M, False, False, L.EPI_NONE, None, alpha)
 
 
@@ -208,13 +210,20 @@ def embedding_fwd(idx, wte):
     return out
 
 
-def embedding_bwd(idx, dout, vocab):
+def embedding_bwd(idx, dout, vocab, accumulate_into=None):
+    """accumulate_into: an existing dense (vocab, C) gradient; the touched rows are updated in place
+    (bf16(old + bf16(sum))), nothing else is read or written."""
     _need(idx, "idx", torch.int64); _need(dout, "dout")
     rows, Cc = idx.numel(), dout.shape[-1]
     # the order is plumbing (a stable sort of <= a few 10k token ids); the summation itself is ours
     order = torch.sort(idx.reshape(-1), stable=True).indices.to(torch.int32)
-    dwte = torch.empty((vocab, Cc), dtype=bf16, device=dout.device)
     ws = torch.empty(max(int(L.lib().obte_embedding_bwd_ws_bytes(rows, Cc)), 16), dtype=torch.uint8, device=dout.device)
+    if accumulate_into is not None:
+        _need(accumulate_into, "grad"); assert tuple(accumulate_into.shape) == (vocab, Cc)
+        L.check(L.lib().obte_embedding_bwd_acc(_ptr(idx), _ptr(order), _ptr(dout), _ptr(accumulate_into), _ptr(ws), rows, Cc, vocab,
+                                                1, _stream()), "obte_embedding_bwd_acc")
+        return None
+    dwte = torch.empty((vocab, Cc), dtype=bf16, device=dout.device)
     L.check(L.lib().obte_embedding_bwd(_ptr(idx), _ptr(order), _ptr(dout), _ptr(dwte), _ptr(ws), rows, Cc, vocab, _stream()),
             "obte_embedding_bwd")
     return dwte
@@ -273,13 +282,25 @@ def block_fwd(x, params, rope, H, mask: MaskSpec):
     return y, act
 
 
-def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec):
+def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec, accumulate_into=None):
+    """accumulate_into: optional list of 6 tensors-or-None (same order as params).  When the four matrix entries are all
+    given, their gradients are added into those tensors in place and the corresponding returned grads are None."""
     _need(x, "x"); _need(dy, "dy")
     B, T, Cc = x.shape
     ws = torch.empty(int(L.lib().obte_block_bwd_ws_bytes(B, T, Cc, H)), dtype=torch.uint8, device=x.device)
     dx = torch.empty_like(x)
-    grads = [torch.empty_like(w) for w in params]
+    acc = accumulate_into is not None and all(accumulate_into[i] is not None for i in (1, 2, 4, 5))
+    grads = []
+    for i, w in enumerate(params):
+        if acc and i in (1, 2, 4, 5):
+            g = accumulate_into[i]
+            _need(g, "grad"); assert g.shape == w.shape
+            grads.append(g)
+        else:
+            grads.append(torch.empty_like(w))
     d = _block_desc(B, T, Cc, H, params, rope, mask)
-    L.check(L.lib().obte_block_bwd(C.byref(d), _ptr(x), _ptr(dy), _ptr(act), _ptr(ws), _ptr(dx), *[_ptr(g) for g in grads],
-                                    _stream()), "obte_block_bwd")
+    L.check(L.lib().obte_block_bwd_acc(C.byref(d), _ptr(x), _ptr(dy), _ptr(act), _ptr(ws), _ptr(dx), *[_ptr(g) for g in grads],
+                                        int(acc), _stream()), "obte_block_bwd")
+    if acc:
+        grads = [None if i in (1, 2, 4, 5) else g for i, g in enumerate(grads)]
     return dx, grads

@@ -150,6 +150,12 @@ class TrainStep:
         self.sync_every = sync_every_micro_step
         self.max_grad_norm = max_grad_norm
 
+    def _inplace(self, enabled: bool):
+        if self.loss_impl != "fused":     # the CPU-oracle configuration of the tests: plain autograd
+            return contextlib.nullcontext()
+        from .model import accumulate_grads_inplace
+        return accumulate_grads_inplace(enabled)
+
     def _mask(self, tokens: torch.Tensor, dtype):
         from . import masks
         rm = masks.RangeMask.from_tokens(tokens, padding=self.use_padding)
@@ -187,7 +193,9 @@ class TrainStep:
             ctx = contextlib.nullcontext()
             if hasattr(self.model, "no_sync") and not last and not self.sync_every:
                 ctx = self.model.no_sync()
-            with ctx:
+            # all but the last micro-batch: nobody observes the per-micro-batch gradients, so the big matrices are
+            # accumulated by the wgrad epilogues themselves (model.accumulate_grads_inplace)
+            with ctx, self._inplace(not last and not self.sync_every):
                 logits = self.model(x, attn_mask=attn_mask)
                 cum_loss += self._loss_backward(logits, y, mask[j * self.mini:(j + 1) * self.mini], n_accum)
         if isinstance(self.optimizer, FusedAdamW):

@@ -219,3 +219,30 @@ def test_loss_curve_tracks_oracle_step_for_step():
     assert ref_losses[-1] < ref_losses[0], ref_losses          # it actually trains
     for a, b in zip(losses, ref_losses):
         assert abs(a - b) <= 0.03 * abs(b) + 0.02, (losses, ref_losses)
+
+
+def test_inplace_gradient_accumulation_is_bitwise_autograd_accumulation(golden_dir):
+    """Accumulating micro-batch gradients inside the wgrad epilogues / embedding scatter (accumulate_grads_inplace) must
+    give exactly what autograd's ``grad += new`` gives: same bf16 arithmetic, no extra pass."""
+    from omnibiote_amd import ops
+    from omnibiote_amd.model import accumulate_grads_inplace
+    g = load(golden_dir, "wide_bf16_mask")
+    H = int(g["cfg"][3])
+    idx = torch.from_numpy(g["masked_ids"]).to(DEV)
+    tok = torch.from_numpy(g["tokens"]).to(DEV)
+    mlm = torch.from_numpy(g["mlm_mask"]).to(DEV)
+    results = []
+    for inplace in (False, True):
+        m = build(g, "cos_only")
+        for j in range(3):
+            rows = slice(0, 3) if j != 1 else slice(1, 3)     # different micro-batches (different row subsets)
+            mask = masks_for(g, "ranges", H)
+            from omnibiote_amd.masks import RangeMask
+            mask = RangeMask(mask.key_ranges[rows].contiguous())
+            with accumulate_grads_inplace(inplace and j > 0):
+                logits = m(idx[rows], attn_mask=mask)
+                _, dlogits = ops.masked_ce(logits, tok[rows], mlm[rows], 3)
+                logits.backward(dlogits)
+        results.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    for k in results[0]:
+        assert torch.equal(results[0][k], results[1][k]), k

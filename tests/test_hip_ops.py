@@ -465,3 +465,25 @@ def test_multi_tensor_adamw_matches_single_tensor_kernel():
         assert torch.equal(p, pp) and torch.equal(m, mm) and torch.equal(v, vv)
     want = sum((g.float() ** 2).sum().item() for g in G)
     assert abs(tot.item() - want) <= 1e-4 * want
+
+
+def test_wgrad_and_embedding_accumulate_in_place():
+    o = ops()
+    for (M, N, K) in [(1024, 1024, 2048), (384, 520, 300), (4096, 256, 512)]:   # split-K and plain plans
+        dy, x, old = rnd(K, M, seed=51, scale=0.5), rnd(K, N, seed=52, scale=0.5), rnd(M, N, seed=53)
+        fresh = o.linear_wgrad(dy.to(DEV), x.to(DEV))
+        want = (old.to(DEV).float() + fresh.float()).to(BF)            # autograd's accumulation
+        acc = old.clone().to(DEV)
+        o.linear_wgrad(dy.to(DEV), x.to(DEV), accumulate_into=acc)
+        assert torch.equal(acc, want), (M, N, K)
+        acc2 = old.clone().to(DEV)
+        o.linear_wgrad(dy.to(DEV), x.to(DEV), alpha=0.25, accumulate_into=acc2)
+        want2 = (old.to(DEV).float() + o.linear_wgrad(dy.to(DEV), x.to(DEV), alpha=0.25).float()).to(BF)
+        assert torch.equal(acc2, want2)
+    V, C, rows = 300, 128, 500
+    idx = torch.from_numpy(np.random.default_rng(3).integers(0, V, size=rows)); idx[:200] = 2
+    dout, old = rnd(rows, C, seed=54), rnd(V, C, seed=55)
+    fresh = o.embedding_bwd(idx.to(DEV), dout.to(DEV), V)
+    acc = old.clone().to(DEV)
+    assert o.embedding_bwd(idx.to(DEV), dout.to(DEV), V, accumulate_into=acc) is None
+    assert torch.equal(acc, (old.to(DEV).float() + fresh.float()).to(BF))
