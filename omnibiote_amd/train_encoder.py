@@ -151,7 +151,7 @@ class TrainStep:
         self.max_grad_norm = max_grad_norm
 
     def _inplace(self, enabled: bool):
-        if self.loss_impl != "fused":     # the CPU-oracle configuration of the tests: plain autograd
+        if self.loss_impl != "fused" or os.environ.get("OBTE_NO_INPLACE_ACCUM") == "1":   # CPU-oracle tests / A-B switch
             return contextlib.nullcontext()
         from .model import accumulate_grads_inplace
         return accumulate_grads_inplace(enabled)
