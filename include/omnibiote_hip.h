@@ -66,7 +66,9 @@ enum {
     OBTE_EPI_GELU = 1,      /* d = bf16(acc) ; d2 = bf16(gelu_erf_1.41421(d))   (model.py:23-25,163-165) */
     OBTE_EPI_ADD = 2,       /* d = bf16(aux + bf16(alpha*acc))  residual add (model.py:179-180); aux may alias d
                                (gradient accumulation in place) */
-    OBTE_EPI_GELU_BWD = 3   /* d = bf16(bf16(acc) * gelu'(aux))  aux = pre-activation */
+    OBTE_EPI_GELU_BWD = 3,  /* d = bf16(bf16(acc) * gelu'(aux))  aux = pre-activation */
+    OBTE_EPI_ADD_DROPOUT = 4 /* d = bf16(aux + dropout(bf16(acc)))   resid_dropout / mlp dropout (model.py:151,167);
+                                element (m,n) uses dropout index m*ldd+n of (dropout_seed, dropout_site) */
 };
 typedef struct {
     const obte_bf16* a; const obte_bf16* b; obte_bf16* d;
@@ -77,6 +79,7 @@ typedef struct {
     int32_t a_kmajor, b_kmajor;
     int32_t epilogue;
     float alpha;
+    float dropout_p; int32_t dropout_site; uint64_t dropout_seed;   /* EPI_ADD_DROPOUT only */
 } obte_gemm_args;
 int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s);
 /* Same, with a caller-owned scratch buffer that enables split-K (fp32 partial tiles summed in a fixed order by a
@@ -94,6 +97,15 @@ int obte_gemm_plan_set(int a_kmajor, int b_kmajor, int epilogue, int64_t M, int6
                        int splits);
 int obte_gemm_plan_clear(void);
 int64_t obte_gemm_workspace_bytes_max(int64_t M, int64_t N, int64_t K);
+
+/* ---- dropout (training/model.py:83-84,160,204) -------------------------------------------------------------------
+ * Every dropout site of the path draws its mask from one counter-based generator: element `idx` of site `site` is
+ * kept iff hash(seed, site, idx) >= p (see csrc/common.h drop_keep); kept values are scaled by 1/(1-p) and rounded to
+ * bf16.  Forward and backward regenerate the mask from (seed, site) — nothing is stored.  Sites: 0 embedding output
+ * (idx = row*C + col), 1 attention probabilities (idx = ((b*H+h)*T + q)*T + key), 2 attention c_proj output,
+ * 3 MLP c_proj output (idx = row*C + col), 7 free for callers.  The RNG stream necessarily differs from PyTorch's.
+ * obte_dropout_bf16: out = dropout(in) elementwise with idx = linear index (in may alias out). */
+int obte_dropout_bf16(const obte_bf16* in, obte_bf16* out, int64_t n, float p, uint64_t seed, int32_t site, obte_stream s);
 
 /* ---- RoPE on the q and k thirds of a packed qkv activation, in place (training/model.py:39-50,108) ------
  * qkv: [rows = B*T, 3*C]; pairs (2j,2j+1) of each head; position = row % T.  cos/sin: fp32 [T, hs/2].
@@ -113,6 +125,7 @@ typedef struct {
     const obte_bf16* qkv; obte_bf16* o; float* lse;
     const int32_t* key_ranges; const obte_bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
     int64_t B, T; int32_t n_head, head_dim; float scale;
+    float dropout_p; uint64_t dropout_seed;     /* attention-probability dropout (site 1); p = 0 disables */
 } obte_attn_fwd_args;
 int obte_attn_fwd(const obte_attn_fwd_args* a, obte_stream s);
 
@@ -125,6 +138,7 @@ typedef struct {
                                                       map (i.e. gradients w.r.t. the un-rotated c_attn output) */
     const int32_t* key_ranges; const obte_bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
     int64_t B, T; int32_t n_head, head_dim; float scale;
+    float dropout_p; uint64_t dropout_seed;     /* must equal the forward call's */
 } obte_attn_bwd_args;
 int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s);
 
@@ -134,12 +148,19 @@ int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s);
  * [2*ceil(rows/32)*C + ...] see obte_embedding_bwd_ws_bytes. */
 int obte_embedding_fwd(const int64_t* idx, const obte_bf16* wte, obte_bf16* out, int64_t rows, int cols,
                        int64_t vocab, obte_stream s);
+/* with the embedding dropout of model.py:242 fused (site 0) */
+int obte_embedding_fwd_dropout(const int64_t* idx, const obte_bf16* wte, obte_bf16* out, int64_t rows, int cols,
+                               int64_t vocab, float p, uint64_t seed, obte_stream s);
 int64_t obte_embedding_bwd_ws_bytes(int64_t rows, int cols);
 int obte_embedding_bwd(const int64_t* idx, const int32_t* order, const obte_bf16* dout, obte_bf16* dwte,
                        void* ws, int64_t rows, int cols, int64_t vocab, obte_stream s);
 /* accumulate != 0: dwte holds an existing gradient; only the touched rows are read-modified-written (no memset). */
 int obte_embedding_bwd_acc(const int64_t* idx, const int32_t* order, const obte_bf16* dout, obte_bf16* dwte,
                            void* ws, int64_t rows, int cols, int64_t vocab, int accumulate, obte_stream s);
+/* dout is the gradient of the DROPPED embedding output: the same mask (p, seed, site 0) is re-applied while summing */
+int obte_embedding_bwd_dropout(const int64_t* idx, const int32_t* order, const obte_bf16* dout, obte_bf16* dwte,
+                               void* ws, int64_t rows, int cols, int64_t vocab, int accumulate, float p, uint64_t seed,
+                               obte_stream s);
 
 /* ---- masked-LM cross entropy, forward + backward in one pass (training/train_encoder.py:301-305) -------------
  * loss_sum[0] += sum over rows with mlm_mask!=0 of (logsumexp(logits[r]) - logits[r,target[r]]) * row_scale
@@ -178,6 +199,7 @@ typedef struct {
     const obte_bf16 *ln1_w, *attn_w, *proj_w, *ln2_w, *fc_w, *mlp_w;   /* parameters */
     const float *rope_cos, *rope_sin;                                   /* [T, hs/2] */
     const int32_t* key_ranges; const obte_bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
+    float dropout_p; uint64_t dropout_seed;   /* one seed per block call; sites 1-3 derive from it.  p = 0: no dropout */
 } obte_block_desc;
 int64_t obte_block_act_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head);
 int64_t obte_block_bwd_ws_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head);

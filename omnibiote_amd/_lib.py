@@ -20,14 +20,16 @@ class GemmArgs(C.Structure):
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("d", C.c_void_p), ("aux", C.c_void_p), ("d2", C.c_void_p),
                 ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
                 ("lda", C.c_int64), ("ldb", C.c_int64), ("ldd", C.c_int64),
-                ("a_kmajor", C.c_int32), ("b_kmajor", C.c_int32), ("epilogue", C.c_int32), ("alpha", C.c_float)]
+                ("a_kmajor", C.c_int32), ("b_kmajor", C.c_int32), ("epilogue", C.c_int32), ("alpha", C.c_float),
+                ("dropout_p", C.c_float), ("dropout_site", C.c_int32), ("dropout_seed", C.c_uint64)]
 
 
 class AttnFwdArgs(C.Structure):
     _fields_ = [("qkv", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
                 ("key_ranges", C.c_void_p), ("mask", C.c_void_p),
                 ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
-                ("B", C.c_int64), ("T", C.c_int64), ("n_head", C.c_int32), ("head_dim", C.c_int32), ("scale", C.c_float)]
+                ("B", C.c_int64), ("T", C.c_int64), ("n_head", C.c_int32), ("head_dim", C.c_int32), ("scale", C.c_float),
+                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -35,7 +37,8 @@ class AttnBwdArgs(C.Structure):
                 ("delta", C.c_void_p), ("dqkv", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
                 ("key_ranges", C.c_void_p), ("mask", C.c_void_p),
                 ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
-                ("B", C.c_int64), ("T", C.c_int64), ("n_head", C.c_int32), ("head_dim", C.c_int32), ("scale", C.c_float)]
+                ("B", C.c_int64), ("T", C.c_int64), ("n_head", C.c_int32), ("head_dim", C.c_int32), ("scale", C.c_float),
+                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)]
 
 
 class BlockDesc(C.Structure):
@@ -56,7 +59,8 @@ class MtArgs(C.Structure):
                 ("step", C.c_int32 * MT_MAX), ("count", C.c_int32)]
 
 
-EPI_NONE, EPI_GELU, EPI_ADD, EPI_GELU_BWD = 0, 1, 2, 3
+EPI_NONE, EPI_GELU, EPI_ADD, EPI_GELU_BWD, EPI_ADD_DROPOUT = 0, 1, 2, 3, 4
+SITE_EMBED, SITE_ATTN, SITE_RESID, SITE_MLP, SITE_USER = 0, 1, 2, 3, 7
 
 # name -> (restype, argtypes); every symbol include/omnibiote_hip.h declares
 SYMBOLS = {
@@ -77,6 +81,9 @@ SYMBOLS = {
     "obte_attn_fwd": (C.c_int, [C.POINTER(AttnFwdArgs), c_stream]),
     "obte_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), c_stream]),
     "obte_embedding_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int64, c_stream]),
+    "obte_embedding_fwd_dropout": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_uint64, c_stream]),
+    "obte_embedding_bwd_dropout": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_uint64, c_stream]),
+    "obte_dropout_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_int32, c_stream]),
     "obte_embedding_bwd_ws_bytes": (C.c_int64, [C.c_int64, C.c_int]),
     "obte_embedding_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int64, c_stream]),
     "obte_embedding_bwd_acc": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int64, C.c_int, c_stream]),

@@ -32,6 +32,7 @@ struct AttnParams {
     const float* rope_cos; const float* rope_sin;               // backward: inverse RoPE on dq, dk (nullable)
     const int32_t* key_ranges; const bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
     int64_t B, T; int H; float scale;
+    DropCfg drop;   // attention-probability dropout (site 1); thresh24 == 0: off
 };
 
 template <int D>
@@ -150,8 +151,9 @@ __device__ __forceinline__ void block_minmax(int& lo, int& hi, int* scratch, int
 // ==========================================================================================================
 // forward
 // ==========================================================================================================
-template <int D, int MODE>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+// (the dropout variants trade occupancy for registers: one wave per SIMD, no spills)
+template <int D, int MODE, bool DROP>
+__global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_fwd_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TB = 64 * 2 * D;  // bytes of one 64-row tile
     constexpr int NS = D / 16;      // k-steps over the head dim
@@ -261,9 +263,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = fast_exp2(sc[mt][r] - m_safe);
+                float pv = fast_exp2(sc[mt][r] - m_safe);
+                rs += pv;   // the normaliser uses the un-dropped probabilities
+                if (DROP) {
+                    const uint64_t di = (((uint64_t)b * p.H + hd) * T + q_c) * (uint64_t)T + (uint64_t)(key0 + 32 * mt + acc_row(r, h));
+                    pv = drop_keep(di, p.drop) ? pv * p.drop.scale : 0.f;
+                }
                 sc[mt][r] = pv;
-                rs += pv;
             }
         l = l * alpha + rs;
         m = m_new;
@@ -346,7 +352,7 @@ __device__ __forceinline__ void rope_inv4(float (&g)[4], const float* cos_t, con
 // backward, part 1: dQ.  Same shape as forward: 128 queries per workgroup, query on the lane.
 //   S^T = K Q^T ; P^T = exp(S^T*scale + mask - lse) ; dP^T = V dO^T ; dS^T = P^T (dP^T - delta) ; dQ^T += K^T dS^T
 // ==========================================================================================================
-template <int D, int MODE>
+template <int D, int MODE, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TB = 64 * 2 * D;
@@ -433,7 +439,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
                 if (MODE == MASK_DENSE) { if (key < T) x += bf2f(mrow[key]) * LOG2E; }
                 float pv = fast_exp2(x);
                 if (key < ks || key >= ke) pv = 0.f;
-                sc[r] = pv * (dp[r] - dl);   // dS^T (without the scale factor)
+                float dpd = dp[r];
+                if (DROP) {
+                    const uint64_t di = (((uint64_t)b * p.H + hd) * T + q_c) * (uint64_t)T + (uint64_t)key;
+                    dpd = drop_keep(di, p.drop) ? dpd * p.drop.scale : 0.f;
+                }
+                sc[r] = pv * (dpd - dl);   // dS^T (without the scale factor)
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -472,8 +483,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 //   S = Q K^T ; P = exp(S*scale + mask - lse) ; dP = dO V^T ; dS = P (dP - delta)
 //   dV^T += dO^T P ; dK^T += Q^T dS
 // ==========================================================================================================
-template <int D, int MODE>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
+template <int D, int MODE, bool DROP>
+__global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_bwd_dkdv_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QB = 32 * 2 * D;  // bytes of one 32-row tile
     constexpr int NS = D / 16, ND = D / 32;
@@ -590,8 +601,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
                 if (MODE == MASK_DENSE) { if (q < T) x += bf2f(mcol[(int64_t)q * p.mask_sq]) * LOG2E; }
                 float pv = fast_exp2(x);
                 if (q < qs || q >= qe) pv = 0.f;
-                sc[r] = pv;
-                dp[r] = pv * (dp[r] - d4[j]);
+                float pd = pv, dpd = dp[r];
+                if (DROP) {
+                    const uint64_t di = (((uint64_t)b * p.H + hd) * T + (uint64_t)(q < T ? q : T - 1)) * (uint64_t)T + (uint64_t)key_c;
+                    const bool kp = drop_keep(di, p.drop);
+                    pd = kp ? pv * p.drop.scale : 0.f;
+                    dpd = kp ? dpd * p.drop.scale : 0.f;
+                }
+                sc[r] = pd;                    // dropped probabilities feed dV
+                dp[r] = pv * (dpd - d4[j]);    // dS
             }
         }
 #pragma unroll
@@ -633,10 +651,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
 }
 
 // Explicit instantiations (implicit instantiation alone left some host stubs undefined with hipcc / ROCm 7.2).
-#define OBTE_INST_ATTN(D, M)                                                \
-    template __global__ void attn_fwd_kernel<D, M>(AttnParams);             \
-    template __global__ void attn_bwd_dq_kernel<D, M>(AttnParams);          \
-    template __global__ void attn_bwd_dkdv_kernel<D, M>(AttnParams);
+#define OBTE_INST_ATTN(D, M)                                                       \
+    template __global__ void attn_fwd_kernel<D, M, false>(AttnParams);             \
+    template __global__ void attn_bwd_dq_kernel<D, M, false>(AttnParams);          \
+    template __global__ void attn_bwd_dkdv_kernel<D, M, false>(AttnParams);        \
+    template __global__ void attn_fwd_kernel<D, M, true>(AttnParams);              \
+    template __global__ void attn_bwd_dq_kernel<D, M, true>(AttnParams);           \
+    template __global__ void attn_bwd_dkdv_kernel<D, M, true>(AttnParams);
 OBTE_INST_ATTN(64, 0) OBTE_INST_ATTN(64, 1) OBTE_INST_ATTN(64, 2)
 OBTE_INST_ATTN(128, 0) OBTE_INST_ATTN(128, 1) OBTE_INST_ATTN(128, 2)
 #undef OBTE_INST_ATTN
@@ -652,10 +673,15 @@ template <int D>
 int launch_fwd(const AttnParams& p, int mode, hipStream_t st) {
     const int smem = 4 * 64 * 2 * D + 64;
     const dim3 grid((unsigned)cdiv64(p.T, 128), p.H, (unsigned)p.B), block(256);
-#define GO(M)                                                                        \
-    do {                                                                             \
-        set_smem(attn_fwd_kernel<D, M>, smem);                                       \
-        hipLaunchKernelGGL((attn_fwd_kernel<D, M>), grid, block, smem, st, p);       \
+#define GO(M)                                                                                 \
+    do {                                                                                      \
+        if (p.drop.thresh24) {                                                                \
+            set_smem(attn_fwd_kernel<D, M, true>, smem);                                      \
+            hipLaunchKernelGGL((attn_fwd_kernel<D, M, true>), grid, block, smem, st, p);      \
+        } else {                                                                              \
+            set_smem(attn_fwd_kernel<D, M, false>, smem);                                     \
+            hipLaunchKernelGGL((attn_fwd_kernel<D, M, false>), grid, block, smem, st, p);     \
+        }                                                                                     \
     } while (0)
     if (mode == MASK_NONE) GO(MASK_NONE); else if (mode == MASK_RANGES) GO(MASK_RANGES); else GO(MASK_DENSE);
 #undef GO
@@ -673,10 +699,15 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
     {
         const int smem = 4 * 64 * 2 * D + 64;
         const dim3 grid((unsigned)cdiv64(p.T, 128), p.H, (unsigned)p.B), block(256);
-#define GO(M)                                                                         \
-    do {                                                                              \
-        set_smem(attn_bwd_dq_kernel<D, M>, smem);                                     \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<D, M>), grid, block, smem, st, p);     \
+#define GO(M)                                                                                    \
+    do {                                                                                         \
+        if (p.drop.thresh24) {                                                                   \
+            set_smem(attn_bwd_dq_kernel<D, M, true>, smem);                                      \
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<D, M, true>), grid, block, smem, st, p);      \
+        } else {                                                                                 \
+            set_smem(attn_bwd_dq_kernel<D, M, false>, smem);                                     \
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<D, M, false>), grid, block, smem, st, p);     \
+        }                                                                                        \
     } while (0)
         if (mode == MASK_NONE) GO(MASK_NONE); else if (mode == MASK_RANGES) GO(MASK_RANGES); else GO(MASK_DENSE);
 #undef GO
@@ -685,10 +716,15 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
     {
         const int smem = 2 * (2 * 32 * 2 * D + 256) + 128 * 2 * D + 64;
         const dim3 grid((unsigned)cdiv64(p.T, 128), p.H, (unsigned)p.B), block(256);
-#define GO(M)                                                                          \
-    do {                                                                               \
-        set_smem(attn_bwd_dkdv_kernel<D, M>, smem);                                    \
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, M>), grid, block, smem, st, p);    \
+#define GO(M)                                                                                      \
+    do {                                                                                           \
+        if (p.drop.thresh24) {                                                                     \
+            set_smem(attn_bwd_dkdv_kernel<D, M, true>, smem);                                      \
+            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, M, true>), grid, block, smem, st, p);      \
+        } else {                                                                                   \
+            set_smem(attn_bwd_dkdv_kernel<D, M, false>, smem);                                     \
+            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, M, false>), grid, block, smem, st, p);     \
+        }                                                                                          \
     } while (0)
         if (mode == MASK_NONE) GO(MASK_NONE); else if (mode == MASK_RANGES) GO(MASK_RANGES); else GO(MASK_DENSE);
 #undef GO
@@ -718,6 +754,8 @@ extern "C" int obte_attn_fwd(const obte_attn_fwd_args* a, obte_stream s) {
     p.qkv = (const bf16*)a->qkv; p.o = (bf16*)a->o; p.lse = a->lse;
     p.key_ranges = a->key_ranges; p.mask = (const bf16*)a->mask; p.mask_sb = a->mask_sb; p.mask_sh = a->mask_sh; p.mask_sq = a->mask_sq;
     p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
+    OBTE_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "obte_attn_fwd: dropout p must be in [0,1)");
+    p.drop = make_drop(a->dropout_p, a->dropout_seed, OBTE_SITE_ATTN);
     const int mode = mask_mode(a->key_ranges, a->mask);
     const int prof = obte_prof_begin((hipStream_t)s, 100, a->B * a->n_head, a->T, a->head_dim);
     rc = a->head_dim == 128 ? launch_fwd<128>(p, mode, (hipStream_t)s) : launch_fwd<64>(p, mode, (hipStream_t)s);
@@ -736,6 +774,8 @@ extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
     p.dqkv = (bf16*)a->dqkv; p.rope_cos = a->rope_cos; p.rope_sin = a->rope_sin;
     p.key_ranges = a->key_ranges; p.mask = (const bf16*)a->mask; p.mask_sb = a->mask_sb; p.mask_sh = a->mask_sh; p.mask_sq = a->mask_sq;
     p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
+    OBTE_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "obte_attn_bwd: dropout p must be in [0,1)");
+    p.drop = make_drop(a->dropout_p, a->dropout_seed, OBTE_SITE_ATTN);
     const int mode = mask_mode(a->key_ranges, a->mask);
     const int prof = obte_prof_begin((hipStream_t)s, 101, a->B * a->n_head, a->T, a->head_dim);
     rc = a->head_dim == 128 ? launch_bwd<128>(p, mode, (hipStream_t)s) : launch_bwd<64>(p, mode, (hipStream_t)s);

@@ -31,7 +31,7 @@ struct ActLayout {
 };
 
 struct WsLayout {
-    int64_t dhpre, dh, dx1, dyattn, dqkv, delta, lnws, gemmws, gemmws_bytes, total;
+    int64_t dhpre, dh, dx1, dyattn, dqkv, delta, lnws, dym, gemmws, gemmws_bytes, total;
     WsLayout(int64_t B, int64_t T, int C, int H) {
         const int64_t M = B * T;
         int64_t o = 0;
@@ -43,6 +43,7 @@ struct WsLayout {
         dqkv = take(M * 3 * C * 2);
         delta = take(B * H * T * 4);
         lnws = take((int64_t)obte_layernorm_bwd_ws_rows() * C * 4);
+        dym = take(M * C * 2);      // dropout-masked copy of an incoming gradient (only touched when dropout_p > 0)
         gemmws_bytes = 0;
         const int64_t shapes[4][2] = {{C, 4 * C}, {4 * C, C}, {C, C}, {3 * C, C}};   // the four weight gradients
         for (auto& sh : shapes) {
@@ -55,13 +56,20 @@ struct WsLayout {
 };
 
 int gemm(const obte_bf16* a, const obte_bf16* b, obte_bf16* d, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-         int ak, int bk, int epi, const obte_bf16* aux, obte_bf16* d2, obte_stream s, void* ws = nullptr, int64_t ws_bytes = 0) {
+         int ak, int bk, int epi, const obte_bf16* aux, obte_bf16* d2, obte_stream s, void* ws = nullptr, int64_t ws_bytes = 0,
+         float drop_p = 0.f, uint64_t drop_seed = 0, int drop_site = 0) {
     obte_gemm_args g = {};
     g.a = a; g.b = b; g.d = d; g.aux = aux; g.d2 = d2;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldd = N;
     g.a_kmajor = ak; g.b_kmajor = bk; g.epilogue = epi; g.alpha = 1.0f;
+    if (epi == OBTE_EPI_ADD && drop_p > 0.f) {   // residual add with dropout on the projection output
+        g.epilogue = OBTE_EPI_ADD_DROPOUT; g.dropout_p = drop_p; g.dropout_seed = drop_seed; g.dropout_site = drop_site;
+    }
     return obte_gemm_bf16_ws(&g, ws, ws_bytes, s);
 }
+
+// dropout sites of one block (csrc/common.h OBTE_SITE_*): 1 attention probabilities, 2 attention c_proj, 3 MLP c_proj
+enum { SITE_RESID = 2, SITE_MLP = 3 };
 
 int check_desc(const char* who, const obte_block_desc* d) {
     OBTE_REQUIRE(d, "%s: null descriptor", who);
@@ -72,6 +80,7 @@ int check_desc(const char* who, const obte_block_desc* d) {
     OBTE_REQUIRE(d->n_embd % 64 == 0 && d->n_embd <= 4096, "%s: n_embd must be a multiple of 64 and <= 4096", who);
     OBTE_REQUIRE(d->ln1_w && d->attn_w && d->proj_w && d->ln2_w && d->fc_w && d->mlp_w && d->rope_cos && d->rope_sin,
                  "%s: null parameter", who);
+    OBTE_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "%s: dropout p must be in [0,1)", who);
     return OBTE_OK;
 }
 
@@ -105,11 +114,12 @@ extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte
     af.qkv = qkv; af.o = yat; af.lse = lse; af.key_ranges = d->key_ranges; af.mask = d->mask;
     af.mask_sb = d->mask_sb; af.mask_sh = d->mask_sh; af.mask_sq = d->mask_sq;
     af.B = d->B; af.T = d->T; af.n_head = H; af.head_dim = hs; af.scale = 8.0f / (float)C;  // model.py:119
+    af.dropout_p = d->dropout_p; af.dropout_seed = d->dropout_seed;
     TRY(obte_attn_fwd(&af, s));
-    TRY(gemm(yat, d->proj_w, x1, M, C, C, C, C, 1, 1, OBTE_EPI_ADD, x, nullptr, s));
+    TRY(gemm(yat, d->proj_w, x1, M, C, C, C, C, 1, 1, OBTE_EPI_ADD, x, nullptr, s, nullptr, 0, d->dropout_p, d->dropout_seed, SITE_RESID));
     TRY(obte_layernorm_fwd(x1, d->ln2_w, h2, mean2, rstd2, M, C, 1e-5f, s));
     TRY(gemm(h2, d->fc_w, hpre, M, 4 * C, C, C, C, 1, 1, OBTE_EPI_GELU, nullptr, hact, s));
-    TRY(gemm(hact, d->mlp_w, y_out, M, C, 4 * C, 4 * C, 4 * C, 1, 1, OBTE_EPI_ADD, x1, nullptr, s));
+    TRY(gemm(hact, d->mlp_w, y_out, M, C, 4 * C, 4 * C, 4 * C, 1, 1, OBTE_EPI_ADD, x1, nullptr, s, nullptr, 0, d->dropout_p, d->dropout_seed, SITE_MLP));
     return OBTE_OK;
 }
 
@@ -145,20 +155,33 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     float *delta = (float*)(S + W.delta), *lnws = (float*)(S + W.lnws);
     void* gws = W.gemmws_bytes > 0 ? (void*)(S + W.gemmws) : nullptr;
 
-    // MLP: out = x1 + hact W_mlp^T
-    TRY(gemm(dy, d->mlp_w, dhpre, M, 4 * C, C, C, 4 * C, 1, 0, OBTE_EPI_GELU_BWD, hpre, nullptr, s));          // dhpre = (dy W_mlp) * gelu'(hpre)
-    TRY(gemm(dy, hact, dmlp_w, C, 4 * C, M, C, 4 * C, 0, 0, wepi, accumulate_matrices ? dmlp_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_mlp = dy^T hact
+    obte_bf16* dym = (obte_bf16*)(S + W.dym);
+    const bool drop = d->dropout_p > 0.f;
+    // MLP: out = x1 + dropout(hact W_mlp^T): the projection sees dy masked by the same (seed, site 3) mask
+    const obte_bf16* dy_mlp = dy;
+    if (drop) {
+        TRY(obte_dropout_bf16(dy, dym, M * C, d->dropout_p, d->dropout_seed, SITE_MLP, s));
+        dy_mlp = dym;
+    }
+    TRY(gemm(dy_mlp, d->mlp_w, dhpre, M, 4 * C, C, C, 4 * C, 1, 0, OBTE_EPI_GELU_BWD, hpre, nullptr, s));      // dhpre = (dy W_mlp) * gelu'(hpre)
+    TRY(gemm(dy_mlp, hact, dmlp_w, C, 4 * C, M, C, 4 * C, 0, 0, wepi, accumulate_matrices ? dmlp_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_mlp = dy^T hact
     TRY(gemm(dhpre, d->fc_w, dh, M, C, 4 * C, 4 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh2 = dhpre W_fc
     TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, M, 4 * C, C, 0, 0, wepi, accumulate_matrices ? dfc_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_fc = dhpre^T h2
     TRY(obte_layernorm_bwd(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, lnws, M, C, s));                     // dx1 = dy + LN2'(dh2)
-    // attention: x1 = x + y W_proj^T
-    TRY(gemm(dx1, d->proj_w, dyattn, M, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));                  // dy_attn = dx1 W_proj
-    TRY(gemm(dx1, yat, dproj_w, C, C, M, C, C, 0, 0, wepi, accumulate_matrices ? dproj_w : nullptr, nullptr, s, gws, W.gemmws_bytes));                       // dW_proj = dx1^T y
+    // attention: x1 = x + dropout(y W_proj^T)
+    const obte_bf16* dx1_proj = dx1;
+    if (drop) {
+        TRY(obte_dropout_bf16(dx1, dym, M * C, d->dropout_p, d->dropout_seed, SITE_RESID, s));
+        dx1_proj = dym;
+    }
+    TRY(gemm(dx1_proj, d->proj_w, dyattn, M, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dy_attn = dx1 W_proj
+    TRY(gemm(dx1_proj, yat, dproj_w, C, C, M, C, C, 0, 0, wepi, accumulate_matrices ? dproj_w : nullptr, nullptr, s, gws, W.gemmws_bytes));                       // dW_proj = dx1^T y
     obte_attn_bwd_args ab = {};
     ab.qkv = qkv; ab.o = yat; ab.d_o = dyattn; ab.lse = lse; ab.delta = delta; ab.dqkv = dqkv;
     ab.rope_cos = d->rope_cos; ab.rope_sin = d->rope_sin;
     ab.key_ranges = d->key_ranges; ab.mask = d->mask; ab.mask_sb = d->mask_sb; ab.mask_sh = d->mask_sh; ab.mask_sq = d->mask_sq;
     ab.B = d->B; ab.T = d->T; ab.n_head = H; ab.head_dim = hs; ab.scale = 8.0f / (float)C;
+    ab.dropout_p = d->dropout_p; ab.dropout_seed = d->dropout_seed;
     TRY(obte_attn_bwd(&ab, s));
     TRY(gemm(dqkv, d->attn_w, dh, M, C, 3 * C, 3 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh1 = dqkv W_attn
     TRY(gemm(dqkv, h1, dattn_w, 3 * C, C, M, 3 * C, C, 0, 0, wepi, accumulate_matrices ? dattn_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_attn = dqkv^T h1

@@ -101,4 +101,31 @@ __device__ __forceinline__ float gelu_ref_grad(float x) {
     return 0.5f * (1.0f + e) + x * (0.5641895835477563f / OBTE_GELU_C) * g;
 }
 
+// ---- dropout: counter-based keep decision -------------------------------------------------------------------
+// keep(idx) is a pure function of (seed, site, element index), so forward and backward regenerate the same mask with
+// no mask tensor in memory, and a host-side restatement (tests) can reproduce it bit for bit.  Two rounds of the
+// "lowbias32" integer finaliser; an element is dropped when the top 24 bits fall below p * 2^24.
+struct DropCfg {
+    uint32_t s0, s1, thresh24;   // thresh24 == 0  <=>  dropout off
+    float scale;                 // 1 / (1 - p)
+};
+__host__ __device__ __forceinline__ uint32_t obte_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ bool drop_keep(uint64_t idx, const DropCfg& c) {
+    uint32_t x = obte_hash32((uint32_t)idx ^ c.s0);
+    x = obte_hash32(x + (uint32_t)(idx >> 32) * 0x9E3779B1U + c.s1);
+    return (x >> 8) >= c.thresh24;
+}
+static inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) {
+    DropCfg c;
+    c.s0 = (uint32_t)seed ^ (site * 0x632BE5ABU);
+    c.s1 = (uint32_t)(seed >> 32) + site * 0x9E3779B9U;
+    c.thresh24 = p > 0.f ? (uint32_t)((double)p * 16777216.0) : 0u;
+    c.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    return c;
+}
+enum { OBTE_SITE_EMBED = 0, OBTE_SITE_ATTN = 1, OBTE_SITE_RESID = 2, OBTE_SITE_MLP = 3, OBTE_SITE_USER = 7 };
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

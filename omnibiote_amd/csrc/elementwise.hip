@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ qkv, const
 // Embedding gather (training/model.py:241).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ idx, const bf16* __restrict__ wte,
-                                                         bf16* __restrict__ out, int64_t rows, int cols, int64_t vocab) {
+                                                         bf16* __restrict__ out, int64_t rows, int cols, int64_t vocab, DropCfg dc) {
     const int cpr = cols / 8;
     const int64_t total = rows * cpr;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -47,7 +47,21 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
         const int c = (int)(i % cpr) * 8;
         int64_t tok = idx[r];
         tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);  // memory safety; the host wrapper validates ids
-        *reinterpret_cast<bf16x8*>(out + r * cols + c) = *reinterpret_cast<const bf16x8*>(wte + tok * cols + c);
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(wte + tok * cols + c);
+        if (dc.thresh24) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = drop_keep((uint64_t)(r * cols + c + j), dc) ? f2bf(bf2f(v[j]) * dc.scale) : f2bf(0.f);
+        }
+        *reinterpret_cast<bf16x8*>(out + r * cols + c) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const bf16* in, bf16* out, int64_t n8, DropCfg dc) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        bf16x8 v = reinterpret_cast<const bf16x8*>(in)[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = drop_keep((uint64_t)(i * 8 + j), dc) ? f2bf(bf2f(v[j]) * dc.scale) : f2bf(0.f);
+        reinterpret_cast<bf16x8*>(out)[i] = v;
     }
 }
 
@@ -78,7 +92,7 @@ __device__ __forceinline__ void embed_store_row(bf16* dst, const float (&acc)[8]
 template <bool ACC>
 __global__ __launch_bounds__(128) void embed_bwd_chunk_kernel(const int64_t* __restrict__ idx, const int32_t* __restrict__ order,
                                                                const bf16* __restrict__ dout, bf16* __restrict__ dwte,
-                                                               float* __restrict__ slab, int64_t rows, int cols) {
+                                                               float* __restrict__ slab, int64_t rows, int cols, DropCfg dc) {
     __shared__ int32_t s_row[EMB_CHUNK];
     __shared__ int64_t s_tok[EMB_CHUNK + 2];  // [0] = token before the chunk (or -1), [1..n] chunk, [n+1] = token after (or -1)
     const int64_t c = blockIdx.x;
@@ -101,8 +115,14 @@ __global__ __launch_bounds__(128) void embed_bwd_chunk_kernel(const int64_t* __r
         int seg_start = 0;
         for (int i = 0; i < n; ++i) {
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(dout + (int64_t)s_row[i] * cols + col);
+            if (dc.thresh24) {   // gradient of the dropped output: bf16(dout * scale) where kept, as autograd would form it
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+                for (int j = 0; j < 8; ++j)
+                    if (drop_keep((uint64_t)((int64_t)s_row[i] * cols + col + j), dc)) acc[j] += bf2f(f2bf(bf2f(v[j]) * dc.scale));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
+            }
             const bool seg_end = (i == n - 1) || (s_tok[i + 2] != s_tok[i + 1]);
             if (seg_end) {
                 const bool is_first = seg_start == 0, is_last = i == n - 1;
@@ -347,14 +367,34 @@ extern "C" int obte_rope_qk_inplace(obte_bf16* qkv, const float* cos_t, const fl
     return OBTE_OK;
 }
 
-extern "C" int obte_embedding_fwd(const int64_t* idx, const obte_bf16* wte, obte_bf16* out, int64_t rows, int cols,
-                                  int64_t vocab, obte_stream s) {
+static int check_p(const char* who, float p) {
+    OBTE_REQUIRE(p >= 0.f && p < 1.f, "%s: dropout p must be in [0, 1) (got %g)", who, (double)p);
+    return OBTE_OK;
+}
+
+extern "C" int obte_embedding_fwd_dropout(const int64_t* idx, const obte_bf16* wte, obte_bf16* out, int64_t rows, int cols,
+                                          int64_t vocab, float p, uint64_t seed, obte_stream s) {
     OBTE_REQUIRE(idx && wte && out, "obte_embedding_fwd: null pointer");
     OBTE_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && vocab > 0, "obte_embedding_fwd: cols must be a multiple of 8");
+    if (check_p("obte_embedding_fwd", p)) return OBTE_EINVAL;
     if (rows == 0) return OBTE_OK;
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(stream_grid(rows * (cols / 8), 256)), dim3(256), 0, (hipStream_t)s, idx,
-                       (const bf16*)wte, (bf16*)out, rows, cols, vocab);
+                       (const bf16*)wte, (bf16*)out, rows, cols, vocab, make_drop(p, seed, OBTE_SITE_EMBED));
     OBTE_CHECK_LAUNCH("obte_embedding_fwd");
+    return OBTE_OK;
+}
+
+extern "C" int obte_embedding_fwd(const int64_t* idx, const obte_bf16* wte, obte_bf16* out, int64_t rows, int cols,
+                                  int64_t vocab, obte_stream s) {
+    return obte_embedding_fwd_dropout(idx, wte, out, rows, cols, vocab, 0.f, 0, s);
+}
+
+extern "C" int obte_dropout_bf16(const obte_bf16* in, obte_bf16* out, int64_t n, float p, uint64_t seed, int32_t site, obte_stream s) {
+    OBTE_REQUIRE(in && out && n > 0 && n % 8 == 0, "obte_dropout_bf16: null pointer or n not a positive multiple of 8");
+    if (check_p("obte_dropout_bf16", p)) return OBTE_EINVAL;
+    hipLaunchKernelGGL(dropout_kernel, dim3(stream_grid(n / 8, 256)), dim3(256), 0, (hipStream_t)s, (const bf16*)in, (bf16*)out, n / 8,
+                       make_drop(p, seed, (uint32_t)site));
+    OBTE_CHECK_LAUNCH("obte_dropout_bf16");
     return OBTE_OK;
 }
 
@@ -362,9 +402,12 @@ extern "C" int64_t obte_embedding_bwd_ws_bytes(int64_t rows, int cols) {
     return cdiv64(rows, EMB_CHUNK) * 2 * (int64_t)cols * (int64_t)sizeof(float);
 }
 
-extern "C" int obte_embedding_bwd_acc(const int64_t* idx, const int32_t* order, const obte_bf16* dout, obte_bf16* dwte,
-                                      void* ws, int64_t rows, int cols, int64_t vocab, int accumulate, obte_stream s) {
+extern "C" int obte_embedding_bwd_dropout(const int64_t* idx, const int32_t* order, const obte_bf16* dout, obte_bf16* dwte,
+                                          void* ws, int64_t rows, int cols, int64_t vocab, int accumulate, float p, uint64_t seed,
+                                          obte_stream s) {
     OBTE_REQUIRE(idx && order && dout && dwte && ws, "obte_embedding_bwd: null pointer");
+    if (check_p("obte_embedding_bwd", p)) return OBTE_EINVAL;
+    const DropCfg dc = make_drop(p, seed, OBTE_SITE_EMBED);
     OBTE_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && vocab > 0, "obte_embedding_bwd: bad shape");
     OBTE_REQUIRE(rows < (1ll << 31), "obte_embedding_bwd: too many rows");
     hipStream_t st = (hipStream_t)s;
@@ -375,10 +418,10 @@ extern "C" int obte_embedding_bwd_acc(const int64_t* idx, const int32_t* order, 
     const int64_t nchunks = cdiv64(rows, EMB_CHUNK);
     if (accumulate)
         hipLaunchKernelGGL(embed_bwd_chunk_kernel<true>, dim3((unsigned)nchunks), dim3(128), 0, st, idx, order, (const bf16*)dout,
-                           (bf16*)dwte, (float*)ws, rows, cols);
+                           (bf16*)dwte, (float*)ws, rows, cols, dc);
     else
         hipLaunchKernelGGL(embed_bwd_chunk_kernel<false>, dim3((unsigned)nchunks), dim3(128), 0, st, idx, order, (const bf16*)dout,
-                           (bf16*)dwte, (float*)ws, rows, cols);
+                           (bf16*)dwte, (float*)ws, rows, cols, dc);
     OBTE_CHECK_LAUNCH("obte_embedding_bwd(chunk)");
     if (accumulate)
         hipLaunchKernelGGL(embed_bwd_span_kernel<true>, dim3((unsigned)nchunks), dim3(128), 0, st, idx, order, (bf16*)dwte,
@@ -390,9 +433,14 @@ extern "C" int obte_embedding_bwd_acc(const int64_t* idx, const int32_t* order, 
     return OBTE_OK;
 }
 
+extern "C" int obte_embedding_bwd_acc(const int64_t* idx, const int32_t* order, const obte_bf16* dout, obte_bf16* dwte,
+                                      void* ws, int64_t rows, int cols, int64_t vocab, int accumulate, obte_stream s) {
+    return obte_embedding_bwd_dropout(idx, order, dout, dwte, ws, rows, cols, vocab, accumulate, 0.f, 0, s);
+}
+
 extern "C" int obte_embedding_bwd(const int64_t* idx, const int32_t* order, const obte_bf16* dout, obte_bf16* dwte,
                                   void* ws, int64_t rows, int cols, int64_t vocab, obte_stream s) {
-    return obte_embedding_bwd_acc(idx, order, dout, dwte, ws, rows, cols, vocab, 0, s);
+    return obte_embedding_bwd_dropout(idx, order, dout, dwte, ws, rows, cols, vocab, 0, 0.f, 0, s);
 }
 
 extern "C" int obte_masked_ce_fwd_bwd(const obte_bf16* logits, const int64_t* target, const uint8_t* mlm_mask,

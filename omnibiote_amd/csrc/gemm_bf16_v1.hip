@@ -34,6 +34,7 @@ struct GemmParams {
     int64_t a_elems, b_elems;
     int tiles_m, tiles_n;
     float alpha;
+    DropCfg drop;
 };
 
 __device__ __forceinline__ int kmaj_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -202,6 +203,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
                 const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.aux + o);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(r[j]) + bf2f(v[j]));
+            } else if (EPI == OBTE_EPI_ADD_DROPOUT) {
+                const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.aux + o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = drop_keep((uint64_t)(o + j), p.drop) ? bf2f(f2bf(bf2f(v[j]) * p.drop.scale)) : 0.f;
+                    v[j] = f2bf(bf2f(r[j]) + t);
+                }
             } else if (EPI == OBTE_EPI_GELU_BWD) {
                 const bf16x8 h = *reinterpret_cast<const bf16x8*>(p.aux + o);
 #pragma unroll
@@ -231,6 +239,7 @@ int dispatch_epi(const GemmParams& p, int epi, hipStream_t st) {
         case OBTE_EPI_GELU: return launch<AK, BK, OBTE_EPI_GELU>(p, st);
         case OBTE_EPI_ADD: return launch<AK, BK, OBTE_EPI_ADD>(p, st);
         case OBTE_EPI_GELU_BWD: return launch<AK, BK, OBTE_EPI_GELU_BWD>(p, st);
+        case OBTE_EPI_ADD_DROPOUT: return launch<AK, BK, OBTE_EPI_ADD_DROPOUT>(p, st);
     }
     obte_set_error("obte_gemm_bf16: unknown epilogue %d", epi);
     return OBTE_EINVAL;
@@ -251,7 +260,8 @@ int obte_gemm_bf16_v1(const obte_gemm_args* g, obte_stream s) {
     OBTE_REQUIRE(g->b_kmajor ? g->ldb >= g->K : g->ldb >= g->N, "obte_gemm_bf16: ldb too small");
     OBTE_REQUIRE(g->ldd >= g->N, "obte_gemm_bf16: ldd too small");
     OBTE_REQUIRE(g->lda <= 1 << 20 && g->ldb <= 1 << 20, "obte_gemm_bf16: leading dimension too large");
-    if (g->epilogue == OBTE_EPI_ADD || g->epilogue == OBTE_EPI_GELU_BWD) OBTE_REQUIRE(g->aux, "obte_gemm_bf16: epilogue needs aux");
+    if (g->epilogue == OBTE_EPI_ADD || g->epilogue == OBTE_EPI_GELU_BWD || g->epilogue == OBTE_EPI_ADD_DROPOUT) OBTE_REQUIRE(g->aux, "obte_gemm_bf16: epilogue needs aux");
+    if (g->epilogue == OBTE_EPI_ADD_DROPOUT) OBTE_REQUIRE(g->dropout_p >= 0.f && g->dropout_p < 1.f, "obte_gemm_bf16: dropout p must be in [0,1)");
     if (g->epilogue == OBTE_EPI_GELU) OBTE_REQUIRE(g->d2, "obte_gemm_bf16: GELU epilogue needs d2");
     if (g->epilogue != OBTE_EPI_NONE && g->epilogue != OBTE_EPI_ADD) OBTE_REQUIRE(g->alpha == 1.0f, "obte_gemm_bf16: alpha != 1 only with EPI_NONE / EPI_ADD");
     GemmParams p;
@@ -263,6 +273,7 @@ int obte_gemm_bf16_v1(const obte_gemm_args* g, obte_stream s) {
     OBTE_REQUIRE(tm * tn < (1ll << 30), "obte_gemm_bf16: too many tiles");
     p.tiles_m = (int)tm; p.tiles_n = (int)tn;
     p.alpha = g->alpha;
+    p.drop = make_drop(g->epilogue == OBTE_EPI_ADD_DROPOUT ? g->dropout_p : 0.f, g->dropout_seed, (uint32_t)g->dropout_site);
     hipStream_t st = (hipStream_t)s;
     if (g->a_kmajor && g->b_kmajor) return dispatch_epi<true, true>(p, g->epilogue, st);
     if (g->a_kmajor && !g->b_kmajor) return dispatch_epi<true, false>(p, g->epilogue, st);

@@ -53,6 +53,7 @@ struct GemmParams {
     int64_t a_elems, b_elems;
     int tiles_m, tiles_n, splits, k_per_split;   // k_per_split in K-tiles
     float alpha;
+    DropCfg drop;
 };
 
 __device__ __forceinline__ int kmaj_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -272,6 +273,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
                 const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.aux + o);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(r[j]) + bf2f(v[j]));
+            } else if (EPI == OBTE_EPI_ADD_DROPOUT) {
+                const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.aux + o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = drop_keep((uint64_t)(o + j), p.drop) ? bf2f(f2bf(bf2f(v[j]) * p.drop.scale)) : 0.f;
+                    v[j] = f2bf(bf2f(r[j]) + t);
+                }
             } else if (EPI == OBTE_EPI_GELU_BWD) {
                 const bf16x8 h = *reinterpret_cast<const bf16x8*>(p.aux + o);
 #pragma unroll
@@ -289,7 +297,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
     template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_NONE, false, BN>(GemmParams);       \
     template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_GELU, false, BN>(GemmParams);       \
     template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_ADD, false, BN>(GemmParams);        \
-    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_GELU_BWD, false, BN>(GemmParams);
+    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_GELU_BWD, false, BN>(GemmParams);      \
+    template __global__ void gemm_v2_kernel<AK, BK, OBTE_EPI_ADD_DROPOUT, false, BN>(GemmParams);
 OBTE_INST(true, true, 128)
 OBTE_INST(true, false, 128)
 OBTE_INST(false, true, 128)
@@ -341,6 +350,7 @@ int dispatch_bn(const GemmParams& p, int epi, hipStream_t st) {
         case OBTE_EPI_GELU: return launch<AK, BK, OBTE_EPI_GELU, false, BN>(p, st);
         case OBTE_EPI_ADD: return launch<AK, BK, OBTE_EPI_ADD, false, BN>(p, st);
         case OBTE_EPI_GELU_BWD: return launch<AK, BK, OBTE_EPI_GELU_BWD, false, BN>(p, st);
+        case OBTE_EPI_ADD_DROPOUT: return launch<AK, BK, OBTE_EPI_ADD_DROPOUT, false, BN>(p, st);
     }
     obte_set_error("obte_gemm_bf16: unknown epilogue %d", epi);
     return OBTE_EINVAL;
@@ -401,6 +411,8 @@ static bool lookup_plan(const obte_gemm_args* g, Plan* out) {
     auto it = g_plans.find(PlanKey((g->a_kmajor ? 2 : 0) + (g->b_kmajor ? 1 : 0), g->epilogue, g->M, g->N, g->K));
     if (it == g_plans.end() && g->epilogue == OBTE_EPI_ADD)   // accumulate-into-grad reuses the plan tuned for the plain form
         it = g_plans.find(PlanKey((g->a_kmajor ? 2 : 0) + (g->b_kmajor ? 1 : 0), OBTE_EPI_NONE, g->M, g->N, g->K));
+    if (it == g_plans.end() && g->epilogue == OBTE_EPI_ADD_DROPOUT)   // same main loop as the residual-add form
+        it = g_plans.find(PlanKey((g->a_kmajor ? 2 : 0) + (g->b_kmajor ? 1 : 0), OBTE_EPI_ADD, g->M, g->N, g->K));
     if (it == g_plans.end()) return false;
     *out = it->second;
     return true;
@@ -452,7 +464,8 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     OBTE_REQUIRE(g->b_kmajor ? g->ldb >= g->K : g->ldb >= g->N, "obte_gemm_bf16: ldb too small");
     OBTE_REQUIRE(g->ldd >= g->N, "obte_gemm_bf16: ldd too small");
     OBTE_REQUIRE(g->lda <= 1 << 20 && g->ldb <= 1 << 20, "obte_gemm_bf16: leading dimension too large");
-    if (g->epilogue == OBTE_EPI_ADD || g->epilogue == OBTE_EPI_GELU_BWD) OBTE_REQUIRE(g->aux, "obte_gemm_bf16: epilogue needs aux");
+    if (g->epilogue == OBTE_EPI_ADD || g->epilogue == OBTE_EPI_GELU_BWD || g->epilogue == OBTE_EPI_ADD_DROPOUT) OBTE_REQUIRE(g->aux, "obte_gemm_bf16: epilogue needs aux");
+    if (g->epilogue == OBTE_EPI_ADD_DROPOUT) OBTE_REQUIRE(g->dropout_p >= 0.f && g->dropout_p < 1.f, "obte_gemm_bf16: dropout p must be in [0,1)");
     if (g->epilogue == OBTE_EPI_GELU) OBTE_REQUIRE(g->d2, "obte_gemm_bf16: GELU epilogue needs d2");
     if (g->epilogue != OBTE_EPI_NONE && g->epilogue != OBTE_EPI_ADD) OBTE_REQUIRE(g->alpha == 1.0f, "obte_gemm_bf16: alpha != 1 only with EPI_NONE / EPI_ADD");
     hipStream_t st = (hipStream_t)s;
@@ -486,6 +499,7 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     p.k_per_split = (int)cdiv64(nk, splits);
     p.splits = (int)cdiv64(nk, p.k_per_split);   // no empty splits
     p.alpha = g->alpha;
+    p.drop = make_drop(g->epilogue == OBTE_EPI_ADD_DROPOUT ? g->dropout_p : 0.f, g->dropout_seed, (uint32_t)g->dropout_site);
     if (g->a_kmajor && g->b_kmajor) rc = dispatch<true, true>(p, g->epilogue, pl.bn, st);
     else if (g->a_kmajor && !g->b_kmajor) rc = dispatch<true, false>(p, g->epilogue, pl.bn, st);
     else if (!g->a_kmajor && g->b_kmajor) rc = dispatch<false, true>(p, g->epilogue, pl.bn, st);

@@ -14,8 +14,10 @@ Contract notes (each mirrors a reference behaviour):
   * softmax scale is 8 / n_embd (model.py:119), GELU uses erf(x / 1.41421) (model.py:25), LayerNorm eps 1e-5.
   * The HIP path computes in bf16 with fp32 accumulation — the regime the reference trains and evaluates in
     (train_encoder.py:21,170).  Parameters must be bf16 on a GPU at forward time; anything else raises.
-  * dropout: only p == 0 (or eval mode) is implemented in this round; p > 0 in training raises
-    NotImplementedError rather than silently training without dropout.
+  * dropout (embedding, attention probabilities, both residual projections; model.py:83-84,160,204) is fused
+    into the kernels with a counter-based mask: same distribution and scaling as nn.Dropout, but necessarily a
+    different random stream than PyTorch's generator.  Each forward draws its seeds from torch's CPU generator, so
+    ``torch.manual_seed`` makes runs reproducible and activation checkpointing recomputes identical masks.
 """
 from __future__ import annotations
 
@@ -168,28 +170,31 @@ class _LinearFn(torch.autograd.Function):
 
 class _EmbeddingFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, idx, wte):
+    def forward(ctx, idx, wte, dropout_p, dropout_seed):
         ctx.save_for_backward(idx)
         ctx.vocab = wte.shape[0]
         ctx.w_param = wte
-        return ops.embedding_fwd(idx.contiguous(), wte)
+        ctx.drop = (dropout_p, dropout_seed)
+        return ops.embedding_fwd(idx.contiguous(), wte, dropout_p, dropout_seed)
 
     @staticmethod
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
-        return None, ops.embedding_bwd(idx.contiguous(), dout.contiguous(), ctx.vocab, accumulate_into=_grad_slot(ctx.w_param))
+        return None, ops.embedding_bwd(idx.contiguous(), dout.contiguous(), ctx.vocab, accumulate_into=_grad_slot(ctx.w_param),
+                                       dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1]), None, None
 
 
 class _BlockFn(torch.autograd.Function):
     """One pre-LN transformer block (model.py:170-181): a single C call per pass."""
 
     @staticmethod
-    def forward(ctx, x, ln1, attn_w, proj_w, ln2, fc_w, mlp_w, rope_cos, rope_sin, n_head, mask):
+    def forward(ctx, x, ln1, attn_w, proj_w, ln2, fc_w, mlp_w, rope_cos, rope_sin, n_head, mask, dropout_p, dropout_seed):
         x = x.contiguous()
         params = (ln1, attn_w, proj_w, ln2, fc_w, mlp_w)
-        y, act = ops.block_fwd(x, params, (rope_cos, rope_sin), n_head, mask)
+        y, act = ops.block_fwd(x, params, (rope_cos, rope_sin), n_head, mask, dropout_p, dropout_seed)
         ctx.save_for_backward(x, act, rope_cos, rope_sin, *params)
         ctx.n_head, ctx.mask = n_head, mask
+        ctx.drop = (dropout_p, dropout_seed)
         ctx.w_params = params
         return y
 
@@ -198,37 +203,59 @@ class _BlockFn(torch.autograd.Function):
         x, act, rope_cos, rope_sin, *params = ctx.saved_tensors
         slots = [_grad_slot(w) for w in ctx.w_params]
         dx, grads = ops.block_bwd(x, dy.contiguous(), act, tuple(params), (rope_cos, rope_sin), ctx.n_head, ctx.mask,
-                                  accumulate_into=slots)
-        return (dx, *grads, None, None, None, None)
+                                  accumulate_into=slots, dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1])
+        return (dx, *grads, None, None, None, None, None, None)
 
 
 class _AttnCoreFn(torch.autograd.Function):
     """rope + fused attention on a packed qkv activation (used by the standalone SelfAttention module)."""
 
     @staticmethod
-    def forward(ctx, qkv, rope_cos, rope_sin, n_head, scale, mask):
+    def forward(ctx, qkv, rope_cos, rope_sin, n_head, scale, mask, dropout_p, dropout_seed):
         B, T, C3 = qkv.shape
         hs = C3 // 3 // n_head
         qkv = qkv.contiguous().clone()
         ops.rope_qk_(qkv, rope_cos, rope_sin, B, T, n_head, hs)
-        o, lse = ops.attn_fwd(qkv, B, T, n_head, hs, scale, mask)
+        o, lse = ops.attn_fwd(qkv, B, T, n_head, hs, scale, mask, dropout_p, dropout_seed)
         ctx.save_for_backward(qkv, o, lse, rope_cos, rope_sin)
-        ctx.meta = (B, T, n_head, hs, scale, mask)
+        ctx.meta = (B, T, n_head, hs, scale, mask, dropout_p, dropout_seed)
         return o
 
     @staticmethod
     def backward(ctx, d_o):
         qkv, o, lse, rope_cos, rope_sin = ctx.saved_tensors
-        B, T, H, hs, scale, mask = ctx.meta
-        dqkv = ops.attn_bwd(qkv, o, d_o.contiguous(), lse, B, T, H, hs, scale, mask, rope=(rope_cos, rope_sin))
-        return dqkv, None, None, None, None, None
+        B, T, H, hs, scale, mask, dp, dseed = ctx.meta
+        dqkv = ops.attn_bwd(qkv, o, d_o.contiguous(), lse, B, T, H, hs, scale, mask, rope=(rope_cos, rope_sin),
+                            dropout_p=dp, dropout_seed=dseed)
+        return dqkv, None, None, None, None, None, None, None
 
 
-def _check_dropout(module: nn.Module, p: float) -> None:
-    if module.training and p > 0.0:
-        raise NotImplementedError(
-            f"dropout={p} in training mode is not implemented by the HIP path yet (round 1 covers the reference's "
-            "--dropout 0 regime). Set config.dropout = 0 or call model.eval().")
+class _DropoutFn(torch.autograd.Function):
+    """Elementwise dropout with the library's counter-based mask (used by the standalone SelfAttention / MLP modules;
+    inside Block the same masks are applied in the GEMM epilogues)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, site):
+        ctx.cfg = (p, seed, site)
+        return ops.dropout(x.contiguous(), p, seed, site)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, site = ctx.cfg
+        return ops.dropout(dy.contiguous(), p, seed, site), None, None, None
+
+
+def _new_seed() -> int:
+    """62-bit seed from torch's CPU generator: reproducible under torch.manual_seed, restored by checkpoint()'s RNG
+    preservation, and no GPU synchronisation."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def _active_p(module: nn.Module, p: float) -> float:
+    p = float(p)
+    if not 0.0 <= p < 1.0:
+        raise ValueError(f"dropout probability has to be in [0, 1), got {p}")
+    return p if module.training else 0.0
 
 
 # ------------------------------------------------------------------------------------------------------- modules
@@ -286,15 +313,17 @@ class SelfAttention(nn.Module):
 
     def forward(self, x, attn_mask=None):
         _require_hip(x, "SelfAttention")
-        _check_dropout(self, self.dropout)
         if self.autoregressive:
             raise NotImplementedError("autoregressive=True is not used by the encoder (model.py:192) and not implemented")
         B, T, C = x.size()
         mask = ops.MaskSpec.from_user(attn_mask, B, T, self.n_head, x.device)
         cos, sin = self.rope()
+        p = _active_p(self, self.dropout)
+        seed = _new_seed() if p > 0 else 0
         qkv = _LinearFn.apply(x, self.c_attn.weight, 1.0)
-        y = _AttnCoreFn.apply(qkv, cos, sin, self.n_head, 8.0 / self.n_embd, mask)
-        return _LinearFn.apply(y, self.c_proj.weight, 1.0)
+        y = _AttnCoreFn.apply(qkv, cos, sin, self.n_head, 8.0 / self.n_embd, mask, p, seed)
+        y = _LinearFn.apply(y, self.c_proj.weight, 1.0)
+        return _DropoutFn.apply(y, p, seed, L.SITE_RESID) if p > 0 else y
 
 
 class MLP(nn.Module):
@@ -306,9 +335,10 @@ class MLP(nn.Module):
 
     def forward(self, x):
         _require_hip(x, "MLP")
-        _check_dropout(self, self.dropout.p)
+        p = _active_p(self, self.dropout.p)
         h = _LinearFn.apply(x, self.c_fc.weight, 1.0)
-        return _LinearFn.apply(fused_gelu(h.float()).to(h.dtype), self.c_proj.weight, 1.0)
+        y = _LinearFn.apply(fused_gelu(h.float()).to(h.dtype), self.c_proj.weight, 1.0)
+        return _DropoutFn.apply(y, p, _new_seed(), L.SITE_MLP) if p > 0 else y
 
 
 class Block(nn.Module):
@@ -324,14 +354,16 @@ class Block(nn.Module):
     def forward(self, x, attn_mask=None):
         _require_hip(x, "Block")
         _require_hip(self.attn.c_attn.weight, "Block parameters")
-        _check_dropout(self, self.attn.dropout)
         if self.attn.autoregressive:
             raise NotImplementedError("autoregressive=True is not used by the encoder and not implemented")
         B, T, C = x.shape
         mask = ops.MaskSpec.from_user(attn_mask, B, T, self.attn.n_head, x.device)
         cos, sin = self.attn.rope()
+        # one dropout probability per block, as in the reference (config.dropout feeds all three nn.Dropout modules)
+        p = _active_p(self, self.attn.dropout)
+        seed = _new_seed() if p > 0 else 0
         return _BlockFn.apply(x, self.ln_1.weight, self.attn.c_attn.weight, self.attn.c_proj.weight, self.ln_2.weight,
-                              self.mlp.c_fc.weight, self.mlp.c_proj.weight, cos, sin, self.attn.n_head, mask)
+                              self.mlp.c_fc.weight, self.mlp.c_proj.weight, cos, sin, self.attn.n_head, mask, p, seed)
 
 
 @dataclass
@@ -389,10 +421,10 @@ class OmniBioTA(nn.Module):
         _require_hip(wte, "OmniBioTA")
         if not idx.is_cuda:
             raise RuntimeError("OmniBioTA.forward: idx must be on the GPU")
-        _check_dropout(self, self.transformer.drop.p)
         b = idx.shape[0]
         mask = ops.MaskSpec.from_user(attn_mask, b, t, self.config.n_head, idx.device)
-        x = _EmbeddingFn.apply(idx, wte)
+        p = _active_p(self, self.transformer.drop.p)
+        x = _EmbeddingFn.apply(idx, wte, p, _new_seed() if p > 0 else 0)
         for i, block in enumerate(self.transformer.h):
             if self.config.checkpoint_freq > 0 and i % self.config.checkpoint_freq == 0:
                 x = checkpoint(block, x, mask, use_reentrant=False)

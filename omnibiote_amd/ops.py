@@ -67,7 +67,7 @@ def layernorm_bwd(dy, x, w, mean, rstd, dresid=None):
 
 
 # --------------------------------------------------------------------------------------------------------- GEMM
-def gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True, epilogue=L.EPI_NONE, aux=None, alpha=1.0, out=None):
+def gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True, epilogue=L.EPI_NONE, aux=None, alpha=1.0, out=None, dropout=None):
     """D[M,N] = epilogue(alpha * sum_k A(m,k) B(n,k)); see include/omnibiote_hip.h.  Returns d, or (d, d2) for
     the GELU epilogue."""
     _need(a, "a"); _need(b, "b")
@@ -80,10 +80,11 @@ def gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True, epilogue=L.EPI_NONE, aux=N
     d2 = None
     if epilogue == L.EPI_GELU:
         d2 = torch.empty((M, N), dtype=bf16, device=a.device)
-    if epilogue in (L.EPI_ADD, L.EPI_GELU_BWD):
+    if epilogue in (L.EPI_ADD, L.EPI_GELU_BWD, L.EPI_ADD_DROPOUT):
         _need(aux, "aux"); assert aux.numel() == M * N
+    dp, dseed, dsite = dropout if dropout is not None else (0.0, 0, 0)   # (p, seed, site) for EPI_ADD_DROPOUT
     g = L.GemmArgs(_ptr(a), _ptr(b), _ptr(d), _ptr(aux), _ptr(d2), M, N, K, lda, ldb, N,
-                   int(a_kmajor), int(b_kmajor), epilogue, float(alpha))
+                   int(a_kmajor), int(b_kmajor), epilogue, float(alpha), float(dp), int(dsite), int(dseed))
     ws_bytes = int(L.lib().obte_gemm_workspace_bytes(M, N, K)) if (epilogue in (L.EPI_NONE, L.EPI_ADD) and M * N <= (1 << 23)) else 0
     if ws_bytes > 0:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
@@ -93,12 +94,20 @@ def gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True, epilogue=L.EPI_NONE, aux=N
     return (d, d2) if d2 is not None else d
 
 
-def linear_fwd(x2d, w, epilogue=L.EPI_NONE, aux=None, alpha=1.0):
+def linear_fwd(x2d, w, epilogue=L.EPI_NONE, aux=None, alpha=1.0, dropout=None):
     """y = x W^T for x [M,K], W [N,K] (nn.Linear forward)."""
     M, K = x2d.shape
     N = w.shape[0]
     assert w.shape[1] == K
-    return gemm(x2d, w, M, N, K, True, True, epilogue, aux, alpha)
+    return gemm(x2d, w, M, N, K, True, True, epilogue, aux, alpha, dropout=dropout)
+
+
+def dropout(x, p, seed, site=L.SITE_USER, out=None):
+    """out = dropout(x) with the library's counter-based mask (element index = flat index); x may alias out."""
+    _need(x, "x")
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().obte_dropout_bf16(_ptr(x), _ptr(out), x.numel(), float(p), int(seed), int(site), _stream()), "obte_dropout_bf16")
+    return out
 
 
 def linear_dgrad(dy2d, w, epilogue=L.EPI_NONE, aux=None, alpha=1.0):
@@ -178,39 +187,41 @@ class MaskSpec:
         return MaskSpec(dense=m)
 
 
-def attn_fwd(qkv, B, T, H, hs, scale, mask: Optional[MaskSpec] = None):
+def attn_fwd(qkv, B, T, H, hs, scale, mask: Optional[MaskSpec] = None, dropout_p=0.0, dropout_seed=0):
     _need(qkv, "qkv"); assert qkv.numel() == B * T * 3 * H * hs
     mask = mask or MaskSpec()
     o = torch.empty((B, T, H * hs), dtype=bf16, device=qkv.device)
     lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
     a = L.AttnFwdArgs(_ptr(qkv), _ptr(o), _ptr(lse), _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq,
-                      B, T, H, hs, float(scale))
+                      B, T, H, hs, float(scale), float(dropout_p), int(dropout_seed))
     L.check(L.lib().obte_attn_fwd(C.byref(a), _stream()), "obte_attn_fwd")
     return o, lse
 
 
-def attn_bwd(qkv, o, d_o, lse, B, T, H, hs, scale, mask: Optional[MaskSpec] = None, rope=None):
+def attn_bwd(qkv, o, d_o, lse, B, T, H, hs, scale, mask: Optional[MaskSpec] = None, rope=None, dropout_p=0.0, dropout_seed=0):
     _need(qkv, "qkv"); _need(o, "o"); _need(d_o, "d_o"); _need(lse, "lse", torch.float32)
     mask = mask or MaskSpec()
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
     cos, sin = rope if rope is not None else (None, None)
     a = L.AttnBwdArgs(_ptr(qkv), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(delta), _ptr(dqkv), _ptr(cos), _ptr(sin),
-                      _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq, B, T, H, hs, float(scale))
+                      _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq, B, T, H, hs, float(scale),
+                      float(dropout_p), int(dropout_seed))
     L.check(L.lib().obte_attn_bwd(C.byref(a), _stream()), "obte_attn_bwd")
     return dqkv
 
 
 # ---------------------------------------------------------------------------------------------------- embedding
-def embedding_fwd(idx, wte):
+def embedding_fwd(idx, wte, dropout_p=0.0, dropout_seed=0):
     _need(idx, "idx", torch.int64); _need(wte, "wte")
     V, Cc = wte.shape
     out = torch.empty(tuple(idx.shape) + (Cc,), dtype=bf16, device=wte.device)
-    L.check(L.lib().obte_embedding_fwd(_ptr(idx), _ptr(wte), _ptr(out), idx.numel(), Cc, V, _stream()), "obte_embedding_fwd")
+    L.check(L.lib().obte_embedding_fwd_dropout(_ptr(idx), _ptr(wte), _ptr(out), idx.numel(), Cc, V, float(dropout_p),
+                                                int(dropout_seed), _stream()), "obte_embedding_fwd")
     return out
 
 
-def embedding_bwd(idx, dout, vocab, accumulate_into=None):
+def embedding_bwd(idx, dout, vocab, accumulate_into=None, dropout_p=0.0, dropout_seed=0):
     """accumulate_into: an existing dense (vocab, C) gradient; the touched rows are updated in place
     (bf16(old + bf16(sum))), nothing else is read or written."""
     _need(idx, "idx", torch.int64); _need(dout, "dout")
@@ -220,12 +231,12 @@ def embedding_bwd(idx, dout, vocab, accumulate_into=None):
     ws = torch.empty(max(int(L.lib().obte_embedding_bwd_ws_bytes(rows, Cc)), 16), dtype=torch.uint8, device=dout.device)
     if accumulate_into is not None:
         _need(accumulate_into, "grad"); assert tuple(accumulate_into.shape) == (vocab, Cc)
-        L.check(L.lib().obte_embedding_bwd_acc(_ptr(idx), _ptr(order), _ptr(dout), _ptr(accumulate_into), _ptr(ws), rows, Cc, vocab,
-                                                1, _stream()), "obte_embedding_bwd_acc")
+        L.check(L.lib().obte_embedding_bwd_dropout(_ptr(idx), _ptr(order), _ptr(dout), _ptr(accumulate_into), _ptr(ws), rows, Cc,
+                                                    vocab, 1, float(dropout_p), int(dropout_seed), _stream()), "obte_embedding_bwd")
         return None
     dwte = torch.empty((vocab, Cc), dtype=bf16, device=dout.device)
-    L.check(L.lib().obte_embedding_bwd(_ptr(idx), _ptr(order), _ptr(dout), _ptr(dwte), _ptr(ws), rows, Cc, vocab, _stream()),
-            "obte_embedding_bwd")
+    L.check(L.lib().obte_embedding_bwd_dropout(_ptr(idx), _ptr(order), _ptr(dout), _ptr(dwte), _ptr(ws), rows, Cc, vocab, 0,
+                                                float(dropout_p), int(dropout_seed), _stream()), "obte_embedding_bwd")
     return dwte
 
 
@@ -261,13 +272,14 @@ def sumsq_(g, out):
 
 
 # -------------------------------------------------------------------------------------------------------- block
-def _block_desc(B, T, Cc, H, params, rope, mask: MaskSpec):
+def _block_desc(B, T, Cc, H, params, rope, mask: MaskSpec, dropout_p=0.0, dropout_seed=0):
     ln1, attn_w, proj_w, ln2, fc_w, mlp_w = params
     return L.BlockDesc(B, T, Cc, H, _ptr(ln1), _ptr(attn_w), _ptr(proj_w), _ptr(ln2), _ptr(fc_w), _ptr(mlp_w),
-                       _ptr(rope[0]), _ptr(rope[1]), _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq)
+                       _ptr(rope[0]), _ptr(rope[1]), _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq,
+                       float(dropout_p), int(dropout_seed))
 
 
-def block_fwd(x, params, rope, H, mask: MaskSpec):
+def block_fwd(x, params, rope, H, mask: MaskSpec, dropout_p=0.0, dropout_seed=0):
     """One transformer block forward.  Returns (y, act) where act is the opaque saved-activation buffer."""
     _need(x, "x")
     B, T, Cc = x.shape
@@ -277,12 +289,12 @@ def block_fwd(x, params, rope, H, mask: MaskSpec):
     assert rope[0].shape[0] >= T
     y = torch.empty_like(x)
     act = torch.empty(int(L.lib().obte_block_act_bytes(B, T, Cc, H)), dtype=torch.uint8, device=x.device)
-    d = _block_desc(B, T, Cc, H, params, rope, mask)
+    d = _block_desc(B, T, Cc, H, params, rope, mask, dropout_p, dropout_seed)
     L.check(L.lib().obte_block_fwd(C.byref(d), _ptr(x), _ptr(y), _ptr(act), _stream()), "obte_block_fwd")
     return y, act
 
 
-def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec, accumulate_into=None):
+def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec, accumulate_into=None, dropout_p=0.0, dropout_seed=0):
     """accumulate_into: optional list of 6 tensors-or-None (same order as params).  When the four matrix entries are all
     given, their gradients are added into those tensors in place and the corresponding returned grads are None."""
     _need(x, "x"); _need(dy, "dy")
@@ -298,7 +310,7 @@ def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec, accumulate_into=None)
             grads.append(g)
         else:
             grads.append(torch.empty_like(w))
-    d = _block_desc(B, T, Cc, H, params, rope, mask)
+    d = _block_desc(B, T, Cc, H, params, rope, mask, dropout_p, dropout_seed)
     L.check(L.lib().obte_block_bwd_acc(C.byref(d), _ptr(x), _ptr(dy), _ptr(act), _ptr(ws), _ptr(dx), *[_ptr(g) for g in grads],
                                         int(acc), _stream()), "obte_block_bwd")
     if acc:

@@ -114,6 +114,47 @@ def readout(emb: torch.Tensor, weight: torch.Tensor, width_mult: float, output_m
 
 
 # --------------------------------------------------------------------------------------------------
+# dropout masks of the HIP path, restated (include/omnibiote_hip.h "dropout"; csrc/common.h drop_keep).
+# The reference uses PyTorch's generator (model.py:83-84,160,204), whose stream no other implementation can
+# reproduce; the product instead derives every mask from a counter-based hash of (seed, site, element index),
+# which this restatement mirrors bit for bit so that dropout-on parity tests can hand the oracle the same mask.
+# --------------------------------------------------------------------------------------------------
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _hash32(x: np.ndarray) -> np.ndarray:
+    x = x & _M32
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & _M32
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & _M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def dropout_keep(idx: np.ndarray, p: float, seed: int, site: int) -> np.ndarray:
+    """Boolean keep decision for element indices ``idx`` (uint64) of dropout site ``site``."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    s0 = np.uint64(((seed & 0xFFFFFFFF) ^ ((site * 0x632BE5AB) & 0xFFFFFFFF)) & 0xFFFFFFFF)
+    s1 = np.uint64(((seed >> 32) + site * 0x9E3779B9) & 0xFFFFFFFF)
+    thresh = np.uint64(int(float(np.float32(p)) * 16777216.0)) if p > 0 else np.uint64(0)
+    x = _hash32((idx & _M32) ^ s0)
+    x = _hash32((x + ((idx >> np.uint64(32)) * np.uint64(0x9E3779B1) & _M32) + s1) & _M32)
+    return (x >> np.uint64(8)) >= thresh
+
+
+def dropout_scale_mask(shape, p: float, seed: int, site: int) -> torch.Tensor:
+    """fp32 tensor of ``shape`` holding 1/(1-p) where kept and 0 where dropped; element index = flat index."""
+    n = int(np.prod(shape))
+    keep = dropout_keep(np.arange(n, dtype=np.uint64), p, seed, site)
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    return torch.from_numpy(np.where(keep, scale, np.float32(0.0)).astype(np.float32).reshape(shape))
+
+
+def dropout_apply(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """dropout as the product rounds it: bf16(x * scale) where kept (x already carries its own dtype)."""
+    return (x.float() * mask).to(x.dtype)
+
+
+# --------------------------------------------------------------------------------------------------
 # attention-mask builder (training/train_encoder.py:25-57) restated over numpy
 # --------------------------------------------------------------------------------------------------
 def document_blocks(tokens: np.ndarray, eos: int = EOS_TOKEN, padding: bool = False) -> List[List[Tuple[int, int]]]:

@@ -159,14 +159,39 @@ def test_checkpointing_gives_identical_gradients(golden_dir):
         assert torch.equal(a, b)
 
 
-def test_dropout_in_training_is_refused_loudly(golden_dir):
-    g = load(golden_dir, "tiny_bf16_mask")
-    m = build(g, "cos_only")
-    m.transformer.drop.p = 0.1
-    with pytest.raises(NotImplementedError):
-        m(torch.from_numpy(g["masked_ids"]).to(DEV))
-    m.eval()
-    m(torch.from_numpy(g["masked_ids"]).to(DEV))   # eval mode: dropout inactive, as in the reference
+def test_dropout_training_mode(golden_dir):
+    """config.dropout > 0 in training mode: masks are applied (output differs from eval, keeps ~1-p of the embedding),
+    runs are reproducible under torch.manual_seed, activation checkpointing recomputes identical masks, eval mode is
+    untouched (the reference's nn.Dropout semantics; the random stream itself necessarily differs from PyTorch's)."""
+    g = load(golden_dir, "wide_bf16_mask")
+    idx = torch.from_numpy(g["masked_ids"]).to(DEV)
+
+    def run(freq, seed, train=True):
+        m = build(g, "cos_only")
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.25
+        for blk in m.transformer.h:
+            blk.attn.dropout = 0.25
+        m.config.checkpoint_freq = freq
+        m.train(train)
+        torch.manual_seed(seed)
+        out = m(idx, attn_mask=masks_for(g, "ranges", 2), return_embeddings=True)
+        out.float().pow(2).sum().backward()
+        return out.detach().clone(), [p.grad.clone() for p in m.parameters() if p.grad is not None]
+
+    o1, g1 = run(0, 7)
+    o2, g2 = run(0, 7)
+    o3, g3 = run(1, 7)          # every block checkpointed: recomputation must regenerate the same masks
+    o4, _ = run(0, 8)
+    oe, _ = run(0, 7, train=False)
+    assert torch.equal(o1, o2) and all(torch.equal(a, b) for a, b in zip(g1, g2))
+    assert torch.equal(o1, o3) and all(torch.equal(a, b) for a, b in zip(g1, g3))
+    assert not torch.equal(o1, o4)
+    assert not torch.equal(o1, oe)
+    mx, mean = stats(oe, g["emb"])
+    assert mx <= 0.10 and mean <= 5e-3
+    assert all(torch.isfinite(x).all() for x in g1)
 
 
 def test_loss_curve_tracks_oracle_step_for_step():

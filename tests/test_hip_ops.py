@@ -487,3 +487,124 @@ def test_wgrad_and_embedding_accumulate_in_place():
     acc = old.clone().to(DEV)
     assert o.embedding_bwd(idx.to(DEV), dout.to(DEV), V, accumulate_into=acc) is None
     assert torch.equal(acc, (old.to(DEV).float() + fresh.float()).to(BF))
+
+
+# ---------------------------------------------------------------------------------------------------- dropout
+SEED = 0x1234_5678_9ABC
+
+
+def test_dropout_mask_matches_restatement_and_rate():
+    n, p = 1 << 20, 0.1
+    x = torch.ones(n, dtype=BF, device=DEV)
+    y = ops().dropout(x, p, SEED, site=7).float().cpu()
+    mask = R.dropout_scale_mask((n,), p, SEED, 7)
+    assert torch.equal(y, mask.to(BF).float())
+    assert abs((y != 0).float().mean().item() - 0.9) < 2e-3
+    z = ops().dropout(x, p, SEED + 1, site=7).float().cpu()
+    assert not torch.equal(y, z)
+    assert torch.equal(ops().dropout(x, 0.0, SEED, site=7), x)
+    with pytest.raises(RuntimeError):
+        ops().dropout(x, 1.0, SEED)
+
+
+def test_embedding_dropout_fwd_bwd():
+    V, C, rows, p = 300, 128, 500, 0.3
+    idx = torch.from_numpy(np.random.default_rng(3).integers(0, V, size=rows)); idx[:150] = 2
+    wte, dout = rnd(V, C, seed=1), rnd(rows, C, seed=2)
+    mask = R.dropout_scale_mask((rows, C), p, SEED, 0)
+    got = ops().embedding_fwd(idx.to(DEV), wte.to(DEV), p, SEED)
+    assert torch.equal(got.cpu(), R.dropout_apply(wte[idx], mask))
+    dw = ops().embedding_bwd(idx.to(DEV), dout.to(DEV), V, dropout_p=p, dropout_seed=SEED)
+    ref = torch.zeros(V, C).index_add_(0, idx, R.dropout_apply(dout, mask).float())
+    close(dw, ref, atol=3e-2, what="embedding bwd with dropout")
+
+
+@pytest.mark.parametrize("bn", ["128", "256"])
+def test_gemm_residual_dropout_epilogue(monkeypatch, bn):
+    monkeypatch.setenv("OBTE_GEMM_BN", bn)
+    M, N, K, p = 300, 512, 128, 0.2
+    x, w, r = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=0.2), rnd(M, N, seed=9)
+    acc = (x.float() @ w.float().t()).to(BF)
+    mask = R.dropout_scale_mask((M, N), p, SEED, 2)
+    ref = r.float() + R.dropout_apply(acc, mask).float()
+    got = ops().linear_fwd(x.to(DEV), w.to(DEV), epilogue=L().EPI_ADD_DROPOUT, aux=r.to(DEV), dropout=(p, SEED, 2))
+    # the bf16 rounding of acc can differ by an ulp from the fp32 reference matmul: compare with tolerance, but the
+    # dropped positions must be exactly the residual
+    close(got, ref, atol=0.04, what="residual dropout")
+    assert torch.equal(got.cpu()[mask == 0], r[mask == 0])
+
+
+@pytest.mark.parametrize("hs", [64, 128])
+@pytest.mark.parametrize("mode", ["none", "ranges", "dense"])
+def test_attention_dropout_fwd_bwd(hs, mode):
+    B, H, T, p = 2, 2, 130, 0.2
+    C = H * hs
+    scale = 8.0 / C
+    qkv, q, k, v = _attn_case(B, T, H, hs, seed=hs)
+    tokens = np.random.default_rng(T).integers(20, 100, size=(B, T))
+    tokens[0, [T // 3]] = R.EOS_TOKEN
+    tokens[1, [5, T - 10]] = R.EOS_TOKEN
+    dense, ranges = _blocks_to_masks(tokens, T)
+    o = ops()
+    mask_add, spec = None, None
+    if mode == "ranges":
+        mask_add, spec = dense.unsqueeze(1), o.MaskSpec(ranges=ranges.to(DEV))
+    elif mode == "dense":
+        mask_add = dense.unsqueeze(1)
+        spec = o.MaskSpec.from_user(dense.to(BF).to(DEV).unsqueeze(1).expand(B, H, T, T), B, T, H, DEV)
+    dmask = R.dropout_scale_mask((B, H, T, T), p, SEED, 1)
+    qf, kf, vf = q.requires_grad_(True), k.requires_grad_(True), v.requires_grad_(True)
+    att = (qf @ kf.transpose(-2, -1)) * scale
+    if mask_add is not None:
+        att = att + mask_add
+    ref = (torch.softmax(att, dim=-1) * dmask) @ vf
+    d_o = rnd(B, T, C, seed=99)
+    ref.backward(d_o.reshape(B, T, H, hs).transpose(1, 2).float())
+    got, lse = o.attn_fwd(qkv.to(DEV), B, T, H, hs, scale, spec, p, SEED)
+    close(got, ref.transpose(1, 2).reshape(B, T, C), atol=8e-3, what=f"attn dropout fwd {mode}")
+    close(lse, torch.logsumexp(att.detach(), dim=-1), atol=2e-3, rtol=1e-3, what="lse is of the un-dropped scores")
+    dqkv = o.attn_bwd(qkv.to(DEV), got, d_o.to(DEV), lse, B, T, H, hs, scale, spec, dropout_p=p, dropout_seed=SEED)
+    dref = torch.cat([t.transpose(1, 2).reshape(B, T, C) for t in (qf.grad, kf.grad, vf.grad)], dim=2)
+    close(dqkv, dref, atol=2e-2, rtol=2.0 ** -6, what=f"attn dropout bwd {mode}")
+
+
+def test_block_dropout_fwd_bwd_vs_oracle():
+    """A whole block with all three dropout sites on, against the oracle fed the restated masks."""
+    B, T, C, H, p = 2, 64, 128, 2, 0.15
+    hs = C // H
+    cfg = R.RefConfig(block_size=T, vocab_size=256, n_layer=1, n_head=H, n_embd=C)
+    w = {k: v.to(BF) for k, v in R.hash_weights(cfg).items()}
+    pre = "transformer.h.0."
+    names = ["ln_1.weight", "attn.c_attn.weight", "attn.c_proj.weight", "ln_2.weight", "mlp.c_fc.weight", "mlp.c_proj.weight"]
+    x, dy = rnd(B, T, C, seed=1), rnd(B, T, C, seed=2, scale=0.1)
+    tab = R.cast_rope_table(R.rope_table(hs, T), BF)
+    m_attn = R.dropout_scale_mask((B, H, T, T), p, SEED, 1)
+    m_res = R.dropout_scale_mask((B, T, C), p, SEED, 2)
+    m_mlp = R.dropout_scale_mask((B, T, C), p, SEED, 3)
+    wf = {k: v.float().requires_grad_(True) for k, v in w.items()}
+    xf = x.float().requires_grad_(True)
+    import torch.nn.functional as F
+    h1 = R.layer_norm(xf, wf[pre + "ln_1.weight"])
+    qkv = F.linear(h1, wf[pre + "attn.c_attn.weight"])
+    q, k, v = qkv.split(C, dim=2)
+    q = R.apply_rope(q.reshape(B, T, H, hs), tab).transpose(1, 2)
+    k = R.apply_rope(k.reshape(B, T, H, hs), tab).transpose(1, 2)
+    v = v.reshape(B, T, H, hs).transpose(1, 2)
+    y = (torch.softmax((q @ k.transpose(-2, -1)) * (8.0 / C), dim=-1) * m_attn) @ v
+    y = y.transpose(1, 2).contiguous().view(B, T, C)
+    x1 = xf + F.linear(y, wf[pre + "attn.c_proj.weight"]) * m_res
+    a = R.gelu_erf(F.linear(R.layer_norm(x1, wf[pre + "ln_2.weight"]), wf[pre + "mlp.c_fc.weight"]))
+    ref = x1 + F.linear(a, wf[pre + "mlp.c_proj.weight"]) * m_mlp
+    ref.backward(dy.float())
+    from omnibiote_amd.model import rope_tables
+    o = ops()
+    params = tuple(w[pre + n].to(DEV) for n in names)
+    rope = rope_tables(tab.to(DEV))
+    spec = o.MaskSpec()
+    yg, act = o.block_fwd(x.to(DEV), params, rope, H, spec, p, SEED)
+    close(yg, ref, atol=4e-2, rtol=2.0 ** -6, what="block dropout fwd")
+    dx, grads = o.block_bwd(x.to(DEV), dy.to(DEV), act, params, rope, H, spec, dropout_p=p, dropout_seed=SEED)
+    close(dx, xf.grad, atol=2e-2, rtol=2.0 ** -5, what="block dropout dx")
+    for n, gg in zip(names, grads):
+        gr = wf[pre + n].grad
+        close(gg, gr, atol=0.03 * gr.abs().max().item() + 1e-3, rtol=2.0 ** -5, what="block dropout d" + n)
