@@ -47,7 +47,8 @@ class BlockDesc(C.Structure):
                 ("ln2_w", C.c_void_p), ("fc_w", C.c_void_p), ("mlp_w", C.c_void_p),
                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
                 ("key_ranges", C.c_void_p), ("mask", C.c_void_p),
-                ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64)]
+                ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
+                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)]
 
 
 MT_MAX = 32
