@@ -50,6 +50,7 @@ def parse():
     p.add_argument("--rows_per_rank", type=int, default=128, help="rows per rank per optimizer step (batch_size / world)")
     p.add_argument("--mini_batch_size", type=int, default=8)
     p.add_argument("--multi_document", action="store_true", help="rows with interior EOS (block-diagonal masks)")
+    p.add_argument("--dropout", type=float, default=0.0, help="0.0 = the parity regime (default); 0.1 = the reference's default")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
     p.add_argument("--shapes_out", default="", help="write the per-shape launch table (from the profiler step) to this file")
@@ -62,7 +63,7 @@ def harness_args(cfg, a, world):
     h.batch_size = a.rows_per_rank * world
     h.mini_batch_size = a.mini_batch_size
     h.n_layer, h.n_embd, h.n_head, h.ctx_len = cfg["n_layer"], cfg["n_embd"], cfg["n_head"], cfg["ctx_len"]
-    h.dropout = 0.0
+    h.dropout = a.dropout
     h.token_budget = 20e9
     return h
 
@@ -228,14 +229,14 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": METRIC, "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "metric": METRIC if a.config == "small" else f"MLM train tokens/sec, {a.config} ctx={T}", "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"OmniBioTA {a.config} ({cfg['n_layer']}L/{cfg['n_embd']}d/{cfg['n_head']}h) ctx={T} MLM train step: "
                                    f"{a.rows_per_rank} rows/rank = {a.rows_per_rank // a.mini_batch_size} micro-batches of {a.mini_batch_size}, "
-                                   f"full 65536-way logits, dropout 0, {'multi' if a.multi_document else 'single'}-document rows",
+                                   f"full 65536-way logits, dropout {a.dropout:g}, {'multi' if a.multi_document else 'single'}-document rows",
                        "global_batch_rows": a.rows_per_rank * world, "mini_batch_size": a.mini_batch_size, "seq_len": T,
-                       "parallelism": f"dp{world}", "dropout": 0.0, "vocab": 65536},
+                       "parallelism": f"dp{world}", "dropout": a.dropout, "vocab": 65536},
             "flops_per_token": fpt,
             "mfma_fraction_whole_step": round(value * fpt / (PEAK_BF16_TFLOPS * 1e12 * world), 4),
             "final_loss": round(float(losses[-1].item()), 4),
@@ -244,7 +245,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -31,6 +31,9 @@ enum {
 
 int obte_abi_version(void);
 const char* obte_last_error(void);
+/* sizeof of the public argument structs in declaration order (gemm, attn_fwd, attn_bwd, mt, block_desc): lets a
+ * binding written in another language verify its struct layout at load time.  Returns the number of structs. */
+int obte_struct_sizes(int64_t* out, int cap);
 
 /* ---- opt-in launch profiler (measurement only; off by default) ----------------------------------------------
  * While enabled, every obte_gemm_bf16 / obte_attn_fwd / obte_attn_bwd call is bracketed by two hipEvents on the

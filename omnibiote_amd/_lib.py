@@ -67,6 +67,7 @@ SITE_EMBED, SITE_ATTN, SITE_RESID, SITE_MLP, SITE_USER = 0, 1, 2, 3, 7
 SYMBOLS = {
     "obte_abi_version": (C.c_int, []),
     "obte_last_error": (C.c_char_p, []),
+    "obte_struct_sizes": (C.c_int, [C.c_void_p, C.c_int]),
     "obte_profile_enable": (C.c_int, [C.c_int]),
     "obte_profile_collect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "obte_layernorm_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_float, c_stream]),
@@ -134,6 +135,11 @@ def lib():
                     raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
                 fn.restype = res
                 fn.argtypes = args
+            sizes = (C.c_int64 * 8)()
+            n = l.obte_struct_sizes(sizes, 8)
+            mine = [C.sizeof(GemmArgs), C.sizeof(AttnFwdArgs), C.sizeof(AttnBwdArgs), C.sizeof(MtArgs), C.sizeof(BlockDesc)]
+            if n != len(mine) or list(sizes[:n]) != mine:
+                raise HipLibraryError(f"struct layout mismatch between _lib.py {mine} and {LIB_PATH} {list(sizes[:n])}")
             _lib = l
     return _lib
 

@@ -13,6 +13,14 @@ void obte_set_error(const char* fmt, ...) {
 
 extern "C" const char* obte_last_error(void) { return g_err; }
 extern "C" int obte_abi_version(void) { return 1; }
+// sizeof of every public argument struct, in header order, so that a binding can check its own layout
+extern "C" int obte_struct_sizes(int64_t* out, int cap) {
+    const int64_t v[] = {(int64_t)sizeof(obte_gemm_args), (int64_t)sizeof(obte_attn_fwd_args), (int64_t)sizeof(obte_attn_bwd_args),
+                         (int64_t)sizeof(obte_mt_args), (int64_t)sizeof(obte_block_desc)};
+    const int n = (int)(sizeof(v) / sizeof(v[0]));
+    for (int i = 0; i < n && i < cap; ++i) out[i] = v[i];
+    return n;
+}
 
 // ---- opt-in launch profiler ---------------------------------------------------------------------------------
 #include <mutex>
