@@ -66,10 +66,14 @@ int obte_layernorm_bwd(const obte_bf16* dy, const obte_bf16* x, const obte_bf16*
  */
 enum {
     OBTE_EPI_NONE = 0,      /* d = bf16(alpha*acc) */
-    OBTE_EPI_GELU = 1,      /* d = bf16(acc) ; d2 = bf16(gelu_erf_1.41421(d))   (model.py:23-25,163-165) */
+    OBTE_EPI_GELU = 1,      /* h = bf16(acc); d = bf16(gelu'(h)) ; d2 = bf16(gelu_erf_1.41421(h))   (model.py:23-25,163-165):
+                               the forward stores the activation and its derivative from one erf evaluation */
     OBTE_EPI_ADD = 2,       /* d = bf16(aux + bf16(alpha*acc))  residual add (model.py:179-180); aux may alias d
                                (gradient accumulation in place) */
-    OBTE_EPI_GELU_BWD = 3,  /* d = bf16(bf16(acc) * gelu'(aux))  aux = pre-activation */
+    OBTE_EPI_GELU_BWD = 3,  /* d = bf16(bf16(acc) * aux)   aux = the derivative stored by EPI_GELU */
+    OBTE_EPI_ROPE_QK = 5,   /* d = packed c_attn output with RoPE applied to its q and k thirds (model.py:102-108): N = 3C,
+                               pairs (2j,2j+1) of each head rotated by (rope_cos, rope_sin)[row % rope_T][j], fp32 [T, hs/2];
+                               all-zero sin = the reference's cos-only bf16 mode */
     OBTE_EPI_ADD_DROPOUT = 4 /* d = bf16(aux + dropout(bf16(acc)))   resid_dropout / mlp dropout (model.py:151,167);
                                 element (m,n) uses dropout index m*ldd+n of (dropout_seed, dropout_site) */
 };
@@ -83,6 +87,7 @@ typedef struct {
     int32_t epilogue;
     float alpha;
     float dropout_p; int32_t dropout_site; uint64_t dropout_seed;   /* EPI_ADD_DROPOUT only */
+    const float* rope_cos; const float* rope_sin; int64_t rope_T; int32_t rope_head_dim;   /* EPI_ROPE_QK only */
 } obte_gemm_args;
 int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s);
 /* Same, with a caller-owned scratch buffer that enables split-K (fp32 partial tiles summed in a fixed order by a

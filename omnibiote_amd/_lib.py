@@ -21,7 +21,8 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
                 ("lda", C.c_int64), ("ldb", C.c_int64), ("ldd", C.c_int64),
                 ("a_kmajor", C.c_int32), ("b_kmajor", C.c_int32), ("epilogue", C.c_int32), ("alpha", C.c_float),
-                ("dropout_p", C.c_float), ("dropout_site", C.c_int32), ("dropout_seed", C.c_uint64)]
+                ("dropout_p", C.c_float), ("dropout_site", C.c_int32), ("dropout_seed", C.c_uint64),
+                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("rope_T", C.c_int64), ("rope_head_dim", C.c_int32)]
 
 
 class AttnFwdArgs(C.Structure):
@@ -60,7 +61,7 @@ class MtArgs(C.Structure):
                 ("step", C.c_int32 * MT_MAX), ("count", C.c_int32)]
 
 
-EPI_NONE, EPI_GELU, EPI_ADD, EPI_GELU_BWD, EPI_ADD_DROPOUT = 0, 1, 2, 3, 4
+EPI_NONE, EPI_GELU, EPI_ADD, EPI_GELU_BWD, EPI_ADD_DROPOUT, EPI_ROPE_QK = 0, 1, 2, 3, 4, 5
 SITE_EMBED, SITE_ATTN, SITE_RESID, SITE_MLP, SITE_USER = 0, 1, 2, 3, 7
 
 # name -> (restype, argtypes); every symbol include/omnibiote_hip.h declares

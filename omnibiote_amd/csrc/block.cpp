@@ -108,8 +108,14 @@ extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte
     float* lse = (float*)(A + L.lse);
 
     TRY(obte_layernorm_fwd(x, d->ln1_w, h1, mean1, rstd1, M, C, 1e-5f, s));
-    TRY(gemm(h1, d->attn_w, qkv, M, 3 * C, C, C, C, 1, 1, OBTE_EPI_NONE, nullptr, nullptr, s));
-    TRY(obte_rope_qk_inplace(qkv, d->rope_cos, d->rope_sin, d->B, d->T, H, hs, 0, s));
+    {   // c_attn with RoPE on its q and k thirds fused in the epilogue (model.py:102-108)
+        obte_gemm_args g = {};
+        g.a = h1; g.b = d->attn_w; g.d = qkv;
+        g.M = M; g.N = 3 * C; g.K = C; g.lda = C; g.ldb = C; g.ldd = 3 * C;
+        g.a_kmajor = 1; g.b_kmajor = 1; g.epilogue = OBTE_EPI_ROPE_QK; g.alpha = 1.0f;
+        g.rope_cos = d->rope_cos; g.rope_sin = d->rope_sin; g.rope_T = d->T; g.rope_head_dim = hs;
+        TRY(obte_gemm_bf16(&g, s));
+    }
     obte_attn_fwd_args af = {};
     af.qkv = qkv; af.o = yat; af.lse = lse; af.key_ranges = d->key_ranges; af.mask = d->mask;
     af.mask_sb = d->mask_sb; af.mask_sh = d->mask_sh; af.mask_sq = d->mask_sq;
@@ -163,7 +169,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
         TRY(obte_dropout_bf16(dy, dym, M * C, d->dropout_p, d->dropout_seed, SITE_MLP, s));
         dy_mlp = dym;
     }
-    TRY(gemm(dy_mlp, d->mlp_w, dhpre, M, 4 * C, C, C, 4 * C, 1, 0, OBTE_EPI_GELU_BWD, hpre, nullptr, s));      // dhpre = (dy W_mlp) * gelu'(hpre)
+    TRY(gemm(dy_mlp, d->mlp_w, dhpre, M, 4 * C, C, C, 4 * C, 1, 0, OBTE_EPI_GELU_BWD, hpre, nullptr, s));      // dhpre = (dy W_mlp) * gelu'(h): hpre holds the derivative
     TRY(gemm(dy_mlp, hact, dmlp_w, C, 4 * C, M, C, 4 * C, 0, 0, wepi, accumulate_matrices ? dmlp_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_mlp = dy^T hact
     TRY(gemm(dhpre, d->fc_w, dh, M, C, 4 * C, 4 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh2 = dhpre W_fc
     TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, M, 4 * C, C, 0, 0, wepi, accumulate_matrices ? dfc_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_fc = dhpre^T h2

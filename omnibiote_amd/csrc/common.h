@@ -94,6 +94,13 @@ __device__ __forceinline__ float gelu_ref(float x) {
     erf_and_gauss(x * (1.0f / OBTE_GELU_C), e, g);
     return x * 0.5f * (1.0f + e);
 }
+__device__ __forceinline__ void gelu_ref_both(float x, float& act, float& der) {
+    float e, g;
+    erf_and_gauss(x * (1.0f / OBTE_GELU_C), e, g);
+    const float half_cdf = 0.5f * (1.0f + e);
+    act = x * half_cdf;
+    der = half_cdf + x * (0.5641895835477563f / OBTE_GELU_C) * g;
+}
 __device__ __forceinline__ float gelu_ref_grad(float x) {
     float e, g;
     erf_and_gauss(x * (1.0f / OBTE_GELU_C), e, g);

@@ -35,6 +35,7 @@ struct GemmParams {
     int tiles_m, tiles_n;
     float alpha;
     DropCfg drop;
+    const float* rope_cos; const float* rope_sin; int64_t rope_T; int rope_hs;
 };
 
 __device__ __forceinline__ int kmaj_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -195,14 +196,36 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * EPI_LD + c8 * 16);
             const int64_t o = m * p.ldd + n;
             if (EPI == OBTE_EPI_GELU) {
+                // one erf/exp evaluation yields both the activation (d2) and its derivative (d): the backward
+                // epilogue is then a plain multiply
                 bf16x8 g;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) g[j] = f2bf(gelu_ref(bf2f(v[j])));
+                for (int j = 0; j < 8; ++j) {
+                    float act, der;
+                    gelu_ref_both(bf2f(v[j]), act, der);
+                    g[j] = f2bf(act);
+                    v[j] = f2bf(der);
+                }
                 *reinterpret_cast<bf16x8*>(p.d2 + o) = g;
             } else if (EPI == OBTE_EPI_ADD) {
                 const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.aux + o);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(r[j]) + bf2f(v[j]));
+            } else if (EPI == OBTE_EPI_ROPE_QK) {
+                // packed c_attn output [.., 3C]: rotate the (even, odd) pairs of the q and k thirds (columns < 2N/3),
+                // position = row % T; the v third passes through.  fp32 arithmetic on the bf16-rounded projection.
+                if (n < 2 * (p.N / 3)) {
+                    const int64_t t = m % p.rope_T;
+                    const int dd = (int)(n % p.rope_hs);
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + t * (p.rope_hs / 2) + dd / 2);
+                    const f32x4 sn = *reinterpret_cast<const f32x4*>(p.rope_sin + t * (p.rope_hs / 2) + dd / 2);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xe = bf2f(v[2 * j]), xo = bf2f(v[2 * j + 1]);
+                        v[2 * j] = f2bf(xe * c[j] - xo * sn[j]);
+                        v[2 * j + 1] = f2bf(xe * sn[j] + xo * c[j]);
+                    }
+                }
             } else if (EPI == OBTE_EPI_ADD_DROPOUT) {
                 const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.aux + o);
 #pragma unroll
@@ -213,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             } else if (EPI == OBTE_EPI_GELU_BWD) {
                 const bf16x8 h = *reinterpret_cast<const bf16x8*>(p.aux + o);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * gelu_ref_grad(bf2f(h[j])));
+                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * bf2f(h[j]));
             }
             *reinterpret_cast<bf16x8*>(p.d + o) = v;
         }
@@ -240,6 +263,7 @@ int dispatch_epi(const GemmParams& p, int epi, hipStream_t st) {
         case OBTE_EPI_ADD: return launch<AK, BK, OBTE_EPI_ADD>(p, st);
         case OBTE_EPI_GELU_BWD: return launch<AK, BK, OBTE_EPI_GELU_BWD>(p, st);
         case OBTE_EPI_ADD_DROPOUT: return launch<AK, BK, OBTE_EPI_ADD_DROPOUT>(p, st);
+        case OBTE_EPI_ROPE_QK: return launch<AK, BK, OBTE_EPI_ROPE_QK>(p, st);
     }
     obte_set_error("obte_gemm_bf16: unknown epilogue %d", epi);
     return OBTE_EINVAL;
@@ -262,6 +286,10 @@ int obte_gemm_bf16_v1(const obte_gemm_args* g, obte_stream s) {
     OBTE_REQUIRE(g->lda <= 1 << 20 && g->ldb <= 1 << 20, "obte_gemm_bf16: leading dimension too large");
     if (g->epilogue == OBTE_EPI_ADD || g->epilogue == OBTE_EPI_GELU_BWD || g->epilogue == OBTE_EPI_ADD_DROPOUT) OBTE_REQUIRE(g->aux, "obte_gemm_bf16: epilogue needs aux");
     if (g->epilogue == OBTE_EPI_ADD_DROPOUT) OBTE_REQUIRE(g->dropout_p >= 0.f && g->dropout_p < 1.f, "obte_gemm_bf16: dropout p must be in [0,1)");
+    if (g->epilogue == OBTE_EPI_ROPE_QK)
+        OBTE_REQUIRE(g->rope_cos && g->rope_sin && g->rope_T > 0 && g->rope_head_dim > 0 && g->rope_head_dim % 8 == 0 && g->N % 3 == 0 &&
+                         (g->N / 3) % g->rope_head_dim == 0,
+                     "obte_gemm_bf16: EPI_ROPE_QK needs cos/sin tables, T, head_dim %% 8 == 0 and N = 3 * n_head * head_dim");
     if (g->epilogue == OBTE_EPI_GELU) OBTE_REQUIRE(g->d2, "obte_gemm_bf16: GELU epilogue needs d2");
     if (g->epilogue != OBTE_EPI_NONE && g->epilogue != OBTE_EPI_ADD) OBTE_REQUIRE(g->alpha == 1.0f, "obte_gemm_bf16: alpha != 1 only with EPI_NONE / EPI_ADD");
     GemmParams p;
@@ -273,6 +301,7 @@ int obte_gemm_bf16_v1(const obte_gemm_args* g, obte_stream s) {
     OBTE_REQUIRE(tm * tn < (1ll << 30), "obte_gemm_bf16: too many tiles");
     p.tiles_m = (int)tm; p.tiles_n = (int)tn;
     p.alpha = g->alpha;
+    p.rope_cos = g->rope_cos; p.rope_sin = g->rope_sin; p.rope_T = g->rope_T; p.rope_hs = g->rope_head_dim;
     p.drop = make_drop(g->epilogue == OBTE_EPI_ADD_DROPOUT ? g->dropout_p : 0.f, g->dropout_seed, (uint32_t)g->dropout_site);
     hipStream_t st = (hipStream_t)s;
     if (g->a_kmajor && g->b_kmajor) return dispatch_epi<true, true>(p, g->epilogue, st);

@@ -67,7 +67,8 @@ def layernorm_bwd(dy, x, w, mean, rstd, dresid=None):
 
 
 # --------------------------------------------------------------------------------------------------------- GEMM
-def gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True, epilogue=L.EPI_NONE, aux=None, alpha=1.0, out=None, dropout=None):
+def gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True, epilogue=L.EPI_NONE, aux=None, alpha=1.0, out=None, dropout=None,
+         rope=None):
     """D[M,N] = epilogue(alpha * sum_k A(m,k) B(n,k)); see include/omnibiote_hip.h.  Returns d, or (d, d2) for
     the GELU epilogue."""
     _need(a, "a"); _need(b, "b")
@@ -85,6 +86,11 @@ def gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True, epilogue=L.EPI_NONE, aux=N
     dp, dseed, dsite = dropout if dropout is not None else (0.0, 0, 0)   # (p, seed, site) for EPI_ADD_DROPOUT
     g = L.GemmArgs(_ptr(a), _ptr(b), _ptr(d), _ptr(aux), _ptr(d2), M, N, K, lda, ldb, N,
                    int(a_kmajor), int(b_kmajor), epilogue, float(alpha), float(dp), int(dsite), int(dseed))
+    if epilogue == L.EPI_ROPE_QK:   # rope = (cos, sin, T, head_dim)
+        cos, sin, rT, rhs = rope
+        _need(cos, "cos", torch.float32); _need(sin, "sin", torch.float32)
+        assert cos.shape[0] >= rT and cos.shape[-1] == rhs // 2
+        g.rope_cos, g.rope_sin, g.rope_T, g.rope_head_dim = _ptr(cos), _ptr(sin), rT, rhs
     ws_bytes = int(L.lib().obte_gemm_workspace_bytes(M, N, K)) if (epilogue in (L.EPI_NONE, L.EPI_ADD) and M * N <= (1 << 23)) else 0
     if ws_bytes > 0:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
