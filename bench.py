@@ -50,6 +50,8 @@ def parse():
     p.add_argument("--rows_per_rank", type=int, default=128, help="rows per rank per optimizer step (batch_size / world)")
     p.add_argument("--mini_batch_size", type=int, default=8)
     p.add_argument("--multi_document", action="store_true", help="rows with interior EOS (block-diagonal masks)")
+    p.add_argument("--masked_lm_head", action="store_true",
+                   help="readout + CE on the MLM-masked rows only (SURVEY §8f rank 1; same loss/gradients, not the headline)")
     p.add_argument("--dropout", type=float, default=0.0, help="0.0 = the parity regime (default); 0.1 = the reference's default")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
@@ -175,7 +177,8 @@ def main():
     model = TE.wrap_ddp(m, local) if (world > 1 or force_ddp) else m
     total_iters = 1000
     opt, sched = TE.build_optimizer(m, h, total_iters)
-    step = TE.TrainStep(model, opt, sched, mini_batch_size=a.mini_batch_size, n_head=cfg["n_head"])
+    step = TE.TrainStep(model, opt, sched, mini_batch_size=a.mini_batch_size, n_head=cfg["n_head"],
+                        lm_head_impl="masked" if a.masked_lm_head else "dense")
     rng = np.random.default_rng(1234 + rank)
     T = cfg["ctx_len"]
     # synthetic batches resident in HBM before timing; a fresh one per step
@@ -234,7 +237,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"OmniBioTA {a.config} ({cfg['n_layer']}L/{cfg['n_embd']}d/{cfg['n_head']}h) ctx={T} MLM train step: "
                                    f"{a.rows_per_rank} rows/rank = {a.rows_per_rank // a.mini_batch_size} micro-batches of {a.mini_batch_size}, "
-                                   f"full 65536-way logits, dropout {a.dropout:g}, {'multi' if a.multi_document else 'single'}-document rows",
+                                   f"{'masked-rows-only' if a.masked_lm_head else 'full'} 65536-way logits, dropout {a.dropout:g}, {'multi' if a.multi_document else 'single'}-document rows",
                        "global_batch_rows": a.rows_per_rank * world, "mini_batch_size": a.mini_batch_size, "seq_len": T,
                        "parallelism": f"dp{world}", "dropout": a.dropout, "vocab": 65536},
             "flops_per_token": fpt,

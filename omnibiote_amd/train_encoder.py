@@ -143,12 +143,18 @@ class TrainStep:
 
     def __init__(self, model, optimizer, scheduler=None, *, mini_batch_size: int, n_head: int, use_padding: bool = False,
                  loss_impl: str = "fused", mask_impl: str = "ranges", sync_every_micro_step: bool = False,
-                 max_grad_norm: float = 1.0):
+                 max_grad_norm: float = 1.0, lm_head_impl: str = "dense"):
         self.model, self.optimizer, self.scheduler = model, optimizer, scheduler
         self.mini, self.n_head, self.use_padding = mini_batch_size, n_head, use_padding
         self.loss_impl, self.mask_impl = loss_impl, mask_impl
         self.sync_every = sync_every_micro_step
         self.max_grad_norm = max_grad_norm
+        # "dense": logits for every position, as the reference computes them (train_encoder.py:296).
+        # "masked" (SURVEY.md §8f rank 1): the loss only looks at the ~15 % MLM-masked positions (loss *= mask, :304), so
+        # the readout and the cross entropy run on those rows alone — the same loss and gradients (rows outside the mask
+        # contribute exact zeros) for 1/6.7 of the lm_head work and none of the 1 GiB logits tensors.
+        assert lm_head_impl in ("dense", "masked")
+        self.lm_head_impl = lm_head_impl
 
     def _inplace(self, enabled: bool):
         if self.loss_impl != "fused" or os.environ.get("OBTE_NO_INPLACE_ACCUM") == "1":   # CPU-oracle tests / A-B switch
@@ -177,15 +183,37 @@ class TrainStep:
         loss.backward()
         return loss.detach().float()
 
+    def _masked_rows_loss_backward(self, x, y, mk, attn_mask, n_accum):
+        """Readout + CE on the masked rows only.  The row indices come from the host-side MLM draw (no device sync)."""
+        from . import ops
+        emb = self.model(x, attn_mask=attn_mask, return_embeddings=True)
+        rows = self._mask_rows_host[self._mb]            # int64 tensor on the device, built from the NumPy draw
+        if rows.numel() == 0:
+            (emb.sum() * 0).backward()
+            return torch.zeros((), dtype=torch.float32, device=x.device)
+        emb_rows = emb.reshape(-1, emb.shape[-1]).index_select(0, rows)
+        core = self.model.module if hasattr(self.model, "module") else self.model
+        logits = core.lm_head(emb_rows)
+        ones = torch.ones(rows.numel(), dtype=torch.bool, device=x.device)
+        loss, dlogits = ops.masked_ce(logits, y.reshape(-1).index_select(0, rows), ones, n_accum)
+        logits.backward(dlogits)
+        return loss.detach()
+
     def __call__(self, input_ids: torch.Tensor) -> Dict[str, torch.Tensor]:
         rows = input_ids.shape[0] // self.mini * self.mini
         input_ids = input_ids[:rows]
         n_accum = rows // self.mini
         self.optimizer.zero_grad(set_to_none=True)
         masked_ids, mask = mlm_corrupt(input_ids)
+        if self.lm_head_impl == "masked":
+            # per-micro-batch row indices of the masked positions; mlm_corrupt drew the mask on the host, but PAD/EOS
+            # exclusions were applied on the device, so fetch the final mask once per optimizer step (one small D2H copy)
+            mh = mask.reshape(rows // self.mini, -1).cpu()
+            self._mask_rows_host = [torch.nonzero(mh[j], as_tuple=False).reshape(-1).to(input_ids.device) for j in range(mh.shape[0])]
         dtype = next(self.model.parameters()).dtype
         cum_loss = torch.zeros((), dtype=torch.float32, device=input_ids.device)
         for j in range(n_accum):
+            self._mb = j
             x = masked_ids[j * self.mini:(j + 1) * self.mini]
             y = input_ids[j * self.mini:(j + 1) * self.mini]
             attn_mask = self._mask(y, dtype)
@@ -196,8 +224,12 @@ class TrainStep:
             # all but the last micro-batch: nobody observes the per-micro-batch gradients, so the big matrices are
             # accumulated by the wgrad epilogues themselves (model.accumulate_grads_inplace)
             with ctx, self._inplace(not last and not self.sync_every):
-                logits = self.model(x, attn_mask=attn_mask)
-                cum_loss += self._loss_backward(logits, y, mask[j * self.mini:(j + 1) * self.mini], n_accum)
+                mk = mask[j * self.mini:(j + 1) * self.mini]
+                if self.lm_head_impl == "masked":
+                    cum_loss += self._masked_rows_loss_backward(x, y, mk, attn_mask, n_accum)
+                else:
+                    logits = self.model(x, attn_mask=attn_mask)
+                    cum_loss += self._loss_backward(logits, y, mk, n_accum)
         if isinstance(self.optimizer, FusedAdamW):
             self.optimizer.step(max_norm=self.max_grad_norm)
         else:

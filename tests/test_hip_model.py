@@ -271,3 +271,39 @@ def test_inplace_gradient_accumulation_is_bitwise_autograd_accumulation(golden_d
         results.append({k: p.grad.clone() for k, p in m.named_parameters()})
     for k in results[0]:
         assert torch.equal(results[0][k], results[1][k]), k
+
+
+def test_masked_rows_lm_head_gives_the_dense_loss_and_gradients():
+    """readout + CE on the MLM-masked rows only must reproduce the dense path's loss and gradients
+    (rows outside the mask contribute exact zeros there)."""
+    from omnibiote_amd import train_encoder as TE
+    from omnibiote_amd.mup_compat import set_base_shapes
+    from omnibiote_amd.model import OmniBioTA, OmniBioTAConfig
+    C, H, Lyr, V, T, rows, mini = 128, 2, 2, 512, 64, 8, 4
+    w = R.hash_weights(R.RefConfig(block_size=T, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C))
+    ids = torch.from_numpy(TE.synthetic_rows(rows, T, V, np.random.default_rng(0), single_document=False)).to(DEV)
+    out = {}
+    for impl in ("dense", "masked"):
+        c = OmniBioTAConfig(); c.block_size, c.vocab_size, c.n_layer, c.n_head, c.n_embd, c.dropout, c.flash = T, V, Lyr, H, C, 0.0, True
+        m = OmniBioTA(c)
+        cb = OmniBioTAConfig(); cb.block_size, cb.vocab_size, cb.n_layer, cb.dropout, cb.flash = T, V, Lyr, 0.0, True
+        cb.n_embd, cb.n_head = 24, 3
+        base = OmniBioTA(cb)
+        cb.n_embd, cb.n_head = 48, 12
+        delta = OmniBioTA(cb)
+        set_base_shapes(m, base, delta=delta, rescale_params=False)
+        m.load_state_dict(w, strict=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.to(BF)
+        m.to(DEV)
+        opt = torch.optim.SGD(m.parameters(), lr=0.0)
+        step = TE.TrainStep(m, opt, None, mini_batch_size=mini, n_head=H, lm_head_impl=impl, max_grad_norm=1e9)
+        np.random.seed(5)
+        loss = step(ids)["loss"].item()
+        out[impl] = (loss, {k: p.grad.float().clone() for k, p in m.named_parameters()})
+    assert abs(out["dense"][0] - out["masked"][0]) <= 1e-3 * abs(out["dense"][0])
+    for k in out["dense"][1]:
+        a, b = out["dense"][1][k].flatten(), out["masked"][1][k].flatten()
+        rel = (a - b).norm().item() / (a.norm().item() + 1e-12)
+        assert rel <= 0.02, (k, rel)
