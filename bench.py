@@ -70,8 +70,9 @@ def harness_args(cfg, a, world):
     return h
 
 
-KIND_NAMES = {12: "gemm_fwd(NT)", 13: "gemm_fwd(NT)+gelu", 14: "gemm_fwd(NT)+residual", 8: "gemm_dgrad(NN)",
-              11: "gemm_dgrad(NN)+gelu_bwd", 0: "gemm_wgrad(TN)", 100: "attn_fwd", 101: "attn_bwd"}
+KIND_NAMES = {12: "gemm_fwd(NT)", 13: "gemm_fwd(NT)+gelu", 14: "gemm_fwd(NT)+residual", 16: "gemm_fwd(NT)+residual+dropout",
+              17: "gemm_fwd(NT)+rope", 8: "gemm_dgrad(NN)", 11: "gemm_dgrad(NN)+gelu_bwd", 0: "gemm_wgrad(TN)",
+              2: "gemm_wgrad(TN)+accumulate", 100: "attn_fwd", 101: "attn_bwd"}
 
 
 def collect_profile(cap=200000):
