@@ -307,3 +307,34 @@ def test_masked_rows_lm_head_gives_the_dense_loss_and_gradients():
         a, b = out["dense"][1][k].flatten(), out["masked"][1][k].flatten()
         rel = (a - b).norm().item() / (a.norm().item() + 1e-12)
         assert rel <= 0.02, (k, rel)
+
+
+def test_eval_style_usage_with_padding_mask_and_odd_length(golden_dir):
+    """How the eval scripts call the model (evals/gue.py:15-21,111): a dense additive mask in which everything at and
+    after the first PAD is -1e9 in both directions (so whole rows are masked), odd sequence length, CLS pooling,
+    eval mode, no_grad."""
+    g = load(golden_dir, "wide_fp32_mask")
+    cfg = R.RefConfig(*[int(v) for v in g["cfg"][:5]])
+    m = build(g, "cos_only").eval()
+    B, T, H = 3, 51, cfg.n_head
+    rng = np.random.default_rng(2)
+    x = rng.integers(20, cfg.vocab_size, size=(B, T))
+    pad_from = [T, 30, 7]
+    mask = torch.zeros(B, T, T)
+    for b, p in enumerate(pad_from):
+        x[b, p:] = R.PAD_TOKEN
+        mask[b, p + 1:, :] = -1e9
+        mask[b, :, p + 1:] = -1e9
+    x = torch.from_numpy(x)
+    with torch.no_grad():
+        out = m(x.to(DEV), attn_mask=mask.to(BF).to(DEV).unsqueeze(1).expand(-1, H, -1, -1), return_embeddings=True)
+    w = {k: v.to(BF).float() for k, v in R.hash_weights(cfg).items()}
+    rope = R.cast_rope_table(R.rope_table(cfg.n_embd // cfg.n_head, cfg.block_size), BF)
+    ref = R.model_forward(w, cfg, x, mask.to(BF).float().unsqueeze(1), return_embeddings=True, rope=rope)
+    # CLS embedding (what the evals consume) and every un-padded position
+    mx, mean = stats(out[:, 0], ref[:, 0].numpy())
+    assert mx <= 0.10 and mean <= 6e-3, (mx, mean)
+    for b, p in enumerate(pad_from):
+        mx, mean = stats(out[b, :min(p + 1, T)], ref[b, :min(p + 1, T)].numpy())
+        assert mx <= 0.12 and mean <= 6e-3, (b, mx, mean)
+    assert torch.isfinite(out.float()).all()
