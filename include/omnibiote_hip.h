@@ -179,6 +179,13 @@ int obte_masked_ce_fwd_bwd(const obte_bf16* logits, const int64_t* target, const
                            const float* grad_scale, float row_scale, float* loss_sum, float* row_loss,
                            obte_bf16* dlogits, int64_t rows, int64_t vocab, obte_stream s);
 
+/* Same, for a dlogits buffer that is reused across calls: prev_mask (nullable) is the mlm_mask of the previous call that
+ * wrote this buffer; with prev_mask = NULL every row is written (use that for the first call on a fresh buffer).  Rows
+ * unmasked both then and now are left untouched: they already hold zeros. */
+int obte_masked_ce_fwd_bwd_reuse(const obte_bf16* logits, const int64_t* target, const uint8_t* mlm_mask,
+                                 const uint8_t* prev_mask, const float* grad_scale, float row_scale, float* row_loss,
+                                 obte_bf16* dlogits, int64_t rows, int64_t vocab, obte_stream s);
+
 /* ---- fused AdamW step, bf16 params/grads/moments as the reference trains (train_encoder.py:170,199,316-317) ---
  * One launch per tensor: p -= lr*(m_hat/(sqrt(v_hat)+eps) + wd*p), grads pre-multiplied by clip_coef[0]
  * (device fp32, 1.0 if no clipping).  step is 1-based.  */

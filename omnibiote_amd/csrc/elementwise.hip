@@ -177,18 +177,21 @@ __global__ __launch_bounds__(128) void embed_bwd_span_kernel(const int64_t* __re
 // Rows outside the MLM mask contribute exactly zero loss and zero gradient in the reference (loss *= mask),
 // so their logits are not read; their dlogits row is written as zeros.
 // ---------------------------------------------------------------------------------------------------------
+// prev_mask (nullable): the MLM mask of the previous call on the SAME dlogits buffer.  Rows that were not masked then and
+// are not masked now already hold zeros and are not touched at all, which removes ~85 % of the gradient write.
 __global__ __launch_bounds__(256) void masked_ce_kernel(const bf16* __restrict__ logits, const int64_t* __restrict__ target,
-                                                         const uint8_t* __restrict__ mlm_mask, const float* __restrict__ grad_scale,
-                                                         float row_scale, float* __restrict__ row_loss, bf16* __restrict__ dlogits,
-                                                         int64_t vocab) {
+                                                         const uint8_t* __restrict__ mlm_mask, const uint8_t* __restrict__ prev_mask,
+                                                         const float* __restrict__ grad_scale, float row_scale,
+                                                         float* __restrict__ row_loss, bf16* __restrict__ dlogits, int64_t vocab) {
     __shared__ float red[8];
     const int64_t r = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bf16* drow = dlogits + r * vocab;
     if (!mlm_mask[r]) {
+        if (threadIdx.x == 0 && row_loss) row_loss[r] = 0.f;
+        if (prev_mask && !prev_mask[r]) return;   // still zero from before
         const bf16x8 z = {};
         for (int64_t c = (int64_t)threadIdx.x * 8; c < vocab; c += 256 * 8) *reinterpret_cast<bf16x8*>(drow + c) = z;
-        if (threadIdx.x == 0 && row_loss) row_loss[r] = 0.f;
         return;
     }
     const bf16* lrow = logits + r * vocab;
@@ -443,16 +446,22 @@ extern "C" int obte_embedding_bwd(const int64_t* idx, const int32_t* order, cons
     return obte_embedding_bwd_dropout(idx, order, dout, dwte, ws, rows, cols, vocab, 0, 0.f, 0, s);
 }
 
+extern "C" int obte_masked_ce_fwd_bwd_reuse(const obte_bf16* logits, const int64_t* target, const uint8_t* mlm_mask,
+                                            const uint8_t* prev_mask, const float* grad_scale, float row_scale, float* row_loss,
+                                            obte_bf16* dlogits, int64_t rows, int64_t vocab, obte_stream s) {
+    OBTE_REQUIRE(logits && target && mlm_mask && grad_scale && dlogits, "obte_masked_ce_fwd_bwd: null pointer");
+    OBTE_REQUIRE(rows > 0 && rows < (1ll << 31) && vocab > 0 && vocab % 8 == 0, "obte_masked_ce_fwd_bwd: vocab must be a multiple of 8");
+    hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)s, (const bf16*)logits, target, mlm_mask,
+                       prev_mask, grad_scale, row_scale, row_loss, (bf16*)dlogits, vocab);
+    OBTE_CHECK_LAUNCH("obte_masked_ce_fwd_bwd");
+    return OBTE_OK;
+}
+
 extern "C" int obte_masked_ce_fwd_bwd(const obte_bf16* logits, const int64_t* target, const uint8_t* mlm_mask,
                                       const float* grad_scale, float row_scale, float* loss_sum, float* row_loss,
                                       obte_bf16* dlogits, int64_t rows, int64_t vocab, obte_stream s) {
     (void)loss_sum;
-    OBTE_REQUIRE(logits && target && mlm_mask && grad_scale && dlogits, "obte_masked_ce_fwd_bwd: null pointer");
-    OBTE_REQUIRE(rows > 0 && rows < (1ll << 31) && vocab > 0 && vocab % 8 == 0, "obte_masked_ce_fwd_bwd: vocab must be a multiple of 8");
-    hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)s, (const bf16*)logits, target, mlm_mask,
-                       grad_scale, row_scale, row_loss, (bf16*)dlogits, vocab);
-    OBTE_CHECK_LAUNCH("obte_masked_ce_fwd_bwd");
-    return OBTE_OK;
+    return obte_masked_ce_fwd_bwd_reuse(logits, target, mlm_mask, nullptr, grad_scale, row_scale, row_loss, dlogits, rows, vocab, s);
 }
 
 extern "C" int obte_adamw_bf16(obte_bf16* p, const obte_bf16* g, obte_bf16* m, obte_bf16* v, int64_t n, float lr,

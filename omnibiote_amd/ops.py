@@ -247,7 +247,24 @@ def embedding_bwd(idx, dout, vocab, accumulate_into=None, dropout_p=0.0, dropout
 
 
 # ---------------------------------------------------------------------------------------------- loss, optimizer
-def masked_ce(logits, targets, mlm_mask, n_accum: int):
+class DLogitsBuffer:
+    """A gradient buffer reused across micro-batches by ``masked_ce``: only the rows whose masked-ness changed since
+    the previous call are written (the other ~85 % already hold zeros).  The caller must be done with the previous
+    contents (i.e. have run the backward that consumes them) before the next ``masked_ce`` on the same buffer — true for
+    a training loop, where forward/loss/backward of one micro-batch are enqueued before the next begins."""
+
+    def __init__(self):
+        self.buf = None
+        self.prev_mask = None
+
+    def get(self, like: torch.Tensor):
+        if self.buf is None or self.buf.shape != like.shape or self.buf.device != like.device:
+            self.buf = torch.empty_like(like)
+            self.prev_mask = None      # fresh memory: the next call writes every row
+        return self.buf
+
+
+def masked_ce(logits, targets, mlm_mask, n_accum: int, reuse: Optional[DLogitsBuffer] = None):
     """Returns (loss scalar fp32 tensor, dlogits bf16) with the reference's micro-batch normalisation
     (train_encoder.py:301-305): loss = sum_masked(CE)/n_accum / count."""
     _need(logits, "logits"); _need(targets, "targets", torch.int64)
@@ -257,9 +274,14 @@ def masked_ce(logits, targets, mlm_mask, n_accum: int):
     m8 = mlm_mask.reshape(-1).to(torch.uint8).contiguous()
     inv_count = (1.0 / m8.sum(dtype=torch.float32)).reshape(1)
     row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
-    dlogits = torch.empty_like(logits)
-    L.check(L.lib().obte_masked_ce_fwd_bwd(_ptr(logits), _ptr(targets), _ptr(m8), _ptr(inv_count), 1.0 / n_accum, None,
-                                            _ptr(row_loss), _ptr(dlogits), rows, V, _stream()), "obte_masked_ce_fwd_bwd")
+    if reuse is None:
+        dlogits, prev = torch.empty_like(logits), None
+    else:
+        dlogits, prev = reuse.get(logits), reuse.prev_mask
+    L.check(L.lib().obte_masked_ce_fwd_bwd_reuse(_ptr(logits), _ptr(targets), _ptr(m8), _ptr(prev), _ptr(inv_count), 1.0 / n_accum,
+                                                  _ptr(row_loss), _ptr(dlogits), rows, V, _stream()), "obte_masked_ce_fwd_bwd")
+    if reuse is not None:
+        reuse.prev_mask = m8
     loss = row_loss.sum() * inv_count[0]
     return loss, dlogits
 

@@ -155,6 +155,7 @@ class TrainStep:
         # contribute exact zeros) for 1/6.7 of the lm_head work and none of the 1 GiB logits tensors.
         assert lm_head_impl in ("dense", "masked")
         self.lm_head_impl = lm_head_impl
+        self._dlogits = None
 
     def _inplace(self, enabled: bool):
         if self.loss_impl != "fused" or os.environ.get("OBTE_NO_INPLACE_ACCUM") == "1":   # CPU-oracle tests / A-B switch
@@ -173,7 +174,9 @@ class TrainStep:
     def _loss_backward(self, logits, targets, mask, n_accum):
         if self.loss_impl == "fused":
             from . import ops
-            loss, dlogits = ops.masked_ce(logits, targets, mask, n_accum)
+            if self._dlogits is None:
+                self._dlogits = ops.DLogitsBuffer()
+            loss, dlogits = ops.masked_ce(logits, targets, mask, n_accum, reuse=self._dlogits)
             logits.backward(dlogits)
             return loss.detach()
         # the reference's own three lines (train_encoder.py:301-305)

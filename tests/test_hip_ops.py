@@ -626,3 +626,19 @@ def test_gemm_rope_epilogue_equals_projection_then_rope(hs, mode):
     plain = o.linear_fwd(x.to(DEV), w.to(DEV))
     o.rope_qk_(plain, cos, sin, B, T, H, hs)
     assert torch.equal(fused, plain)
+
+
+def test_masked_ce_reused_gradient_buffer():
+    """A dlogits buffer reused across calls: rows unmasked in consecutive calls are skipped, yet the buffer always equals
+    what a fresh full write would produce."""
+    rows, V = 96, 1024
+    o = ops()
+    buf = o.DLogitsBuffer()
+    for it in range(4):
+        logits = rnd(rows, V, seed=10 + it, scale=2.0).to(DEV)
+        tgt = torch.from_numpy(np.random.default_rng(it).integers(0, V, size=rows)).to(DEV)
+        mask = torch.from_numpy(np.random.default_rng(100 + it).random(rows) < 0.2).to(DEV)
+        mask[it] = True
+        loss_a, fresh = o.masked_ce(logits, tgt, mask, 2)
+        loss_b, reused = o.masked_ce(logits, tgt, mask, 2, reuse=buf)
+        assert torch.equal(fresh, reused) and loss_a.item() == loss_b.item()
