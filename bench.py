@@ -10,7 +10,8 @@ global-norm clip, MuAdamW-grouped AdamW, LinearLR — BASELINE.json configs[1] a
 HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects: ``roofline`` for the dominant kernel family (bf16 MFMA GEMM; per-launch durations from HIP events
-recorded on the launch stream by the library's opt-in profiler over the timed region itself), and, at N=1, ``cpu_baseline`` — the CPU oracle (oracle/omnibiote_ref.py, the reference's
+recorded on the launch stream by the library's opt-in profiler during a separate, untimed step so that ``value``
+is not perturbed), and, at N=1, ``cpu_baseline`` — the CPU oracle (oracle/omnibiote_ref.py, the reference's
 arithmetic restated in plain torch) timed on this host on a bounded sample of the same workload.
 """
 from __future__ import annotations
@@ -194,11 +195,6 @@ def main():
     for i in range(a.warmup):
         losses.append(step(batches[i % len(batches)])["loss"])
     sync()
-    # the library's launch profiler brackets every GEMM / attention launch of the timed region with HIP events on the
-    # launch stream (rank 0 only; measured cost: below run-to-run noise, the step is GPU-bound)
-    profile_live = not a.no_roofline and rank == 0
-    if profile_live:
-        _lib.lib().obte_profile_enable(1)
     t0 = time.perf_counter()
     for i in range(a.steps):
         losses.append(step(batches[(a.warmup + i) % len(batches)])["loss"])
@@ -213,11 +209,14 @@ def main():
     fpt = TE.flops_per_token(n_params, cfg["n_layer"], cfg["n_embd"], T)
 
     roofline = None
-    if profile_live:
+    if not a.no_roofline and rank == 0:
+        _lib.lib().obte_profile_enable(1)
+        step(batches[0])
+        torch.cuda.synchronize()
         ms, dims, kind = collect_profile()
         _lib.lib().obte_profile_enable(0)
         if len(ms):
-            roofline = roofline_from_profile(ms, dims, kind, a.steps)
+            roofline = roofline_from_profile(ms, dims, kind, 1)
             if a.shapes_out:
                 tab = {}
                 for t, d, k in zip(ms, dims, kind):
@@ -228,7 +227,7 @@ def main():
                     f.write(f"{'kernel':28s} {'d0':>7s} {'d1':>7s} {'d2':>7s} {'calls':>6s} {'avg_us':>9s} {'TFLOP/s':>8s} {'ms/step':>8s}\n")
                     for (name, d0, d1, d2), (n, tt) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
                         fl = 2.0 * d0 * d1 * d2 if not name.startswith("attn") else 4.0 * d0 * d1 * d1 * d2 * (1.0 if name == "attn_fwd" else 2.5)
-                        f.write(f"{name:28s} {d0:7d} {d1:7d} {d2:7d} {n // a.steps:6d} {tt / n * 1e3:9.1f} {fl * n / (tt * 1e-3) / 1e12:8.1f} {tt / a.steps:8.2f}\n")
+                        f.write(f"{name:28s} {d0:7d} {d1:7d} {d2:7d} {n:6d} {tt / n * 1e3:9.1f} {fl * n / (tt * 1e-3) / 1e12:8.1f} {tt:8.2f}\n")
     if world > 1:
         dist.barrier()
 
