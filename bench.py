@@ -10,8 +10,9 @@ global-norm clip, MuAdamW-grouped AdamW, LinearLR — BASELINE.json configs[1] a
 HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects: ``roofline`` for the dominant kernel family (bf16 MFMA GEMM; per-launch durations from HIP events
-recorded on the launch stream by the library's opt-in profiler during a separate, untimed step so that ``value``
-is not perturbed), and, at N=1, ``cpu_baseline`` — the CPU oracle (oracle/omnibiote_ref.py, the reference's
+recorded on the launch stream by the library's opt-in profiler during one extra step right after the timed region:
+bracketing every launch of the timed steps themselves with events was measured to cost 6 % of ``value`` — the events keep
+the tail of one kernel from overlapping the head of the next — so the timed region runs un-instrumented), and, at N=1, ``cpu_baseline`` — the CPU oracle (oracle/omnibiote_ref.py, the reference's
 arithmetic restated in plain torch) timed on this host on a bounded sample of the same workload.
 """
 from __future__ import annotations
