@@ -21,8 +21,12 @@ Changed on purpose (same mathematics, MI355X-first mechanics):
   * loss: fused CE forward+backward kernel (one pass over the logits); the per-step scalars (loss, token count) are
     reduced with one small device all-reduce instead of two pickled gloo all_gather_object calls (:335,354);
   * clip + AdamW run as fused kernels without a host sync (the clip coefficient stays on the device).
-Data: synthetic token batches of the reference loader's output contract — the datasets and wandb are
-not available offline; ``--base_dir`` is accepted and ignored with a notice.
+Data: with ``--base_dir`` pointing at the reference's directory layout (``genbank/train``, ``uniref100/train`` ... of
+``.npy`` token shards, train_encoder.py:70-99) batches come from ``omnibiote_amd.loader`` (same packing and mixing as the
+reference loader, loader thread + bounded queue, pinned-memory copies on their own stream); otherwise from synthetic rows
+of the same contract.  Checkpoints follow the reference's convention (whole-object model pickle every
+``--save_freq`` tokens, previous one removed, train_encoder.py:412-423); optimizer and scheduler are saved as state_dicts.
+wandb logging is replaced by one line per step on rank 0.
 """
 from __future__ import annotations
 
@@ -357,13 +361,50 @@ def effective_batch(i: int, total_iters: int, args, batch_size: int) -> int:
     return e // mini * mini
 
 
+TRAIN_TYPES = {   # train_encoder.py:72-93
+    "protein": (["uniref100/train"], [1.0]),
+    "nucleotide": (["genbank/train"], [1.0]),
+    "mixed": (["genbank/train", "uniref100/train"], [0.80, 0.20]),
+    "halfnhalf": (["genbank/train", "uniref100/train"], [0.50, 0.50]),
+}
+
+
+def make_batch_source(args, batch_size: int, device, rng):
+    """A callable ``rows -> LongTensor (rows, ctx_len)`` on ``device``.  Real shards when --base_dir has them, else synthetic."""
+    if args.train_type not in TRAIN_TYPES:
+        raise ValueError("Invalid train_type. Must be one of 'protein', 'nucleotide', 'mixed', or 'halfnhalf'")
+    dirs, props = TRAIN_TYPES[args.train_type]
+    dirs = [os.path.join(args.base_dir, d) for d in dirs] if args.base_dir else []
+    if dirs and all(os.path.isdir(d) and os.listdir(d) for d in dirs):
+        import queue
+        import threading
+        from . import loader as LD
+        files = [sorted(os.path.join(d, f) for f in os.listdir(d)) for d in dirs]
+        readers = [LD.line_reader(f, banned_tokens=[args.banned_token]) for f in files]
+        gens = [LD.get_sequence(r, args.ctx_len, args.use_padding) for r in readers]
+        batches = LD.get_batch(gens, LD.batch_split(batch_size, props), return_pt=True)
+        q = queue.Queue(maxsize=2)                                   # train_encoder.py:140-142
+        threading.Thread(target=LD.data_loader_parallel, args=(q, batches, device), daemon=True).start()
+        pool = [q.get(block=True)]
+
+        def real(rows):
+            while sum(b.shape[0] for b in pool) < rows:              # the reference's grand_batch top-up (:258-261)
+                pool.append(q.get(block=True))
+            cat = torch.cat(pool, dim=0) if len(pool) > 1 else pool[0]
+            pool[:] = [cat[rows:]]
+            return cat[:rows]
+        return real, "shards under " + args.base_dir
+    if args.base_dir:
+        print(f"note: no token shards under {args.base_dir}; training on synthetic rows")
+
+    def synth(rows):
+        return torch.from_numpy(synthetic_rows(rows, args.ctx_len, 2 ** 16, rng, single_document=not args.multi_document)).to(device)
+    return synth, "synthetic rows"
+
+
 def run(args):
     if args.FSDP:
         raise NotImplementedError("--FSDP is outside this build's scope (the north star names DDP)")
-    if args.resume_from:
-        raise NotImplementedError("--resume_from is outside this round's scope")
-    if args.base_dir:
-        print("note: --base_dir ignored; this harness trains on synthetic token batches")
     dist.init_process_group("nccl")   # RCCL on ROCm
     rank, world = dist.get_rank(), dist.get_world_size()
     local = int(os.environ.get("LOCAL_RANK", rank % max(torch.cuda.device_count(), 1)))
@@ -374,6 +415,12 @@ def run(args):
     np.random.seed(1234 + rank)
     torch.manual_seed(1234)   # identical initial weights on every rank (DDP broadcasts rank 0's anyway)
     m = build_model(args, device)
+    if args.resume_from > 0:   # train_encoder.py:174-178
+        from .checkpoint import load_checkpoint
+        m = load_checkpoint(f"{args.save_name}_{args.resume_from}.pt", map_location=device)
+        m.to(torch.bfloat16).to(device)
+        print(f"Loaded model from {args.resume_from} token checkpoint")
+    torch.manual_seed(1234 + rank)   # per-rank dropout streams from here on
     n_params = m.get_num_params()
     from . import tune
     tune.tune_model_shapes(args.mini_batch_size * args.ctx_len, args.n_embd, 2 ** 16, device=device, verbose=(rank == 0))
@@ -382,13 +429,27 @@ def run(args):
     opt, sched = build_optimizer(m, args, total_iters)
     step = TrainStep(model, opt, sched, mini_batch_size=args.mini_batch_size, n_head=args.n_head, use_padding=args.use_padding)
     rng = np.random.default_rng(1234 + rank)
-    trained = 0
+    next_batch, source = make_batch_source(args, batch_size, device, rng)
+    if rank == 0:
+        print(f"data: {source}")
+    trained, last_save, start = 0, 0, 0
+    if args.resume_from > 0:   # train_encoder.py:210-223 (optimizer/scheduler as state_dicts, not whole objects)
+        trained = last_save = args.resume_from
+        start = int(total_iters * (trained / args.token_budget))
+        st = torch.load(f"{args.save_name}_optimizer_{args.resume_from}.pt", map_location=device, weights_only=False)
+        opt.load_state_dict(st["optimizer"]); sched.load_state_dict(st["scheduler"])
     fpt = flops_per_token(n_params, args.n_layer, args.n_embd, args.ctx_len)
-    n_steps = total_iters if args.max_steps <= 0 else min(total_iters, args.max_steps)
-    for i in range(n_steps):
+    n_steps = total_iters if args.max_steps <= 0 else min(total_iters, start + args.max_steps)
+
+    def save(tag):
+        from .checkpoint import save_checkpoint
+        save_checkpoint(model, f"{args.save_name}{tag}.pt")
+        torch.save({"optimizer": opt.state_dict(), "scheduler": sched.state_dict()}, f"{args.save_name}_optimizer{tag}.pt")
+
+    for i in range(start, n_steps):
         t0 = time.time()
         rows = effective_batch(i, total_iters, args, batch_size)
-        ids = torch.from_numpy(synthetic_rows(rows, args.ctx_len, 2 ** 16, rng, single_document=not args.multi_document)).to(device)
+        ids = next_batch(rows)
         out = step(ids)
         stats = torch.stack([out["loss"], out["tokens"].float()])
         if world > 1:
@@ -401,6 +462,15 @@ def run(args):
             lrs = [g["lr"] for g in opt.param_groups]
             print(f"step {i} loss {loss:.4f} lr {lrs[0]:.5f}|{lrs[-1]:.5f} tokens/s {toks / dt:,.0f} "
                   f"MFMA-frac {toks / dt * fpt / (2.5e15 * world) * 100:.1f}% trained {trained / 1e6:.2f}M", flush=True)
+            if trained - last_save > args.save_freq:   # train_encoder.py:412-423: keep only the newest
+                save(f"_{trained}")
+                if last_save > 0:
+                    for f in (f"{args.save_name}_{last_save}.pt", f"{args.save_name}_optimizer_{last_save}.pt"):
+                        if os.path.exists(f):
+                            os.remove(f)
+                last_save = trained
+    if rank == 0 and args.save_name:
+        save("")                                        # train_encoder.py:429-432
     dist.destroy_process_group()
 
 

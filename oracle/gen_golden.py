@@ -31,24 +31,34 @@ sys.path.insert(0, HERE)
 import omnibiote_ref as R  # noqa: E402
 
 
+class MuReadout(nn.Linear):
+    """In-process stand-in for mup.layer.MuReadout (restated; see the module docstring).  It presents itself as
+    ``mup.layer.MuReadout`` so that a pickled model names the class the way the real package would."""
+
+    def __init__(self, *a, readout_zero_init=False, output_mult=1.0, **kw):
+        self.output_mult = output_mult
+        super().__init__(*a, **kw)
+
+    def width_mult(self):
+        return self.in_features / R.MUP_BASE_WIDTH
+
+    def forward(self, x):
+        return super().forward(self.output_mult * x / self.width_mult())
+
+
+MuReadout.__module__ = "mup.layer"
+
+
 def _install_mup_standin():
     mup = types.ModuleType("mup")
-
-    class MuReadout(nn.Linear):
-        def __init__(self, *a, readout_zero_init=False, output_mult=1.0, **kw):
-            self.output_mult = output_mult
-            super().__init__(*a, **kw)
-
-        def width_mult(self):
-            return self.in_features / R.MUP_BASE_WIDTH
-
-        def forward(self, x):
-            return super().forward(self.output_mult * x / self.width_mult())
-
+    layer = types.ModuleType("mup.layer")
+    layer.MuReadout = MuReadout
+    mup.layer = layer
     mup.MuReadout = MuReadout
     mup.set_base_shapes = lambda *a, **k: None
     mup.MuAdamW = None
     sys.modules["mup"] = mup
+    sys.modules["mup.layer"] = layer
 
 
 def _import_reference():
@@ -218,6 +228,23 @@ def rope_case(ref_model):
     print("rope_gelu: ok")
 
 
+def checkpoint_case(ref_model):
+    """A checkpoint exactly as the reference trainer writes it (train_encoder.py:170,413): the whole model object, after
+    ``.to(bfloat16)``, pickled with torch.save.  Data produced BY the reference (class names inside the pickle point at its
+    ``model`` module and at ``mup``), used to test omnibiote_amd.checkpoint.load_checkpoint."""
+    cfg = R.RefConfig(block_size=64, vocab_size=64, n_layer=1, n_head=2, n_embd=128)
+    m = build_ref(ref_model, cfg, torch.bfloat16)
+    m.eval()
+    torch.save(m, os.path.join(OUT, "ref_checkpoint_bf16.pt"))
+    rng = np.random.default_rng(21)
+    tok = rng.integers(4, 64, size=(2, 40)).astype(np.int64)
+    with torch.no_grad():
+        emb = m(torch.from_numpy(tok), return_embeddings=True)
+    np.savez_compressed(os.path.join(OUT, "ref_checkpoint_io.npz"), tokens=tok, emb=emb.float().numpy(),
+                        cfg=np.array([64, 64, 1, 2, 128, 1], dtype=np.int64))
+    print("checkpoint: ok", os.path.getsize(os.path.join(OUT, "ref_checkpoint_bf16.pt")), "bytes")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -239,6 +266,7 @@ def main():
     mask_cases(ref_train)
     encode_case(ref_model)
     rope_case(ref_model)
+    checkpoint_case(ref_model)
 
 
 if __name__ == "__main__":
