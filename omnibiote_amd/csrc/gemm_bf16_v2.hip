@@ -106,111 +106,11 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, int mn0, int s, in
     }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPLIT, int BN>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
-    using CF = Cfg<BN>;
-    constexpr int NJ = CF::NJ, NPB = CF::NPB, STAGE_BYTES = CF::STAGE;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-
-    // ---- workgroup -> (tile, split): bijective XCD remap, then 8-row groups of tiles ------------------------
-    const int nwg = p.tiles_m * p.tiles_n * p.splits;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int split = wgid % p.splits;
-    const int tid_ = wgid / p.splits;
-    const int group_sz = 8 * p.tiles_n;
-    const int first_m = (tid_ / group_sz) * 8;
-    const int gsz = min(p.tiles_m - first_m, 8);
-    const int tm = first_m + (tid_ % group_sz) % gsz;
-    const int tn = (tid_ % group_sz) / gsz;
-    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-    constexpr int NW = BN / 2;   // wave tile width
-
-    int voff_a[4], voff_b[NPB];
-    dma_offsets<A_KMAJOR, BM, 4>(wave, lane, p.lda, voff_a);
-    dma_offsets<B_KMAJOR, BN, NPB>(wave, lane, p.ldb, voff_b);
-
-    const int wm = wave >> 1, wn = wave & 1;
-    f32x4 acc[NJ][4];
-#pragma unroll
-    for (int i = 0; i < NJ; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk_total = (int)((p.K + BKT - 1) / BKT);
-    const int kt0 = split * p.k_per_split;
-    const int nk = min(p.k_per_split, nk_total - kt0);
-
-    auto issue = [&](int t, int stage) {
-        const int64_t k0 = (int64_t)(kt0 + t) * BKT;
-        const int64_t ao = A_KMAJOR ? (m0 * p.lda + k0) : (k0 * p.lda + m0);
-        const int64_t bo = B_KMAJOR ? (n0 * p.ldb + k0) : (k0 * p.ldb + n0);
-        char* st = smem + stage * STAGE_BYTES;
-        dma_tile<4>(p.a + ao, p.a_elems - ao, voff_a, st, wave);
-        dma_tile<NPB>(p.b + bo, p.b_elems - bo, voff_b, st + A_TILE, wave);
-    };
-
-    // ---- main loop, software pipelined over half K-tiles -------------------------------------------------------
-    // Each K-tile (64) is two MFMA k-steps; fragments are double-buffered in registers (F0: k-step 0, F1: k-step 1).
-    //   step t:  [3-stage ring: issue DMA of tile t+2]  read F1(t) | MFMA F0(t) | wait tile t+1, barrier |
-    //            read F0(t+1)  [2-stage ring: issue DMA of tile t+2]  | MFMA F1(t)
-    // so every LDS fragment read and every DMA issue runs under 32 (or 16) MFMAs of the same wave, there is one
-    // barrier per K-tile, and the DMA waits are counted (3-stage: the six pieces of tile t+2 stay in flight).
-    // sched_barrier pins this order; left alone hipcc sinks each ds_read to just before its first use.
-    auto stage_of = [&](int t) { return CF::NSTAGE == 3 ? t % 3 : (t & 1); };
-    auto load_frags = [&](int t, int ks, bf16x8 (&af)[4], bf16x8 (&bfr)[NJ]) {
-        const char* ta = smem + stage_of(t) * STAGE_BYTES;
-        const char* tb = ta + A_TILE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KMAJOR, BM>(ta, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-        for (int i = 0; i < NJ; ++i) bfr[i] = load_frag<B_KMAJOR, BN>(tb, wn * (BN / 2) + i * 16, ks, lane);
-    };
-    auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[NJ]) {
-#pragma unroll
-        for (int ni = 0; ni < NJ; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-                // operands swapped: the accumulator holds C^T (row = n, col = m)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
-    };
-
-    bf16x8 a0[4], b0[NJ], a1[4], b1[NJ];
-    if (nk > 0) {
-        issue(0, 0);
-        if (nk > 1) issue(1, 1);
-        if (CF::NSTAGE == 3 && nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (CF::NSTAGE == 2 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NPB) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        load_frags(0, 0, a0, b0);
-    }
-    for (int t = 0; t + 1 < nk; ++t) {
-        if (CF::NSTAGE == 3 && t + 2 < nk) issue(t + 2, (t + 2) % 3);   // stage of tile t-1: free since the last barrier
-        load_frags(t, 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        // the builtin form (not inline asm) so that hipcc's own wait bookkeeping knows F1 has landed and does not
-        // make MFMA F1 wait behind the F0(t+1) reads issued below.  simm16: vmcnt[3:0], expcnt 7, lgkmcnt 0.
-        if (CF::NSTAGE == 3 && t + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0076);   // vmcnt(6) lgkmcnt(0)
-        else __builtin_amdgcn_s_waitcnt(0x0070);                                  // vmcnt(0) lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();   // tile t+1 landed for everyone; everyone holds tile t's fragments in registers
-        load_frags(t + 1, 0, a0, b0);
-        if (CF::NSTAGE == 2 && t + 2 < nk) issue(t + 2, t & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (nk > 0) {   // last K-tile: nothing left to fetch
-        load_frags(nk - 1, 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a0, b0);
-        mma(a1, b1);
-    }
+// Tile epilogue shared by both main-loop structures: stage the accumulators through LDS, apply EPI, write 16-B pieces.
+template <int EPI, bool SPLIT, int BN>
+__device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BN / 32][4], char* smem, int wave, int lane,
+                                              int64_t m0, int64_t n0, int wm, int wn, int split) {
+    constexpr int NJ = BN / 32, NW = BN / 2;
     __syncthreads();  // all fragment reads done (and no DMA outstanding): LDS becomes the epilogue staging area
 
     const int em = lane & 15, en = (lane >> 4) * 4;
@@ -313,6 +213,112 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
     }
 }
 
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPLIT, int BN>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
+    using CF = Cfg<BN>;
+    constexpr int NJ = CF::NJ, NPB = CF::NPB, STAGE_BYTES = CF::STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+
+    // ---- workgroup -> (tile, split): bijective XCD remap, then 8-row groups of tiles ------------------------
+    const int nwg = p.tiles_m * p.tiles_n * p.splits;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int split = wgid % p.splits;
+    const int tid_ = wgid / p.splits;
+    const int group_sz = 8 * p.tiles_n;
+    const int first_m = (tid_ / group_sz) * 8;
+    const int gsz = min(p.tiles_m - first_m, 8);
+    const int tm = first_m + (tid_ % group_sz) % gsz;
+    const int tn = (tid_ % group_sz) / gsz;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    int voff_a[4], voff_b[NPB];
+    dma_offsets<A_KMAJOR, BM, 4>(wave, lane, p.lda, voff_a);
+    dma_offsets<B_KMAJOR, BN, NPB>(wave, lane, p.ldb, voff_b);
+
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4 acc[NJ][4];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk_total = (int)((p.K + BKT - 1) / BKT);
+    const int kt0 = split * p.k_per_split;
+    const int nk = min(p.k_per_split, nk_total - kt0);
+
+    auto issue = [&](int t, int stage) {
+        const int64_t k0 = (int64_t)(kt0 + t) * BKT;
+        const int64_t ao = A_KMAJOR ? (m0 * p.lda + k0) : (k0 * p.lda + m0);
+        const int64_t bo = B_KMAJOR ? (n0 * p.ldb + k0) : (k0 * p.ldb + n0);
+        char* st = smem + stage * STAGE_BYTES;
+        dma_tile<4>(p.a + ao, p.a_elems - ao, voff_a, st, wave);
+        dma_tile<NPB>(p.b + bo, p.b_elems - bo, voff_b, st + A_TILE, wave);
+    };
+
+    // ---- main loop, software pipelined over half K-tiles -------------------------------------------------------
+    // Each K-tile (64) is two MFMA k-steps; fragments are double-buffered in registers (F0: k-step 0, F1: k-step 1).
+    //   step t:  [3-stage ring: issue DMA of tile t+2]  read F1(t) | MFMA F0(t) | wait tile t+1, barrier |
+    //            read F0(t+1)  [2-stage ring: issue DMA of tile t+2]  | MFMA F1(t)
+    // so every LDS fragment read and every DMA issue runs under 32 (or 16) MFMAs of the same wave, there is one
+    // barrier per K-tile, and the DMA waits are counted (3-stage: the six pieces of tile t+2 stay in flight).
+    // sched_barrier pins this order; left alone hipcc sinks each ds_read to just before its first use.
+    auto stage_of = [&](int t) { return CF::NSTAGE == 3 ? t % 3 : (t & 1); };
+    auto load_frags = [&](int t, int ks, bf16x8 (&af)[4], bf16x8 (&bfr)[NJ]) {
+        const char* ta = smem + stage_of(t) * STAGE_BYTES;
+        const char* tb = ta + A_TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KMAJOR, BM>(ta, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) bfr[i] = load_frag<B_KMAJOR, BN>(tb, wn * (BN / 2) + i * 16, ks, lane);
+    };
+    auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[NJ]) {
+#pragma unroll
+        for (int ni = 0; ni < NJ; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                // operands swapped: the accumulator holds C^T (row = n, col = m)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    };
+
+    bf16x8 a0[4], b0[NJ], a1[4], b1[NJ];
+    if (nk > 0) {
+        issue(0, 0);
+        if (nk > 1) issue(1, 1);
+        if (CF::NSTAGE == 3 && nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (CF::NSTAGE == 2 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NPB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags(0, 0, a0, b0);
+    }
+    for (int t = 0; t + 1 < nk; ++t) {
+        if (CF::NSTAGE == 3 && t + 2 < nk) issue(t + 2, (t + 2) % 3);   // stage of tile t-1: free since the last barrier
+        load_frags(t, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        // the builtin form (not inline asm) so that hipcc's own wait bookkeeping knows F1 has landed and does not
+        // make MFMA F1 wait behind the F0(t+1) reads issued below.  simm16: vmcnt[3:0], expcnt 7, lgkmcnt 0.
+        if (CF::NSTAGE == 3 && t + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0076);   // vmcnt(6) lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0x0070);                                  // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();   // tile t+1 landed for everyone; everyone holds tile t's fragments in registers
+        load_frags(t + 1, 0, a0, b0);
+        if (CF::NSTAGE == 2 && t + 2 < nk) issue(t + 2, t & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nk > 0) {   // last K-tile: nothing left to fetch
+        load_frags(nk - 1, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        mma(a1, b1);
+    }
+    tile_epilogue<EPI, SPLIT, BN>(p, acc, smem, wave, lane, m0, n0, wm, wn, split);
+}
+
 // Explicit instantiations: with implicit instantiation alone hipcc (ROCm 7.2) emitted the host stub of only the
 // first specialisation it met; the library then failed to load with undefined kernel symbols.
 #define OBTE_INST(AK, BK, BN)                                                                    \
@@ -332,6 +338,187 @@ OBTE_INST(true, false, 256)
 OBTE_INST(false, true, 256)
 OBTE_INST(false, false, 256)
 #undef OBTE_INST
+
+// ---- third structure: 256x256 tile, ring of FOUR half K-tiles (32 k each, 32 KiB), loads three half-steps ahead ----
+// The 2-stage ring above keeps at most one 64-KiB K-tile in flight per CU and each burst has to complete inside one
+// iteration; measured, an iteration then lasts as long as one burst's round trip (~2 us: every line of a tile is a
+// first touch for its L2, so each burst sees the beyond-L2 latency).  Splitting the ring into 32-k half-stages lets the
+// refill of a slot start as soon as ITS fragments are in registers: three half-stages (96 KiB) are in flight in
+// steady state and each has three half-steps (1.5 K-tiles of MFMA work) to land.  One barrier per half-step.
+//   step u:  wait half-stage u+1 (vmcnt(8): u+2, u+3 stay in flight) | barrier | read F(u+1) | issue u+4 -> slot u&3 |
+//            MFMA F(u)
+// k-contiguous half image: [256 rows][32 k], 64-B rows, chunk c of row r at c ^ ((4 - (r>>2)) & 3) (conflict-free
+// ds_read_b128 for the 16x32 fragment); k-strided half image: [32 k][256], as above.
+constexpr int H_TILE = BM * 32 * 2;             // 16 KiB per operand per half-stage
+constexpr int H_STAGE = 2 * H_TILE;             // 32 KiB
+constexpr int V3_RING = 4 * H_STAGE;            // 128 KiB
+constexpr int V3_SMEM = V3_RING > Cfg<256>::EPI_BYTES ? V3_RING : Cfg<256>::EPI_BYTES;
+
+__device__ __forceinline__ int kmaj32_off(int row, int chunk) { return row * 64 + ((chunk ^ ((4 - (row >> 2)) & 3)) << 4); }
+
+template <bool KMAJOR>
+__device__ __forceinline__ void dma_offsets_h(int wave, int lane, int64_t ld, int (&voff)[2]) {
+    if (KMAJOR) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave + 8 * i) * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((4 - (row >> 2)) & 3);
+            voff[i] = (int)((row * ld + chunk * 8) * 2);
+        }
+    } else {
+        dma_offsets<false, 256, 2>(wave, lane, ld, voff);   // 32 k-rows x 512 B = pieces 0..15
+    }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 load_frag_h(const char* tile, int mn0, int lane) {
+    if (KMAJOR) return *reinterpret_cast<const bf16x8*>(tile + kmaj32_off(mn0 + (lane & 15), lane >> 4));
+    return load_frag<false, 256>(tile, mn0, 0, lane);
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPLIT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
+    constexpr int BN = 256, NJ = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+
+    const int nwg = p.tiles_m * p.tiles_n * p.splits;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int split = wgid % p.splits;
+    const int tid_ = wgid / p.splits;
+    const int group_sz = 8 * p.tiles_n;
+    const int first_m = (tid_ / group_sz) * 8;
+    const int gsz = min(p.tiles_m - first_m, 8);
+    const int tm = first_m + (tid_ % group_sz) % gsz;
+    const int tn = (tid_ % group_sz) / gsz;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+
+    int voff_a[2], voff_b[2];
+    dma_offsets_h<A_KMAJOR>(wave, lane, p.lda, voff_a);
+    dma_offsets_h<B_KMAJOR>(wave, lane, p.ldb, voff_b);
+
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4 acc[NJ][4];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk_total = (int)((p.K + BKT - 1) / BKT);
+    const int kt0 = split * p.k_per_split;
+    const int nh = 2 * min(p.k_per_split, nk_total - kt0);   // half-steps; even, >= 4 (checked by the host)
+
+    auto issue = [&](int u) {
+        const int64_t k0 = (int64_t)kt0 * BKT + (int64_t)u * 32;
+        const int64_t ao = A_KMAJOR ? (m0 * p.lda + k0) : (k0 * p.lda + m0);
+        const int64_t bo = B_KMAJOR ? (n0 * p.ldb + k0) : (k0 * p.ldb + n0);
+        char* st = smem + (u & 3) * H_STAGE;
+        dma_tile<2>(p.a + ao, p.a_elems - ao, voff_a, st, wave);
+        dma_tile<2>(p.b + bo, p.b_elems - bo, voff_b, st + H_TILE, wave);
+    };
+    auto load_frags = [&](int u, bf16x8 (&af)[4], bf16x8 (&bfr)[NJ]) {
+        const char* ta = smem + (u & 3) * H_STAGE;
+        const char* tb = ta + H_TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = load_frag_h<A_KMAJOR>(ta, wm * 64 + i * 16, lane);
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) bfr[i] = load_frag_h<B_KMAJOR>(tb, wn * 128 + i * 16, lane);
+    };
+    auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[NJ]) {
+#pragma unroll
+        for (int ni = 0; ni < NJ; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    };
+
+    bf16x8 a0[4], b0[NJ], a1[4], b1[NJ];
+    issue(0); issue(1); issue(2); issue(3);
+    __builtin_amdgcn_s_waitcnt(0x007C);   // vmcnt(12): half-stage 0 landed
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, a0, b0);
+    int u = 0;
+    for (; u + 4 < nh; u += 2) {
+        __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0): half-stage u+1 landed, F(u) reads complete
+        __builtin_amdgcn_s_barrier();
+        load_frags(u + 1, a1, b1);
+        issue(u + 4);                         // slot u&3: every wave holds F(u) in registers since the barrier
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0078);
+        __builtin_amdgcn_s_barrier();
+        load_frags(u + 2, a0, b0);
+        issue(u + 5);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // last four half-steps (u == nh - 4): nothing left to issue, the waits count down
+    __builtin_amdgcn_s_waitcnt(0x0078);
+    __builtin_amdgcn_s_barrier();
+    load_frags(u + 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0074);       // vmcnt(4)
+    __builtin_amdgcn_s_barrier();
+    load_frags(u + 2, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0070);       // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    load_frags(u + 3, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0);
+    mma(a1, b1);
+    tile_epilogue<EPI, SPLIT, BN>(p, acc, smem, wave, lane, m0, n0, wm, wn, split);
+}
+
+#define OBTE_INST3(AK, BK)                                                                   \
+    template __global__ void gemm_v3_kernel<AK, BK, OBTE_EPI_NONE, true>(GemmParams);        \
+    template __global__ void gemm_v3_kernel<AK, BK, OBTE_EPI_NONE, false>(GemmParams);       \
+    template __global__ void gemm_v3_kernel<AK, BK, OBTE_EPI_GELU, false>(GemmParams);       \
+    template __global__ void gemm_v3_kernel<AK, BK, OBTE_EPI_ADD, false>(GemmParams);        \
+    template __global__ void gemm_v3_kernel<AK, BK, OBTE_EPI_GELU_BWD, false>(GemmParams);   \
+    template __global__ void gemm_v3_kernel<AK, BK, OBTE_EPI_ADD_DROPOUT, false>(GemmParams); \
+    template __global__ void gemm_v3_kernel<AK, BK, OBTE_EPI_ROPE_QK, false>(GemmParams);
+OBTE_INST3(true, true)
+OBTE_INST3(true, false)
+OBTE_INST3(false, true)
+OBTE_INST3(false, false)
+#undef OBTE_INST3
+
+template <bool AK, bool BK, int EPI, bool SPLIT>
+int launch3(const GemmParams& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_v3_kernel<AK, BK, EPI, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_SMEM);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_v3_kernel<AK, BK, EPI, SPLIT>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(NTHREADS), V3_SMEM, st, p);
+    OBTE_CHECK_LAUNCH("obte_gemm_bf16");
+    return OBTE_OK;
+}
+
+template <bool AK, bool BK>
+int dispatch3(const GemmParams& p, int epi, hipStream_t st) {
+    if (p.splits > 1) return launch3<AK, BK, OBTE_EPI_NONE, true>(p, st);
+    switch (epi) {
+        case OBTE_EPI_NONE: return launch3<AK, BK, OBTE_EPI_NONE, false>(p, st);
+        case OBTE_EPI_GELU: return launch3<AK, BK, OBTE_EPI_GELU, false>(p, st);
+        case OBTE_EPI_ADD: return launch3<AK, BK, OBTE_EPI_ADD, false>(p, st);
+        case OBTE_EPI_GELU_BWD: return launch3<AK, BK, OBTE_EPI_GELU_BWD, false>(p, st);
+        case OBTE_EPI_ADD_DROPOUT: return launch3<AK, BK, OBTE_EPI_ADD_DROPOUT, false>(p, st);
+        case OBTE_EPI_ROPE_QK: return launch3<AK, BK, OBTE_EPI_ROPE_QK, false>(p, st);
+    }
+    obte_set_error("obte_gemm_bf16: unknown epilogue %d", epi);
+    return OBTE_EINVAL;
+}
 
 // d[m][n] = bf16(alpha * sum_s slab[s][m][n]) in split order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, bf16* __restrict__ d, const bf16* aux,
@@ -395,13 +582,20 @@ bool use_v1() {
     return v == 1;
 }
 
+// OBTE_GEMM=v3 forces the four-half-stage structure wherever the plan is 256 wide (diagnostics / A-B timing)
+bool use_v3(int variant) {
+    if (variant == 3) return true;
+    const char* e = getenv("OBTE_GEMM");   // not cached: the tests flip it
+    return e && e[0] == 'v' && e[1] == '3';
+}
+
 }  // namespace obte_gemm_v2
 using namespace obte_gemm_v2;
 
 // Tile width and split-K plan.  Prefer the 256-wide tile (higher FLOP per loaded byte) whenever it still yields
 // at least one workgroup per CU, directly or through a split of a long K; otherwise the 128-wide tile.
 // Split-K needs a workspace, epilogue NONE and ldd == N.
-struct Plan { int bn; int splits; int variant; };   // variant: 1 = first structure (gemm_bf16_v1.hip), 2 = this file
+struct Plan { int bn; int splits; int variant; };   // variant: 1 = first structure (gemm_bf16_v1.hip), 2 / 3 = this file (K-tile ring / half-tile ring)
 static int splits_for(int64_t tiles, int64_t nk) {
     if (tiles >= 200 || nk < 16) return 1;
     int s = (int)((256 + tiles - 1) / tiles);
@@ -447,7 +641,8 @@ static bool lookup_plan(const obte_gemm_args* g, Plan* out) {
 
 extern "C" int obte_gemm_plan_set(int a_kmajor, int b_kmajor, int epilogue, int64_t M, int64_t N, int64_t K, int variant,
                                   int bn, int splits) {
-    OBTE_REQUIRE((variant == 1 || variant == 2) && (bn == 128 || bn == 256) && splits >= 1 && splits <= 64, "obte_gemm_plan_set: bad plan");
+    OBTE_REQUIRE(variant >= 1 && variant <= 3 && (bn == 128 || bn == 256) && splits >= 1 && splits <= 64, "obte_gemm_plan_set: bad plan");
+    OBTE_REQUIRE(!(variant == 3 && bn != 256), "obte_gemm_plan_set: the four-half-stage structure is 256 wide");
     OBTE_REQUIRE(!(variant == 1 && splits != 1), "obte_gemm_plan_set: the first structure has no split-K");
     std::lock_guard<std::mutex> lk(g_plan_mu);
     g_plans[PlanKey((a_kmajor ? 2 : 0) + (b_kmajor ? 1 : 0), epilogue, M, N, K)] = Plan{bn, splits, variant};
@@ -532,7 +727,13 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     p.alpha = g->alpha;
     p.rope_cos = g->rope_cos; p.rope_sin = g->rope_sin; p.rope_T = g->rope_T; p.rope_hs = g->rope_head_dim;
     p.drop = make_drop(g->epilogue == OBTE_EPI_ADD_DROPOUT ? g->dropout_p : 0.f, g->dropout_seed, (uint32_t)g->dropout_site);
-    if (g->a_kmajor && g->b_kmajor) rc = dispatch<true, true>(p, g->epilogue, pl.bn, st);
+    const bool v3 = use_v3(pl.variant) && pl.bn == 256 && p.k_per_split >= 2 && nk - (int64_t)(p.splits - 1) * p.k_per_split >= 2;
+    if (v3) {
+        if (g->a_kmajor && g->b_kmajor) rc = dispatch3<true, true>(p, g->epilogue, st);
+        else if (g->a_kmajor && !g->b_kmajor) rc = dispatch3<true, false>(p, g->epilogue, st);
+        else if (!g->a_kmajor && g->b_kmajor) rc = dispatch3<false, true>(p, g->epilogue, st);
+        else rc = dispatch3<false, false>(p, g->epilogue, st);
+    } else if (g->a_kmajor && g->b_kmajor) rc = dispatch<true, true>(p, g->epilogue, pl.bn, st);
     else if (g->a_kmajor && !g->b_kmajor) rc = dispatch<true, false>(p, g->epilogue, pl.bn, st);
     else if (!g->a_kmajor && g->b_kmajor) rc = dispatch<false, true>(p, g->epilogue, pl.bn, st);
     else rc = dispatch<false, false>(p, g->epilogue, pl.bn, st);

@@ -37,6 +37,8 @@ def candidates(M: int, N: int, K: int, epi: int) -> List[Tuple[int, int, int]]:
     c = [(1, 128, 1), (2, 128, 1)]
     if N >= 256:
         c.append((2, 256, 1))
+        if K >= 128:
+            c.append((3, 256, 1))
     nk = (K + 63) // 64
     if epi == L.EPI_NONE and M * N * 4 * 8 <= (1 << 28):   # split-K only for small outputs (weight gradients)
         for bn in (128, 256):
@@ -46,6 +48,8 @@ def candidates(M: int, N: int, K: int, epi: int) -> List[Tuple[int, int, int]]:
             for s in (2, 3, 4, 5, 6, 8):
                 if nk // s >= 8 and tiles * s <= 1024:
                     c.append((2, bn, s))
+                    if bn == 256:
+                        c.append((3, bn, s))
     return c
 
 

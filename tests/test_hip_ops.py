@@ -405,10 +405,18 @@ def test_gemm_linearity_full_size():
     close(y[rows], ref, atol=0.02, what="full-size rows")
 
 
-@pytest.mark.parametrize("bn", ["128", "256"])
+def _force_gemm(monkeypatch, bn):
+    """'128' / '256': tile width of the K-tile ring; '256h': the 256-wide half-tile ring (structure 3)."""
+    monkeypatch.setenv("OBTE_GEMM_BN", bn[:3])
+    if bn.endswith("h"):
+        monkeypatch.setenv("OBTE_GEMM", "v3")
+
+
+@pytest.mark.parametrize("bn", ["128", "256", "256h"])
 def test_gemm_both_tile_widths(monkeypatch, bn):
-    """Every layout, epilogue and the split-K path on both tile widths (the library picks per shape; here forced)."""
-    monkeypatch.setenv("OBTE_GEMM_BN", bn)
+    """Every layout, epilogue and the split-K path on both tile widths and both ring structures (the library picks
+    per shape; here forced)."""
+    _force_gemm(monkeypatch, bn)
     o = ops()
     for (M, N, K) in [(520, 392, 256), (256, 256, 128), (300, 1024, 1024)]:
         x, w = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=0.2)
@@ -519,9 +527,9 @@ def test_embedding_dropout_fwd_bwd():
     close(dw, ref, atol=3e-2, what="embedding bwd with dropout")
 
 
-@pytest.mark.parametrize("bn", ["128", "256"])
+@pytest.mark.parametrize("bn", ["128", "256", "256h"])
 def test_gemm_residual_dropout_epilogue(monkeypatch, bn):
-    monkeypatch.setenv("OBTE_GEMM_BN", bn)
+    _force_gemm(monkeypatch, bn)
     M, N, K, p = 300, 512, 128, 0.2
     x, w, r = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=0.2), rnd(M, N, seed=9)
     acc = (x.float() @ w.float().t()).to(BF)
