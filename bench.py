@@ -56,6 +56,7 @@ def parse():
     p.add_argument("--dropout", type=float, default=0.0, help="0.0 = the parity regime (default); 0.1 = the reference's default")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
+    p.add_argument("--plan_cache", default="", help="JSON file of tuned GEMM plans: loaded if present (no tuning launches), else tuned and written")
     p.add_argument("--shapes_out", default="", help="write the per-shape launch table (from the profiler step) to this file")
     return p.parse_args()
 
@@ -171,7 +172,12 @@ def main():
         m = TE.build_model(h, dev)
     n_params = m.get_num_params()
     from omnibiote_amd import tune
-    tune.tune_model_shapes(a.mini_batch_size * cfg["ctx_len"], cfg["n_embd"], 2 ** 16, device=dev, verbose=(rank == 0 and bool(a.shapes_out)))
+    if a.plan_cache and os.path.exists(a.plan_cache):
+        tune.load_plans(a.plan_cache)
+    else:
+        tune.tune_model_shapes(a.mini_batch_size * cfg["ctx_len"], cfg["n_embd"], 2 ** 16, device=dev, verbose=(rank == 0 and bool(a.shapes_out)))
+        if a.plan_cache and rank == 0:
+            tune.save_plans(a.plan_cache)
     force_ddp = os.environ.get("OBTE_FORCE_DDP") == "1"   # rehearse the N>1 code path on one GPU
     if force_ddp and world == 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
