@@ -101,6 +101,24 @@ __device__ __forceinline__ void gelu_ref_both(float x, float& act, float& der) {
     act = x * half_cdf;
     der = half_cdf + x * (0.5641895835477563f / OBTE_GELU_C) * g;
 }
+// Two elements at a time on v_pk_{mul,fma,add}_f32 (one issue slot for both); only the rcp and exp stay scalar.
+// Same formula and constants as erf_and_gauss / gelu_ref_both above.  (Measured: the GELU epilogue's extra ~20 us on
+// the fc shape is its second 67-MB output, not this arithmetic — packed or scalar time the same.)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_ref_both2(f32x2_t x, f32x2_t& act, f32x2_t& der) {
+    const f32x2_t u = x * (1.0f / OBTE_GELU_C);
+    const f32x2_t au = __builtin_elementwise_abs(u);
+    const f32x2_t den = au * 0.3275911f + 1.0f;
+    const f32x2_t t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    const f32x2_t e2 = u * u * -1.4426950408889634f;   // exp(-u^2) = exp2(-u^2 * log2 e)
+    const f32x2_t gauss = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+    const f32x2_t poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const f32x2_t e_abs = 1.0f - poly * gauss;
+    const f32x2_t e = {__builtin_copysignf(e_abs[0], u[0]), __builtin_copysignf(e_abs[1], u[1])};
+    const f32x2_t half_cdf = e * 0.5f + 0.5f;
+    act = x * half_cdf;
+    der = half_cdf + x * (0.5641895835477563f / OBTE_GELU_C) * gauss;
+}
 __device__ __forceinline__ float gelu_ref_grad(float x) {
     float e, g;
     erf_and_gauss(x * (1.0f / OBTE_GELU_C), e, g);

@@ -200,11 +200,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
                 // epilogue is then a plain multiply
                 bf16x8 g;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float act, der;
-                    gelu_ref_both(bf2f(v[j]), act, der);
-                    g[j] = f2bf(act);
-                    v[j] = f2bf(der);
+                for (int j = 0; j < 8; j += 2) {
+                    f32x2_t act, der;
+                    gelu_ref_both2(f32x2_t{bf2f(v[j]), bf2f(v[j + 1])}, act, der);
+                    g[j] = f2bf(act[0]); g[j + 1] = f2bf(act[1]);
+                    v[j] = f2bf(der[0]); v[j + 1] = f2bf(der[1]);
                 }
                 *reinterpret_cast<bf16x8*>(p.d2 + o) = g;
             } else if (EPI == OBTE_EPI_ADD) {
