@@ -106,6 +106,12 @@ int obte_gemm_plan_set(int a_kmajor, int b_kmajor, int epilogue, int64_t M, int6
 int obte_gemm_plan_clear(void);
 int64_t obte_gemm_workspace_bytes_max(int64_t M, int64_t N, int64_t K);
 
+/* Grouped launch: `count` (1..4) independent GEMMs of ONE layout and epilogue (OBTE_EPI_NONE or OBTE_EPI_ADD) in a
+ * single grid of 256x256 tiles, each tile running its full K (>= 128) — no split-K workspace, no reduce launches.
+ * Replaces, in one call, the four weight-gradient products autograd issues for the nn.Linear layers of one block
+ * (training/model.py:102,151,163,166 under loss.backward(), train_encoder.py:462): dW_mlp, dW_fc, dW_proj, dW_attn. */
+int obte_gemm_grouped_bf16(const obte_gemm_args* gs, int count, obte_stream s);
+
 /* ---- dropout (training/model.py:83-84,160,204) -------------------------------------------------------------------
  * Every dropout site of the path draws its mask from one counter-based generator: element `idx` of site `site` is
  * kept iff hash(seed, site, idx) >= p (see csrc/common.h drop_keep); kept values are scaled by 1/(1-p) and rounded to

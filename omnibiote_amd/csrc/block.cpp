@@ -31,7 +31,7 @@ struct ActLayout {
 };
 
 struct WsLayout {
-    int64_t dhpre, dh, dx1, dyattn, dqkv, delta, lnws, dym, gemmws, gemmws_bytes, total;
+    int64_t dhpre, dh, dx1, dyattn, dqkv, delta, lnws, dym, dym2, gemmws, gemmws_bytes, total;
     WsLayout(int64_t B, int64_t T, int C, int H) {
         const int64_t M = B * T;
         int64_t o = 0;
@@ -43,7 +43,8 @@ struct WsLayout {
         dqkv = take(M * 3 * C * 2);
         delta = take(B * H * T * 4);
         lnws = take((int64_t)obte_layernorm_bwd_ws_rows() * C * 4);
-        dym = take(M * C * 2);      // dropout-masked copy of an incoming gradient (only touched when dropout_p > 0)
+        dym = take(M * C * 2);      // dropout-masked copies of the two incoming gradients (only touched when dropout_p > 0);
+        dym2 = take(M * C * 2);     // two buffers: both stay live until the grouped weight-gradient launch at the end
         gemmws_bytes = 0;
         const int64_t shapes[4][2] = {{C, 4 * C}, {4 * C, C}, {C, C}, {3 * C, C}};   // the four weight gradients
         for (auto& sh : shapes) {
@@ -66,6 +67,19 @@ int gemm(const obte_bf16* a, const obte_bf16* b, obte_bf16* d, int64_t M, int64_
         g.epilogue = OBTE_EPI_ADD_DROPOUT; g.dropout_p = drop_p; g.dropout_seed = drop_seed; g.dropout_site = drop_site;
     }
     return obte_gemm_bf16_ws(&g, ws, ws_bytes, s);
+}
+
+// The four weight gradients of a block go out as ONE grouped launch (obte_gemm_grouped_bf16) when their 256x256 tiles
+// fill the chip reasonably (>= 70 % of the CU slots of the rounds they need); tiny widths keep the per-matrix split-K
+// launches.  OBTE_GROUPED_WGRAD=0/1 overrides (A/B timing, tests).
+bool use_grouped_wgrad(int C, int64_t M) {
+    const char* e = getenv("OBTE_GROUPED_WGRAD");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1' && M >= 128;
+    if (M < 1024) return false;
+    auto t = [](int64_t m, int64_t n) { return ((m + 255) / 256) * ((n + 255) / 256); };
+    const int64_t tiles = t(C, 4 * C) + t(4 * C, C) + t(C, C) + t(3 * C, C);
+    const int64_t rounds = (tiles + 255) / 256;
+    return tiles * 10 >= rounds * 256 * 7;
 }
 
 // dropout sites of one block (csrc/common.h OBTE_SITE_*): 1 attention probabilities, 2 attention c_proj, 3 MLP c_proj
@@ -162,7 +176,9 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     void* gws = W.gemmws_bytes > 0 ? (void*)(S + W.gemmws) : nullptr;
 
     obte_bf16* dym = (obte_bf16*)(S + W.dym);
+    obte_bf16* dym2 = (obte_bf16*)(S + W.dym2);
     const bool drop = d->dropout_p > 0.f;
+    const bool grouped = use_grouped_wgrad(C, M);
     // MLP: out = x1 + dropout(hact W_mlp^T): the projection sees dy masked by the same (seed, site 3) mask
     const obte_bf16* dy_mlp = dy;
     if (drop) {
@@ -170,18 +186,18 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
         dy_mlp = dym;
     }
     TRY(gemm(dy_mlp, d->mlp_w, dhpre, M, 4 * C, C, C, 4 * C, 1, 0, OBTE_EPI_GELU_BWD, hpre, nullptr, s));      // dhpre = (dy W_mlp) * gelu'(h): hpre holds the derivative
-    TRY(gemm(dy_mlp, hact, dmlp_w, C, 4 * C, M, C, 4 * C, 0, 0, wepi, accumulate_matrices ? dmlp_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_mlp = dy^T hact
+    if (!grouped) TRY(gemm(dy_mlp, hact, dmlp_w, C, 4 * C, M, C, 4 * C, 0, 0, wepi, accumulate_matrices ? dmlp_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_mlp = dy^T hact
     TRY(gemm(dhpre, d->fc_w, dh, M, C, 4 * C, 4 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh2 = dhpre W_fc
-    TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, M, 4 * C, C, 0, 0, wepi, accumulate_matrices ? dfc_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_fc = dhpre^T h2
+    if (!grouped) TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, M, 4 * C, C, 0, 0, wepi, accumulate_matrices ? dfc_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_fc = dhpre^T h2
     TRY(obte_layernorm_bwd(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, lnws, M, C, s));                     // dx1 = dy + LN2'(dh2)
     // attention: x1 = x + dropout(y W_proj^T)
     const obte_bf16* dx1_proj = dx1;
     if (drop) {
-        TRY(obte_dropout_bf16(dx1, dym, M * C, d->dropout_p, d->dropout_seed, SITE_RESID, s));
-        dx1_proj = dym;
+        TRY(obte_dropout_bf16(dx1, dym2, M * C, d->dropout_p, d->dropout_seed, SITE_RESID, s));
+        dx1_proj = dym2;
     }
     TRY(gemm(dx1_proj, d->proj_w, dyattn, M, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dy_attn = dx1 W_proj
-    TRY(gemm(dx1_proj, yat, dproj_w, C, C, M, C, C, 0, 0, wepi, accumulate_matrices ? dproj_w : nullptr, nullptr, s, gws, W.gemmws_bytes));                       // dW_proj = dx1^T y
+    if (!grouped) TRY(gemm(dx1_proj, yat, dproj_w, C, C, M, C, C, 0, 0, wepi, accumulate_matrices ? dproj_w : nullptr, nullptr, s, gws, W.gemmws_bytes));                       // dW_proj = dx1^T y
     obte_attn_bwd_args ab = {};
     ab.qkv = qkv; ab.o = yat; ab.d_o = dyattn; ab.lse = lse; ab.delta = delta; ab.dqkv = dqkv;
     ab.rope_cos = d->rope_cos; ab.rope_sin = d->rope_sin;
@@ -190,7 +206,21 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     ab.dropout_p = d->dropout_p; ab.dropout_seed = d->dropout_seed;
     TRY(obte_attn_bwd(&ab, s));
     TRY(gemm(dqkv, d->attn_w, dh, M, C, 3 * C, 3 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh1 = dqkv W_attn
-    TRY(gemm(dqkv, h1, dattn_w, 3 * C, C, M, 3 * C, C, 0, 0, wepi, accumulate_matrices ? dattn_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_attn = dqkv^T h1
+    if (!grouped) TRY(gemm(dqkv, h1, dattn_w, 3 * C, C, M, 3 * C, C, 0, 0, wepi, accumulate_matrices ? dattn_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_attn = dqkv^T h1
     TRY(obte_layernorm_bwd(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, lnws, M, C, s));                      // dx = dx1 + LN1'(dh1)
+    if (grouped) {
+        // dW_mlp = dy^T hact, dW_fc = dhpre^T h2, dW_proj = dx1^T y, dW_attn = dqkv^T h1 — one grid, full K per tile
+        obte_gemm_args gs[4] = {};
+        auto put = [&](int i, const obte_bf16* a, const obte_bf16* b, obte_bf16* dw, int64_t m, int64_t n) {
+            gs[i].a = a; gs[i].b = b; gs[i].d = dw; gs[i].aux = accumulate_matrices ? dw : nullptr;
+            gs[i].M = m; gs[i].N = n; gs[i].K = M; gs[i].lda = m; gs[i].ldb = n; gs[i].ldd = n;
+            gs[i].a_kmajor = 0; gs[i].b_kmajor = 0; gs[i].epilogue = wepi; gs[i].alpha = 1.0f;
+        };
+        put(0, dhpre, h2, dfc_w, 4 * C, C);
+        put(1, dy_mlp, hact, dmlp_w, C, 4 * C);
+        put(2, dqkv, h1, dattn_w, 3 * C, C);
+        put(3, dx1_proj, yat, dproj_w, C, C);
+        TRY(obte_gemm_grouped_bf16(gs, 4, s));
+    }
     return OBTE_OK;
 }

@@ -378,17 +378,18 @@ __device__ __forceinline__ bf16x8 load_frag_h(const char* tile, int mn0, int lan
     return load_frag<false, 256>(tile, mn0, 0, lane);
 }
 
+// bijective XCD remap: workgroups that land on one XCD (bid % 8) get a contiguous range of work ids
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+}
+
+// one 256x256 tile (or K-split of it) of problem p; wgid in [0, tiles_m * tiles_n * splits)
 template <bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPLIT>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
+__device__ __forceinline__ void v3_tile(const GemmParams& p, const int wgid, char* smem) {
     constexpr int BN = 256, NJ = 8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-
-    const int nwg = p.tiles_m * p.tiles_n * p.splits;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     const int split = wgid % p.splits;
     const int tid_ = wgid / p.splits;
     const int group_sz = 8 * p.tiles_n;
@@ -479,6 +480,52 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
     mma(a0, b0);
     mma(a1, b1);
     tile_epilogue<EPI, SPLIT, BN>(p, acc, smem, wave, lane, m0, n0, wm, wn, split);
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPLIT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v3_tile<A_KMAJOR, B_KMAJOR, EPI, SPLIT>(p, xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.splits), smem);
+}
+
+// Grouped launch: up to four independent GEMMs of one layout and epilogue in ONE grid (no split-K).  Built for the
+// four weight gradients of a transformer block (dW = dY^T X with K = tokens): alone, none of them has enough
+// 256x256 tiles for 256 CUs, so each used to run as a split-K launch plus a reduce kernel over fp32 slabs; together
+// they have 192 tiles at n_embd = 1024 (768 at 2048), every tile runs the full K with the accumulate-into-grad
+// epilogue, and the slabs, the four reduce launches and three kernel tails disappear.
+constexpr int GROUP_MAX = 4;
+struct GroupParams {
+    GemmParams g[GROUP_MAX];
+    int first_wg[GROUP_MAX + 1];
+};
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_group_kernel(GroupParams gp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wgid = xcd_remap(blockIdx.x, gp.first_wg[GROUP_MAX]);
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < GROUP_MAX; ++j) i += (wgid >= gp.first_wg[j]) ? 1 : 0;
+    v3_tile<A_KMAJOR, B_KMAJOR, EPI, false>(gp.g[i], wgid - gp.first_wg[i], smem);
+}
+#define OBTE_INSTG(AK, BK)                                                                     \
+    template __global__ void gemm_v3_group_kernel<AK, BK, OBTE_EPI_NONE>(GroupParams);         \
+    template __global__ void gemm_v3_group_kernel<AK, BK, OBTE_EPI_ADD>(GroupParams);
+OBTE_INSTG(true, true)
+OBTE_INSTG(true, false)
+OBTE_INSTG(false, true)
+OBTE_INSTG(false, false)
+#undef OBTE_INSTG
+
+template <bool AK, bool BK, int EPI>
+int launch_group(const GroupParams& gp, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_v3_group_kernel<AK, BK, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_SMEM);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_v3_group_kernel<AK, BK, EPI>), dim3(gp.first_wg[GROUP_MAX]), dim3(NTHREADS), V3_SMEM, st, gp);
+    OBTE_CHECK_LAUNCH("obte_gemm_grouped_bf16");
+    return OBTE_OK;
 }
 
 #define OBTE_INST3(AK, BK)                                                                   \
@@ -676,7 +723,7 @@ extern "C" int64_t obte_gemm_workspace_bytes_max(int64_t M, int64_t N, int64_t K
 }
 
 
-extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64_t workspace_bytes, obte_stream s) {
+static int validate_args(const obte_gemm_args* g) {
     OBTE_REQUIRE(g && g->a && g->b && g->d, "obte_gemm_bf16: null pointer");
     OBTE_REQUIRE(g->M > 0 && g->N > 0 && g->K > 0, "obte_gemm_bf16: empty problem M=%lld N=%lld K=%lld",
                  (long long)g->M, (long long)g->N, (long long)g->K);
@@ -696,6 +743,30 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
                      "obte_gemm_bf16: EPI_ROPE_QK needs cos/sin tables, T, head_dim %% 8 == 0 and N = 3 * n_head * head_dim");
     if (g->epilogue == OBTE_EPI_GELU) OBTE_REQUIRE(g->d2, "obte_gemm_bf16: GELU epilogue needs d2");
     if (g->epilogue != OBTE_EPI_NONE && g->epilogue != OBTE_EPI_ADD) OBTE_REQUIRE(g->alpha == 1.0f, "obte_gemm_bf16: alpha != 1 only with EPI_NONE / EPI_ADD");
+    return OBTE_OK;
+}
+
+static void fill_params(const obte_gemm_args* g, void* workspace, GemmParams& p) {
+    p.a = (const bf16*)g->a; p.b = (const bf16*)g->b; p.d = (bf16*)g->d; p.aux = (const bf16*)g->aux; p.d2 = (bf16*)g->d2;
+    p.slab = (float*)workspace;
+    p.M = g->M; p.N = g->N; p.K = g->K; p.lda = g->lda; p.ldb = g->ldb; p.ldd = g->ldd;
+    p.a_elems = (g->a_kmajor ? g->M : g->K) * g->lda;
+    p.b_elems = (g->b_kmajor ? g->N : g->K) * g->ldb;
+    {   // timing-only diagnostic: zero-record descriptors drop every LDS-DMA (results are wrong; never set in production)
+        static int noload = -1, nostore = -1, exit_now = -1;
+        if (noload < 0) {
+            const char* e = getenv("OBTE_GEMM_DEBUG");
+            nostore = (e && strstr(e, "nostore")) ? 1 : 0;
+            exit_now = (e && strstr(e, "exit")) ? 1 : 0;
+            noload = (e && strstr(e, "noload")) ? 1 : 0;
+        }
+        if (noload) { p.a_elems = 0; p.b_elems = 0; }
+        p.store_rows = exit_now ? -1 : (nostore ? 0 : p.M);
+    }
+}
+
+extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64_t workspace_bytes, obte_stream s) {
+    { const int vrc = validate_args(g); if (vrc != OBTE_OK) return vrc; }
     hipStream_t st = (hipStream_t)s;
     const int prof = obte_prof_begin(st, (g->a_kmajor ? 8 : 0) + (g->b_kmajor ? 4 : 0) + g->epilogue, g->M, g->N, g->K);
     int rc;
@@ -709,22 +780,7 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
         return rc;
     }
     GemmParams p;
-    p.a = (const bf16*)g->a; p.b = (const bf16*)g->b; p.d = (bf16*)g->d; p.aux = (const bf16*)g->aux; p.d2 = (bf16*)g->d2;
-    p.slab = (float*)workspace;
-    p.M = g->M; p.N = g->N; p.K = g->K; p.lda = g->lda; p.ldb = g->ldb; p.ldd = g->ldd;
-    p.a_elems = (g->a_kmajor ? g->M : g->K) * g->lda;
-    p.b_elems = (g->b_kmajor ? g->N : g->K) * g->ldb;
-    {   // timing-only diagnostic: zero-record descriptors drop every LDS-DMA (results are wrong; never set in production)
-        static int noload = -1, nostore = -1;
-        if (noload < 0) {
-            const char* e = getenv("OBTE_GEMM_DEBUG");
-            noload = (e && strstr(e, "noload")) ? 1 : 0;
-            nostore = (e && strstr(e, "nostore")) ? 1 : 0;
-        }
-        if (noload) { p.a_elems = 0; p.b_elems = 0; }
-        p.store_rows = nostore ? 0 : p.M;
-        { const char* e = getenv("OBTE_GEMM_DEBUG"); if (e && strstr(e, "exit")) p.store_rows = -1; }
-    }
+    fill_params(g, workspace, p);
     const int64_t tm = cdiv64(g->M, BM), tn = cdiv64(g->N, pl.bn);
     OBTE_REQUIRE(tm * tn < (1ll << 26), "obte_gemm_bf16: too many tiles");
     p.tiles_m = (int)tm; p.tiles_n = (int)tn;
@@ -759,3 +815,44 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
 }
 
 extern "C" int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s) { return obte_gemm_bf16_ws(g, nullptr, 0, s); }
+
+// Grouped launch (see gemm_v3_group_kernel).  All problems share layout and epilogue (NONE or ADD); each needs K >= 128.
+extern "C" int obte_gemm_grouped_bf16(const obte_gemm_args* gs, int count, obte_stream s) {
+    OBTE_REQUIRE(gs && count >= 1 && count <= GROUP_MAX, "obte_gemm_grouped_bf16: count must be 1..%d", GROUP_MAX);
+    GroupParams gp;
+    memset(&gp, 0, sizeof(gp));
+    hipStream_t st = (hipStream_t)s;
+    int wg = 0;
+    for (int i = 0; i < count; ++i) {
+        const obte_gemm_args* g = gs + i;
+        OBTE_REQUIRE(g->a_kmajor == gs[0].a_kmajor && g->b_kmajor == gs[0].b_kmajor && g->epilogue == gs[0].epilogue,
+                     "obte_gemm_grouped_bf16: problems must share layout and epilogue");
+        { const int vrc = validate_args(g); if (vrc != OBTE_OK) return vrc; }
+        OBTE_REQUIRE(g->epilogue == OBTE_EPI_NONE || g->epilogue == OBTE_EPI_ADD, "obte_gemm_grouped_bf16: epilogue must be NONE or ADD");
+        OBTE_REQUIRE(g->K >= 128, "obte_gemm_grouped_bf16: K must be >= 128 (K=%lld)", (long long)g->K);
+        GemmParams& p = gp.g[i];
+        fill_params(g, nullptr, p);
+        const int64_t tm = cdiv64(g->M, BM), tn = cdiv64(g->N, 256);
+        OBTE_REQUIRE(tm * tn < (1ll << 24), "obte_gemm_grouped_bf16: too many tiles");
+        p.tiles_m = (int)tm; p.tiles_n = (int)tn; p.splits = 1;
+        p.k_per_split = (int)cdiv64(g->K, BKT);
+        p.alpha = g->alpha;
+        p.drop = make_drop(0.f, 0, 0);
+        gp.first_wg[i] = wg;
+        wg += (int)(tm * tn);
+    }
+    for (int i = count; i <= GROUP_MAX; ++i) gp.first_wg[i] = wg;
+    for (int i = count; i < GROUP_MAX; ++i) gp.g[i] = gp.g[0];   // never selected (first_wg[i] == total)
+    int64_t mx = 0, flop_k = 0;
+    for (int i = 0; i < count; ++i) { mx += gs[i].M * gs[i].N; flop_k = gs[i].K; }
+    // profiler record: one entry, M*N summed over the group (shown as d0 = sum(M*N)/N0, d1 = N0)
+    const int prof = obte_prof_begin(st, 32 + (gs[0].a_kmajor ? 8 : 0) + (gs[0].b_kmajor ? 4 : 0) + gs[0].epilogue, mx / gs[0].N, gs[0].N, flop_k);
+    int rc;
+    const bool add = gs[0].epilogue == OBTE_EPI_ADD;
+    if (gs[0].a_kmajor && gs[0].b_kmajor) rc = add ? launch_group<true, true, OBTE_EPI_ADD>(gp, st) : launch_group<true, true, OBTE_EPI_NONE>(gp, st);
+    else if (gs[0].a_kmajor) rc = add ? launch_group<true, false, OBTE_EPI_ADD>(gp, st) : launch_group<true, false, OBTE_EPI_NONE>(gp, st);
+    else if (gs[0].b_kmajor) rc = add ? launch_group<false, true, OBTE_EPI_ADD>(gp, st) : launch_group<false, true, OBTE_EPI_NONE>(gp, st);
+    else rc = add ? launch_group<false, false, OBTE_EPI_ADD>(gp, st) : launch_group<false, false, OBTE_EPI_NONE>(gp, st);
+    obte_prof_end(prof, st);
+    return rc;
+}

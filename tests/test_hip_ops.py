@@ -332,7 +332,9 @@ def test_adamw_matches_fp32_formula():
 # ------------------------------------------------------------------------------------------------------ block
 @pytest.mark.parametrize("C,H,T", [(128, 2, 64), (256, 2, 77), (1024, 8, 128)])
 @pytest.mark.parametrize("mode", ["complex", "cos_only"])
-def test_block_fwd_bwd_vs_oracle(C, H, T, mode):
+@pytest.mark.parametrize("grouped", ["0", "1"])
+def test_block_fwd_bwd_vs_oracle(monkeypatch, C, H, T, mode, grouped):
+    monkeypatch.setenv("OBTE_GROUPED_WGRAD", grouped)   # per-matrix split-K launches / one grouped weight-gradient launch
     B = 2
     hs = C // H
     cfg = R.RefConfig(block_size=T, vocab_size=256, n_layer=1, n_head=H, n_embd=C)
@@ -440,6 +442,34 @@ def test_gemm_both_tile_widths(monkeypatch, bn):
     d, d2 = o.linear_fwd(x.to(DEV), w.to(DEV), epilogue=L().EPI_GELU)
     close(d2, R.gelu_erf(acc.to(BF).float()), atol=0.03, what="gelu act")
     close(o.linear_fwd(x.to(DEV), w.to(DEV), alpha=1 / 42.0), acc / 42.0, atol=2e-3, what="alpha")
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_gemm_grouped_matches_single_launches(accumulate):
+    """One grouped launch of four weight-gradient shaped products (ragged M/N, K not a multiple of 64) against fp32
+    references and against the single-problem entry point."""
+    o = ops()
+    K = 1000
+    shapes = [(520, 264), (256, 1024), (776, 256), (256, 256)]
+    probs, refs, singles = [], [], []
+    for i, (M, N) in enumerate(shapes):
+        a, b = rnd(K, M, seed=60 + i, scale=0.5), rnd(K, N, seed=70 + i, scale=0.5)
+        base = rnd(M, N, seed=80 + i)
+        out = base.clone().to(DEV)
+        probs.append((a.to(DEV), b.to(DEV), M, N, K, out))
+        acc = a.float().t() @ b.float()
+        refs.append(base.float() + acc.to(BF).float() if accumulate else acc)
+        singles.append(o.linear_wgrad(a.to(DEV), b.to(DEV), accumulate_into=base.clone().to(DEV) if accumulate else None))
+    outs = o.gemm_grouped(probs, accumulate=accumulate)
+    for got, ref, single in zip(outs, refs, singles):
+        close(got, ref, atol=0.01 * math.sqrt(K) + 0.02, what="grouped wgrad")
+        close(got, single.float().cpu(), atol=0.07, what="grouped vs single launch")   # fp32 summation order differs (split-K)
+    with pytest.raises(RuntimeError, match="share layout"):
+        bad = (L().GemmArgs * 2)()
+        a, b, M, N, K_, out = probs[0]
+        bad[0] = L().GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, M, N, K_, M, N, N, 0, 0, 0, 1.0, 0.0, 0, 0)
+        bad[1] = L().GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, M, N, K_, M, N, N, 1, 0, 0, 1.0, 0.0, 0, 0)
+        L().check(L().lib().obte_gemm_grouped_bf16(bad, 2, None), "obte_gemm_grouped_bf16")
 
 
 def test_multi_tensor_adamw_matches_single_tensor_kernel():
@@ -576,8 +606,10 @@ def test_attention_dropout_fwd_bwd(hs, mode):
     close(dqkv, dref, atol=2e-2, rtol=2.0 ** -6, what=f"attn dropout bwd {mode}")
 
 
-def test_block_dropout_fwd_bwd_vs_oracle():
+@pytest.mark.parametrize("grouped", ["0", "1"])
+def test_block_dropout_fwd_bwd_vs_oracle(monkeypatch, grouped):
     """A whole block with all three dropout sites on, against the oracle fed the restated masks."""
+    monkeypatch.setenv("OBTE_GROUPED_WGRAD", grouped)
     B, T, C, H, p = 2, 64, 128, 2, 0.15
     hs = C // H
     cfg = R.RefConfig(block_size=T, vocab_size=256, n_layer=1, n_head=H, n_embd=C)
