@@ -53,6 +53,11 @@ int obte_layernorm_bwd_ws_rows(void);
 int obte_layernorm_bwd(const obte_bf16* dy, const obte_bf16* x, const obte_bf16* w, const float* mean,
                        const float* rstd, const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dw, float* ws,
                        int64_t rows, int cols, obte_stream s);
+/* Same, with dw accumulated in place when accumulate_dw != 0: dw = bf16(dw + bf16(sum)) — the arithmetic of autograd's
+ * `param.grad += new` (train_encoder.py:462, gradient accumulation over micro-batches) without its extra launch. */
+int obte_layernorm_bwd_acc(const obte_bf16* dy, const obte_bf16* x, const obte_bf16* w, const float* mean,
+                       const float* rstd, const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dw, float* ws,
+                       int64_t rows, int cols, int accumulate_dw, obte_stream s);
 
 /* ---- bf16 GEMM on MFMA, fp32 accumulate (nn.Linear fwd/dgrad/wgrad: training/model.py:102,151,163,166,253)
  * D[M,N] = epilogue(alpha * sum_k A(m,k) * B(n,k)).
@@ -230,10 +235,10 @@ int obte_block_bwd(const obte_block_desc* d, const obte_bf16* x, const obte_bf16
                    obte_bf16* dx, obte_bf16* dln1_w, obte_bf16* dattn_w, obte_bf16* dproj_w, obte_bf16* dln2_w,
                    obte_bf16* dfc_w, obte_bf16* dmlp_w, obte_stream s);
 
-/* Same as obte_block_bwd; with accumulate_matrices != 0 the four weight-matrix gradients are ADDED to the contents of
- * d*_w (bf16(old + bf16(new)), what autograd's accumulation would produce) instead of overwriting them — gradient
- * accumulation over micro-batches without the separate read-modify-write pass.  The LayerNorm gradients are still
- * overwritten. */
+/* Same as obte_block_bwd; accumulate_matrices is a bit set: with bit 0 the four weight-matrix gradients are ADDED to
+ * the contents of d*_w (bf16(old + bf16(new)), what autograd's accumulation would produce) instead of overwriting
+ * them — gradient accumulation over micro-batches without the separate read-modify-write pass; with bit 1 the same
+ * for the two LayerNorm weight gradients (dln1_w, dln2_w).  Unset bits: overwrite. */
 int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, const obte_bf16* dy, const void* act, void* ws,
                        obte_bf16* dx, obte_bf16* dln1_w, obte_bf16* dattn_w, obte_bf16* dproj_w, obte_bf16* dln2_w,
                        obte_bf16* dfc_w, obte_bf16* dmlp_w, int accumulate_matrices, obte_stream s);

@@ -74,6 +74,7 @@ SYMBOLS = {
     "obte_layernorm_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_float, c_stream]),
     "obte_layernorm_bwd_ws_rows": (C.c_int, []),
     "obte_layernorm_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, c_stream]),
+    "obte_layernorm_bwd_acc": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, C.c_int, c_stream]),
     "obte_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), c_stream]),
     "obte_gemm_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "obte_gemm_bf16_ws": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_int64, c_stream]),

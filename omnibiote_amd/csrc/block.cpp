@@ -156,7 +156,10 @@ extern "C" int obte_block_bwd(const obte_block_desc* d, const obte_bf16* x, cons
 extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, const obte_bf16* dy, const void* act, void* ws,
                                   obte_bf16* dx, obte_bf16* dln1_w, obte_bf16* dattn_w, obte_bf16* dproj_w, obte_bf16* dln2_w,
                                   obte_bf16* dfc_w, obte_bf16* dmlp_w, int accumulate_matrices, obte_stream s) {
-    const int wepi = accumulate_matrices ? OBTE_EPI_ADD : OBTE_EPI_NONE;   // dW += ... straight into the .grad buffers
+    // accumulate_matrices: bit 0 = the four matrices, bit 1 = the two LayerNorm weights: dW += ... straight into the .grad buffers
+    const int acc_ln = (accumulate_matrices & 2) ? 1 : 0;
+    accumulate_matrices &= 1;
+    const int wepi = accumulate_matrices ? OBTE_EPI_ADD : OBTE_EPI_NONE;
     TRY(check_desc("obte_block_bwd", d));
     OBTE_REQUIRE(x && dy && act && ws && dx && dln1_w && dattn_w && dproj_w && dln2_w && dfc_w && dmlp_w, "obte_block_bwd: null pointer");
     const int C = d->n_embd, H = d->n_head, hs = C / H;
@@ -189,7 +192,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     if (!grouped) TRY(gemm(dy_mlp, hact, dmlp_w, C, 4 * C, M, C, 4 * C, 0, 0, wepi, accumulate_matrices ? dmlp_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_mlp = dy^T hact
     TRY(gemm(dhpre, d->fc_w, dh, M, C, 4 * C, 4 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh2 = dhpre W_fc
     if (!grouped) TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, M, 4 * C, C, 0, 0, wepi, accumulate_matrices ? dfc_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_fc = dhpre^T h2
-    TRY(obte_layernorm_bwd(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, lnws, M, C, s));                     // dx1 = dy + LN2'(dh2)
+    TRY(obte_layernorm_bwd_acc(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, lnws, M, C, acc_ln, s));                     // dx1 = dy + LN2'(dh2)
     // attention: x1 = x + dropout(y W_proj^T)
     const obte_bf16* dx1_proj = dx1;
     if (drop) {
@@ -207,7 +210,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     TRY(obte_attn_bwd(&ab, s));
     TRY(gemm(dqkv, d->attn_w, dh, M, C, 3 * C, 3 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh1 = dqkv W_attn
     if (!grouped) TRY(gemm(dqkv, h1, dattn_w, 3 * C, C, M, 3 * C, C, 0, 0, wepi, accumulate_matrices ? dattn_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_attn = dqkv^T h1
-    TRY(obte_layernorm_bwd(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, lnws, M, C, s));                      // dx = dx1 + LN1'(dh1)
+    TRY(obte_layernorm_bwd_acc(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, lnws, M, C, acc_ln, s));                      // dx = dx1 + LN1'(dh1)
     if (grouped) {
         // dW_mlp = dy^T hact, dW_fc = dhpre^T h2, dW_proj = dx1^T y, dW_attn = dqkv^T h1 — one grid, full K per tile
         obte_gemm_args gs[4] = {};

@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
 }
 
 // dw[c] = sum over the per-workgroup partial rows; 32 columns x 8 row-groups per workgroup, 128-B row segments.
-__global__ __launch_bounds__(256) void ln_dw_reduce_kernel(const float* __restrict__ ws, bf16* __restrict__ dw, int nblk, int cols) {
+// accumulate: dw = bf16(dw + bf16(sum)) — what autograd's `grad += new` would compute, without the extra launch.
+__global__ __launch_bounds__(256) void ln_dw_reduce_kernel(const float* __restrict__ ws, bf16* __restrict__ dw, int nblk, int cols, int accumulate) {
     __shared__ float red[8][32];
     const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void ln_dw_reduce_kernel(const float* __restri
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) t += red[i][cl];
-        dw[c] = f2bf(t);
+        dw[c] = accumulate ? f2bf(bf2f(dw[c]) + bf2f(f2bf(t))) : f2bf(t);
     }
 }
 
@@ -193,6 +194,12 @@ extern "C" int obte_layernorm_fwd(const obte_bf16* x, const obte_bf16* w, obte_b
 extern "C" int obte_layernorm_bwd(const obte_bf16* dy, const obte_bf16* x, const obte_bf16* w, const float* mean,
                                   const float* rstd, const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dw, float* ws,
                                   int64_t rows, int cols, obte_stream s) {
+    return obte_layernorm_bwd_acc(dy, x, w, mean, rstd, dresid, dx, dw, ws, rows, cols, 0, s);
+}
+
+extern "C" int obte_layernorm_bwd_acc(const obte_bf16* dy, const obte_bf16* x, const obte_bf16* w, const float* mean,
+                                      const float* rstd, const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dw, float* ws,
+                                      int64_t rows, int cols, int accumulate_dw, obte_stream s) {
     OBTE_REQUIRE(dy && x && w && mean && rstd && dx && dw && ws, "obte_layernorm_bwd: null pointer");
     OBTE_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 4096, "obte_layernorm_bwd: bad shape rows=%lld cols=%d", (long long)rows, cols);
     const int nblk = (int)(cdiv64(rows, 4) < LN_BWD_MAX_BLOCKS ? cdiv64(rows, 4) : LN_BWD_MAX_BLOCKS);
@@ -217,7 +224,7 @@ extern "C" int obte_layernorm_bwd(const obte_bf16* dy, const obte_bf16* x, const
     }
 #undef LN_BWD
     OBTE_CHECK_LAUNCH("obte_layernorm_bwd");
-    hipLaunchKernelGGL(ln_dw_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, (const float*)ws, (bf16*)dw, nblk, cols);
+    hipLaunchKernelGGL(ln_dw_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, (const float*)ws, (bf16*)dw, nblk, cols, accumulate_dw);
     OBTE_CHECK_LAUNCH("obte_layernorm_bwd(dw reduce)");
     return OBTE_OK;
 }

@@ -39,7 +39,10 @@ class RangeMask:
         return RangeMask(self.key_ranges.to(device))
 
     @staticmethod
-    def from_tokens(input_ids: torch.Tensor, eos_token: int = EOS_TOKEN, padding: bool = False) -> "RangeMask":
+    def from_tokens(input_ids: torch.Tensor, eos_token: int = EOS_TOKEN, padding: bool = False, group: int = 0) -> "RangeMask":
+        """``group`` > 0: ``input_ids`` stacks several mini-batches of ``group`` rows each (the reference builds one
+        mask per mini-batch, and its row-0 exception applies to the first row of EACH mini-batch) — one pass of tensor
+        ops for a whole optimizer step's rows instead of one per micro-step."""
         B, T = input_ids.shape
         dev = input_ids.device
         is_eos = input_ids == eos_token
@@ -61,7 +64,8 @@ class RangeMask:
         after_c1 = torch.clamp(c1 + 1, max=Tx - 1)
         c2 = torch.where(c1 + 1 < Tx, nxt.gather(1, after_c1.unsqueeze(1)).squeeze(1), torch.full_like(c1, BIG))
         has_c2 = (c2 < BIG).unsqueeze(1)
-        quirk_row = (torch.arange(B, device=dev) >= 1).unsqueeze(1)
+        row = torch.arange(B, device=dev)
+        quirk_row = ((row % group if group > 0 else row) >= 1).unsqueeze(1)
         end = torch.where(quirk_row & (n_before == 0) & has_c2, (c2 + 1).unsqueeze(1).expand(B, Tx), end)
         start = torch.where(quirk_row & (n_before == 1), torch.zeros_like(start), start)
         # positions with no EOS at or after them are never painted: empty range ...

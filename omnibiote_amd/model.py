@@ -131,12 +131,13 @@ class _LayerNormFn(torch.autograd.Function):
     def forward(ctx, x, w):
         y, mean, rstd = ops.layernorm_fwd(x.contiguous(), w)
         ctx.save_for_backward(x, w, mean, rstd)
+        ctx.w_param = w
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, mean, rstd = ctx.saved_tensors
-        dx, dw = ops.layernorm_bwd(dy.contiguous(), x.contiguous(), w, mean, rstd)
+        dx, dw = ops.layernorm_bwd(dy.contiguous(), x.contiguous(), w, mean, rstd, accumulate_into=_grad_slot(ctx.w_param))
         return dx, dw
 
 

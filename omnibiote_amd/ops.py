@@ -50,7 +50,8 @@ def layernorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float = 1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dresid=None):
+def layernorm_bwd(dy, x, w, mean, rstd, dresid=None, accumulate_into=None):
+    """accumulate_into: an existing bf16 weight gradient to add into in place (then the returned dw is None)."""
     _need(dy, "dy"); _need(x, "x"); _need(w, "weight")
     _need(mean, "mean", torch.float32); _need(rstd, "rstd", torch.float32)
     cols = x.shape[-1]
@@ -59,11 +60,14 @@ def layernorm_bwd(dy, x, w, mean, rstd, dresid=None):
     if dresid is not None:
         _need(dresid, "dresid"); assert dresid.shape == x.shape
     dx = torch.empty_like(x)
-    dw = torch.empty_like(w)
+    if accumulate_into is not None:
+        _need(accumulate_into, "grad"); assert accumulate_into.shape == w.shape
+    dw = accumulate_into if accumulate_into is not None else torch.empty_like(w)
     ws = torch.empty(L.lib().obte_layernorm_bwd_ws_rows() * cols, dtype=torch.float32, device=x.device)
-    L.check(L.lib().obte_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dresid), _ptr(dx),
-                                        _ptr(dw), _ptr(ws), rows, cols, _stream()), "obte_layernorm_bwd")
-    return dx, dw
+    L.check(L.lib().obte_layernorm_bwd_acc(_ptr(dy), _ptr(x), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dresid), _ptr(dx),
+                                            _ptr(dw), _ptr(ws), rows, cols, int(accumulate_into is not None), _stream()),
+            "obte_layernorm_bwd")
+    return dx, (None if accumulate_into is not None else dw)
 
 
 # --------------------------------------------------------------------------------------------------------- GEMM
@@ -339,15 +343,17 @@ def block_fwd(x, params, rope, H, mask: MaskSpec, dropout_p=0.0, dropout_seed=0)
 
 def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec, accumulate_into=None, dropout_p=0.0, dropout_seed=0):
     """accumulate_into: optional list of 6 tensors-or-None (same order as params).  When the four matrix entries are all
-    given, their gradients are added into those tensors in place and the corresponding returned grads are None."""
+    given, their gradients are added into those tensors in place and the corresponding returned grads are None; the
+    same, independently, for the two LayerNorm weights (entries 0 and 3)."""
     _need(x, "x"); _need(dy, "dy")
     B, T, Cc = x.shape
     ws = torch.empty(int(L.lib().obte_block_bwd_ws_bytes(B, T, Cc, H)), dtype=torch.uint8, device=x.device)
     dx = torch.empty_like(x)
     acc = accumulate_into is not None and all(accumulate_into[i] is not None for i in (1, 2, 4, 5))
+    acc_ln = accumulate_into is not None and all(accumulate_into[i] is not None for i in (0, 3))
     grads = []
     for i, w in enumerate(params):
-        if acc and i in (1, 2, 4, 5):
+        if (acc and i in (1, 2, 4, 5)) or (acc_ln and i in (0, 3)):
             g = accumulate_into[i]
             _need(g, "grad"); assert g.shape == w.shape
             grads.append(g)
@@ -355,7 +361,6 @@ def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec, accumulate_into=None,
             grads.append(torch.empty_like(w))
     d = _block_desc(B, T, Cc, H, params, rope, mask, dropout_p, dropout_seed)
     L.check(L.lib().obte_block_bwd_acc(C.byref(d), _ptr(x), _ptr(dy), _ptr(act), _ptr(ws), _ptr(dx), *[_ptr(g) for g in grads],
-                                        int(acc), _stream()), "obte_block_bwd")
-    if acc:
-        grads = [None if i in (1, 2, 4, 5) else g for i, g in enumerate(grads)]
+                                        int(acc) + 2 * int(acc_ln), _stream()), "obte_block_bwd")
+    grads = [None if ((acc and i in (1, 2, 4, 5)) or (acc_ln and i in (0, 3))) else g for i, g in enumerate(grads)]
     return dx, grads

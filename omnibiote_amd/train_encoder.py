@@ -160,6 +160,7 @@ class TrainStep:
         assert lm_head_impl in ("dense", "masked")
         self.lm_head_impl = lm_head_impl
         self._dlogits = None
+        self._all_ranges = None
 
     def _inplace(self, enabled: bool):
         if self.loss_impl != "fused" or os.environ.get("OBTE_NO_INPLACE_ACCUM") == "1":   # CPU-oracle tests / A-B switch
@@ -167,9 +168,12 @@ class TrainStep:
         from .model import accumulate_grads_inplace
         return accumulate_grads_inplace(enabled)
 
-    def _mask(self, tokens: torch.Tensor, dtype):
+    def _mask(self, tokens: torch.Tensor, dtype, j: int = -1):
         from . import masks
-        rm = masks.RangeMask.from_tokens(tokens, padding=self.use_padding)
+        if j >= 0 and self._all_ranges is not None:   # built once per optimizer step for every micro-batch
+            rm = masks.RangeMask(self._all_ranges[j * self.mini:(j + 1) * self.mini])
+        else:
+            rm = masks.RangeMask.from_tokens(tokens, padding=self.use_padding)
         if self.mask_impl == "ranges":
             return rm
         B, T = tokens.shape
@@ -219,11 +223,13 @@ class TrainStep:
             self._mask_rows_host = [torch.nonzero(mh[j], as_tuple=False).reshape(-1).to(input_ids.device) for j in range(mh.shape[0])]
         dtype = next(self.model.parameters()).dtype
         cum_loss = torch.zeros((), dtype=torch.float32, device=input_ids.device)
+        from . import masks
+        self._all_ranges = masks.RangeMask.from_tokens(input_ids, padding=self.use_padding, group=self.mini).key_ranges
         for j in range(n_accum):
             self._mb = j
             x = masked_ids[j * self.mini:(j + 1) * self.mini]
             y = input_ids[j * self.mini:(j + 1) * self.mini]
-            attn_mask = self._mask(y, dtype)
+            attn_mask = self._mask(y, dtype, j)
             last = j == n_accum - 1
             ctx = contextlib.nullcontext()
             if hasattr(self.model, "no_sync") and not last and not self.sync_every:

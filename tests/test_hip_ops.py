@@ -145,6 +145,12 @@ def test_layernorm_fwd_bwd(rows, cols):
     close(dw, wf.grad, atol=0.02 * math.sqrt(rows), what="ln dw")
     dx2, _ = o.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, dresid=dres.to(DEV))
     close(dx2, xf.grad + dres.float(), atol=8e-3, what="ln dx+resid")
+    # in-place accumulation: exactly autograd's bf16(old + new)
+    old = rnd(cols, seed=5)
+    slot = old.clone().to(DEV)
+    _, none = o.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, accumulate_into=slot)
+    assert none is None
+    assert torch.equal(slot.cpu(), (old.float() + dw.cpu().float()).to(BF))
 
 
 # ------------------------------------------------------------------------------------------------------- RoPE

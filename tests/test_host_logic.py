@@ -47,6 +47,21 @@ def test_range_mask_builder_random_vs_oracle(seed):
         np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_range_mask_builder_grouped_equals_per_mini_batch(seed):
+    """One pass over all rows of an optimizer step (group = mini-batch size) must give exactly the ranges of building
+    each mini-batch on its own — including the reference's first-row exception, which restarts with every mini-batch."""
+    rng = np.random.default_rng(100 + seed)
+    mini, n, T = int(rng.integers(1, 5)), int(rng.integers(1, 5)), int(rng.integers(4, 70))
+    tok = rng.integers(4, 30, size=(mini * n, T))
+    tok[rng.random(tok.shape) < 0.15] = R.EOS_TOKEN
+    for padding in (False, True):
+        allr = masks.RangeMask.from_tokens(torch.from_numpy(tok), padding=padding, group=mini).key_ranges
+        for j in range(n):
+            one = masks.RangeMask.from_tokens(torch.from_numpy(tok[j * mini:(j + 1) * mini]), padding=padding).key_ranges
+            assert torch.equal(allr[j * mini:(j + 1) * mini], one)
+
+
 def test_from_dense_rejects_non_block_masks():
     m = torch.full((1, 4, 4), -1e9)
     m[0, 0, 0] = 0; m[0, 0, 2] = 0
