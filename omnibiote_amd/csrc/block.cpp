@@ -208,12 +208,15 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     ab.B = d->B; ab.T = d->T; ab.n_head = H; ab.head_dim = hs; ab.scale = 8.0f / (float)C;
     ab.dropout_p = d->dropout_p; ab.dropout_seed = d->dropout_seed;
     TRY(obte_attn_bwd(&ab, s));
-    TRY(gemm(dqkv, d->attn_w, dh, M, C, 3 * C, 3 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh1 = dqkv W_attn
+    // OBTE_GROUPED_DGRAD=0 keeps dh1 = dqkv W_attn as its own launch (A/B timing)
+    const char* gd = getenv("OBTE_GROUPED_DGRAD");
+    const bool group_dgrad = grouped && !(gd && gd[0] == '0');
+    if (!group_dgrad) TRY(gemm(dqkv, d->attn_w, dh, M, C, 3 * C, 3 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh1 = dqkv W_attn
     if (!grouped) TRY(gemm(dqkv, h1, dattn_w, 3 * C, C, M, 3 * C, C, 0, 0, wepi, accumulate_matrices ? dattn_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_attn = dqkv^T h1
-    TRY(obte_layernorm_bwd_acc(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, lnws, M, C, acc_ln, s));                      // dx = dx1 + LN1'(dh1)
     if (grouped) {
-        // dW_mlp = dy^T hact, dW_fc = dhpre^T h2, dW_proj = dx1^T y, dW_attn = dqkv^T h1 — one grid, full K per tile
-        obte_gemm_args gs[4] = {};
+        // One grid: dW_fc = dhpre^T h2, dW_mlp = dy^T hact, dW_attn = dqkv^T h1, dW_proj = dx1^T y (K = tokens, full K
+        // per tile) and, on the CUs those tiles leave idle, dh1 = dqkv W_attn (K = 3C).
+        obte_gemm_args gs[5] = {};
         auto put = [&](int i, const obte_bf16* a, const obte_bf16* b, obte_bf16* dw, int64_t m, int64_t n) {
             gs[i].a = a; gs[i].b = b; gs[i].d = dw; gs[i].aux = accumulate_matrices ? dw : nullptr;
             gs[i].M = m; gs[i].N = n; gs[i].K = M; gs[i].lda = m; gs[i].ldb = n; gs[i].ldd = n;
@@ -223,7 +226,11 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
         put(1, dy_mlp, hact, dmlp_w, C, 4 * C);
         put(2, dqkv, h1, dattn_w, 3 * C, C);
         put(3, dx1_proj, yat, dproj_w, C, C);
-        TRY(obte_gemm_grouped_bf16(gs, 4, s));
+        gs[4].a = dqkv; gs[4].b = d->attn_w; gs[4].d = dh; gs[4].M = M; gs[4].N = C; gs[4].K = 3 * C;
+        gs[4].lda = 3 * C; gs[4].ldb = C; gs[4].ldd = C; gs[4].a_kmajor = 1; gs[4].b_kmajor = 0;
+        gs[4].epilogue = OBTE_EPI_NONE; gs[4].alpha = 1.0f;
+        TRY(obte_gemm_grouped_bf16(gs, group_dgrad ? 5 : 4, s));
     }
+    TRY(obte_layernorm_bwd_acc(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, lnws, M, C, acc_ln, s));                      // dx = dx1 + LN1'(dh1)
     return OBTE_OK;
 }

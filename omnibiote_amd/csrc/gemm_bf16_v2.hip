@@ -179,9 +179,11 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
                 }
                 *reinterpret_cast<bf16x8*>(p.d2 + o) = g;
             } else if (EPI == OBTE_EPI_ADD) {
-                const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.aux + o);
+                if (p.aux) {   // uniform; null only inside a mixed group (a problem without accumulation)
+                    const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.aux + o);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(r[j]) + bf2f(v[j]));
+                    for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(r[j]) + bf2f(v[j]));
+                }
             } else if (EPI == OBTE_EPI_ROPE_QK) {
                 // packed c_attn output [.., 3C]: rotate the (even, odd) pairs of the q and k thirds (columns < 2N/3),
                 // position = row % T; the v third passes through.  fp32 arithmetic on the bf16-rounded projection.
@@ -488,42 +490,53 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
     v3_tile<A_KMAJOR, B_KMAJOR, EPI, SPLIT>(p, xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.splits), smem);
 }
 
-// Grouped launch: up to four independent GEMMs of one layout and epilogue in ONE grid (no split-K).  Built for the
-// four weight gradients of a transformer block (dW = dY^T X with K = tokens): alone, none of them has enough
-// 256x256 tiles for 256 CUs, so each used to run as a split-K launch plus a reduce kernel over fp32 slabs; together
-// they have 192 tiles at n_embd = 1024 (768 at 2048), every tile runs the full K with the accumulate-into-grad
-// epilogue, and the slabs, the four reduce launches and three kernel tails disappear.
-constexpr int GROUP_MAX = 4;
+// Grouped launch: up to GROUP_MAX independent GEMMs in ONE grid of 256x256 tiles, each tile running its full K (no
+// split-K).  Built for the backward pass of a transformer block: alone, none of its four weight gradients
+// (dW = dY^T X, K = tokens) has enough tiles for 256 CUs, so each used to be a split-K launch plus a reduce kernel
+// over fp32 slabs; together they have 192 tiles at n_embd = 1024 (768 at 2048), every tile accumulates straight into
+// the gradient, and the slabs, the reduce launches and three kernel tails disappear.  The 64 CUs those 192 tiles leave
+// idle are filled with the tiles of a SHORTER independent product of the same layer (the c_attn input gradient,
+// 128 tiles of K = 3 n_embd): problems come in two classes — class 0 = the leading problems with the longest K,
+// class 1 = the rest — and when both class sizes divide by 8 every XCD receives its share of class 0 first, then
+// its share of class 1, so the short tiles start on the CUs that got no long one and behind the first finishers.
+// Layout and accumulate/overwrite are per problem (uniform branches; aux == null means overwrite).
+constexpr int GROUP_MAX = 6;
 struct GroupParams {
     GemmParams g[GROUP_MAX];
     int first_wg[GROUP_MAX + 1];
+    int layout[GROUP_MAX];      // bit 1: A k-contiguous, bit 0: B k-contiguous
+    int n_class0;               // workgroups of class 0 (0: single class)
 };
-template <bool A_KMAJOR, bool B_KMAJOR, int EPI>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_group_kernel(GroupParams gp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wgid = xcd_remap(blockIdx.x, gp.first_wg[GROUP_MAX]);
+    const int nwg = gp.first_wg[GROUP_MAX];
+    int wgid;
+    if (gp.n_class0 > 0) {   // both class sizes are multiples of 8 (host-checked)
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int c0 = gp.n_class0 >> 3, c1 = (nwg - gp.n_class0) >> 3;
+        wgid = k < c0 ? xcd * c0 + k : gp.n_class0 + xcd * c1 + (k - c0);
+    } else {
+        wgid = xcd_remap(blockIdx.x, nwg);
+    }
     int i = 0;
 #pragma unroll
     for (int j = 1; j < GROUP_MAX; ++j) i += (wgid >= gp.first_wg[j]) ? 1 : 0;
-    v3_tile<A_KMAJOR, B_KMAJOR, EPI, false>(gp.g[i], wgid - gp.first_wg[i], smem);
+    const int local = wgid - gp.first_wg[i];
+    switch (gp.layout[i]) {
+        case 0: v3_tile<false, false, OBTE_EPI_ADD, false>(gp.g[i], local, smem); break;
+        case 1: v3_tile<false, true, OBTE_EPI_ADD, false>(gp.g[i], local, smem); break;
+        case 2: v3_tile<true, false, OBTE_EPI_ADD, false>(gp.g[i], local, smem); break;
+        default: v3_tile<true, true, OBTE_EPI_ADD, false>(gp.g[i], local, smem); break;
+    }
 }
-#define OBTE_INSTG(AK, BK)                                                                     \
-    template __global__ void gemm_v3_group_kernel<AK, BK, OBTE_EPI_NONE>(GroupParams);         \
-    template __global__ void gemm_v3_group_kernel<AK, BK, OBTE_EPI_ADD>(GroupParams);
-OBTE_INSTG(true, true)
-OBTE_INSTG(true, false)
-OBTE_INSTG(false, true)
-OBTE_INSTG(false, false)
-#undef OBTE_INSTG
 
-template <bool AK, bool BK, int EPI>
 int launch_group(const GroupParams& gp, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_v3_group_kernel<AK, BK, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_SMEM);
+        (void)hipFuncSetAttribute((const void*)gemm_v3_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V3_SMEM);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_v3_group_kernel<AK, BK, EPI>), dim3(gp.first_wg[GROUP_MAX]), dim3(NTHREADS), V3_SMEM, st, gp);
+    hipLaunchKernelGGL(gemm_v3_group_kernel, dim3(gp.first_wg[GROUP_MAX]), dim3(NTHREADS), V3_SMEM, st, gp);
     OBTE_CHECK_LAUNCH("obte_gemm_grouped_bf16");
     return OBTE_OK;
 }
@@ -816,43 +829,43 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
 
 extern "C" int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s) { return obte_gemm_bf16_ws(g, nullptr, 0, s); }
 
-// Grouped launch (see gemm_v3_group_kernel).  All problems share layout and epilogue (NONE or ADD); each needs K >= 128.
+// Grouped launch (see gemm_v3_group_kernel).  Each problem: any layout, epilogue NONE or ADD, K >= 128.
 extern "C" int obte_gemm_grouped_bf16(const obte_gemm_args* gs, int count, obte_stream s) {
     OBTE_REQUIRE(gs && count >= 1 && count <= GROUP_MAX, "obte_gemm_grouped_bf16: count must be 1..%d", GROUP_MAX);
     GroupParams gp;
     memset(&gp, 0, sizeof(gp));
     hipStream_t st = (hipStream_t)s;
-    int wg = 0;
+    int wg = 0, class0 = 0;
+    bool in_class0 = true;
+    double flop = 0.0;
     for (int i = 0; i < count; ++i) {
         const obte_gemm_args* g = gs + i;
-        OBTE_REQUIRE(g->a_kmajor == gs[0].a_kmajor && g->b_kmajor == gs[0].b_kmajor && g->epilogue == gs[0].epilogue,
-                     "obte_gemm_grouped_bf16: problems must share layout and epilogue");
-        { const int vrc = validate_args(g); if (vrc != OBTE_OK) return vrc; }
         OBTE_REQUIRE(g->epilogue == OBTE_EPI_NONE || g->epilogue == OBTE_EPI_ADD, "obte_gemm_grouped_bf16: epilogue must be NONE or ADD");
+        { const int vrc = validate_args(g); if (vrc != OBTE_OK) return vrc; }
         OBTE_REQUIRE(g->K >= 128, "obte_gemm_grouped_bf16: K must be >= 128 (K=%lld)", (long long)g->K);
+        OBTE_REQUIRE(g->alpha == 1.0f, "obte_gemm_grouped_bf16: alpha must be 1");
         GemmParams& p = gp.g[i];
         fill_params(g, nullptr, p);
+        if (g->epilogue == OBTE_EPI_NONE) p.aux = nullptr;
         const int64_t tm = cdiv64(g->M, BM), tn = cdiv64(g->N, 256);
         OBTE_REQUIRE(tm * tn < (1ll << 24), "obte_gemm_grouped_bf16: too many tiles");
         p.tiles_m = (int)tm; p.tiles_n = (int)tn; p.splits = 1;
         p.k_per_split = (int)cdiv64(g->K, BKT);
-        p.alpha = g->alpha;
+        p.alpha = 1.0f;
         p.drop = make_drop(0.f, 0, 0);
+        gp.layout[i] = (g->a_kmajor ? 2 : 0) + (g->b_kmajor ? 1 : 0);
         gp.first_wg[i] = wg;
         wg += (int)(tm * tn);
+        if (in_class0 && p.k_per_split == gp.g[0].k_per_split) class0 = wg; else in_class0 = false;
+        flop += 2.0 * (double)g->M * (double)g->N * (double)g->K;
     }
     for (int i = count; i <= GROUP_MAX; ++i) gp.first_wg[i] = wg;
-    for (int i = count; i < GROUP_MAX; ++i) gp.g[i] = gp.g[0];   // never selected (first_wg[i] == total)
-    int64_t mx = 0, flop_k = 0;
-    for (int i = 0; i < count; ++i) { mx += gs[i].M * gs[i].N; flop_k = gs[i].K; }
-    // profiler record: one entry, M*N summed over the group (shown as d0 = sum(M*N)/N0, d1 = N0)
-    const int prof = obte_prof_begin(st, 32 + (gs[0].a_kmajor ? 8 : 0) + (gs[0].b_kmajor ? 4 : 0) + gs[0].epilogue, mx / gs[0].N, gs[0].N, flop_k);
-    int rc;
-    const bool add = gs[0].epilogue == OBTE_EPI_ADD;
-    if (gs[0].a_kmajor && gs[0].b_kmajor) rc = add ? launch_group<true, true, OBTE_EPI_ADD>(gp, st) : launch_group<true, true, OBTE_EPI_NONE>(gp, st);
-    else if (gs[0].a_kmajor) rc = add ? launch_group<true, false, OBTE_EPI_ADD>(gp, st) : launch_group<true, false, OBTE_EPI_NONE>(gp, st);
-    else if (gs[0].b_kmajor) rc = add ? launch_group<false, true, OBTE_EPI_ADD>(gp, st) : launch_group<false, true, OBTE_EPI_NONE>(gp, st);
-    else rc = add ? launch_group<false, false, OBTE_EPI_ADD>(gp, st) : launch_group<false, false, OBTE_EPI_NONE>(gp, st);
+    for (int i = count; i < GROUP_MAX; ++i) { gp.g[i] = gp.g[0]; gp.layout[i] = gp.layout[0]; }   // never selected
+    gp.n_class0 = (class0 < wg && class0 % 8 == 0 && (wg - class0) % 8 == 0) ? class0 : 0;
+    // profiler record: one entry; d0 chosen so that 2*d0*d1*d2 is the group's total FLOP
+    const int prof = obte_prof_begin(st, 32 + (count > 1 && gp.layout[count - 1] != gp.layout[0] ? 1 : 0) + (gs[0].epilogue == OBTE_EPI_ADD ? 2 : 0),
+                                     (int64_t)(flop / (2.0 * (double)gs[0].N * (double)gs[0].K) + 0.5), gs[0].N, gs[0].K);
+    const int rc = launch_group(gp, st);
     obte_prof_end(prof, st);
     return rc;
 }

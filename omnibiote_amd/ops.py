@@ -104,19 +104,22 @@ def gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True, epilogue=L.EPI_NONE, aux=N
     return (d, d2) if d2 is not None else d
 
 
-def gemm_grouped(problems, a_kmajor=False, b_kmajor=False, accumulate=False):
-    """Up to four GEMMs of one layout in a single launch (obte_gemm_grouped_bf16).  ``problems`` is a list of
-    (a, b, M, N, K, out); with ``accumulate`` each ``out`` is updated in place (out += A B).  Returns the outs."""
-    assert 1 <= len(problems) <= 4
+def gemm_grouped(problems):
+    """Up to six GEMMs in a single launch (obte_gemm_grouped_bf16).  ``problems`` is a list of dicts with keys
+    a, b, M, N, K, out and optionally a_kmajor / b_kmajor (default False: the weight-gradient layout) and accumulate
+    (out += A B in place).  Put the problems with the longest K first.  Returns the outs."""
+    assert 1 <= len(problems) <= 6
     arr = (L.GemmArgs * len(problems))()
-    for i, (a, b, M, N, K, out) in enumerate(problems):
+    for i, q in enumerate(problems):
+        a, b, M, N, K, out = q["a"], q["b"], q["M"], q["N"], q["K"], q["out"]
+        ak, bk, acc = bool(q.get("a_kmajor", False)), bool(q.get("b_kmajor", False)), bool(q.get("accumulate", False))
         _need(a, "a"); _need(b, "b"); _need(out, "out")
         assert a.numel() == M * K and b.numel() == N * K and out.numel() == M * N
-        arr[i] = L.GemmArgs(_ptr(a), _ptr(b), _ptr(out), _ptr(out) if accumulate else None, None, M, N, K,
-                            K if a_kmajor else M, K if b_kmajor else N, N, int(a_kmajor), int(b_kmajor),
-                            L.EPI_ADD if accumulate else L.EPI_NONE, 1.0, 0.0, 0, 0)
+        arr[i] = L.GemmArgs(_ptr(a), _ptr(b), _ptr(out), _ptr(out) if acc else None, None, M, N, K,
+                            K if ak else M, K if bk else N, N, int(ak), int(bk),
+                            L.EPI_ADD if acc else L.EPI_NONE, 1.0, 0.0, 0, 0)
     L.check(L.lib().obte_gemm_grouped_bf16(arr, len(problems), _stream()), "obte_gemm_grouped_bf16")
-    return [p[5] for p in problems]
+    return [q["out"] for q in problems]
 
 
 def linear_fwd(x2d, w, epilogue=L.EPI_NONE, aux=None, alpha=1.0, dropout=None):

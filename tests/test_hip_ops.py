@@ -452,8 +452,9 @@ def test_gemm_both_tile_widths(monkeypatch, bn):
 
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_gemm_grouped_matches_single_launches(accumulate):
-    """One grouped launch of four weight-gradient shaped products (ragged M/N, K not a multiple of 64) against fp32
-    references and against the single-problem entry point."""
+    """One grouped launch of four weight-gradient shaped products (ragged M/N, K not a multiple of 64) plus a shorter
+    input-gradient shaped product in another layout (the mix a block's backward issues), against fp32 references and
+    against the single-problem entry point."""
     o = ops()
     K = 1000
     shapes = [(520, 264), (256, 1024), (776, 256), (256, 256)]
@@ -461,21 +462,26 @@ def test_gemm_grouped_matches_single_launches(accumulate):
     for i, (M, N) in enumerate(shapes):
         a, b = rnd(K, M, seed=60 + i, scale=0.5), rnd(K, N, seed=70 + i, scale=0.5)
         base = rnd(M, N, seed=80 + i)
-        out = base.clone().to(DEV)
-        probs.append((a.to(DEV), b.to(DEV), M, N, K, out))
+        probs.append(dict(a=a.to(DEV), b=b.to(DEV), M=M, N=N, K=K, out=base.clone().to(DEV), accumulate=accumulate))
         acc = a.float().t() @ b.float()
         refs.append(base.float() + acc.to(BF).float() if accumulate else acc)
         singles.append(o.linear_wgrad(a.to(DEV), b.to(DEV), accumulate_into=base.clone().to(DEV) if accumulate else None))
-    outs = o.gemm_grouped(probs, accumulate=accumulate)
+    # dX = dY W: A k-contiguous [M, K2], B k-strided [K2, N]; never accumulates
+    M5, N5, K5 = 1000, 392, 320
+    dy, w = rnd(M5, K5, seed=90, scale=0.5), rnd(K5, N5, seed=91, scale=0.2)
+    probs.append(dict(a=dy.to(DEV), b=w.to(DEV), M=M5, N=N5, K=K5, out=torch.full((M5, N5), 7.0, dtype=BF, device=DEV), a_kmajor=True))
+    refs.append(dy.float() @ w.float())
+    singles.append(o.linear_dgrad(dy.to(DEV), w.to(DEV)))
+    outs = o.gemm_grouped(probs)
     for got, ref, single in zip(outs, refs, singles):
-        close(got, ref, atol=0.01 * math.sqrt(K) + 0.02, what="grouped wgrad")
+        close(got, ref, atol=0.01 * math.sqrt(K) + 0.02, what="grouped")
         close(got, single.float().cpu(), atol=0.07, what="grouped vs single launch")   # fp32 summation order differs (split-K)
-    with pytest.raises(RuntimeError, match="share layout"):
-        bad = (L().GemmArgs * 2)()
-        a, b, M, N, K_, out = probs[0]
-        bad[0] = L().GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, M, N, K_, M, N, N, 0, 0, 0, 1.0, 0.0, 0, 0)
-        bad[1] = L().GemmArgs(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, M, N, K_, M, N, N, 1, 0, 0, 1.0, 0.0, 0, 0)
-        L().check(L().lib().obte_gemm_grouped_bf16(bad, 2, None), "obte_gemm_grouped_bf16")
+    with pytest.raises(RuntimeError, match="epilogue must be NONE or ADD"):
+        q = probs[0]
+        bad = (L().GemmArgs * 1)()
+        bad[0] = L().GemmArgs(q["a"].data_ptr(), q["b"].data_ptr(), q["out"].data_ptr(), None, None, q["M"], q["N"], K, q["M"], q["N"], q["N"],
+                              0, 0, L().EPI_GELU, 1.0, 0.0, 0, 0)
+        L().check(L().lib().obte_gemm_grouped_bf16(bad, 1, None), "obte_gemm_grouped_bf16")
 
 
 def test_multi_tensor_adamw_matches_single_tensor_kernel():
