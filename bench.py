@@ -74,8 +74,8 @@ def harness_args(cfg, a, world):
 
 KIND_NAMES = {12: "gemm_fwd(NT)", 13: "gemm_fwd(NT)+gelu", 14: "gemm_fwd(NT)+residual", 16: "gemm_fwd(NT)+residual+dropout",
               17: "gemm_fwd(NT)+rope", 8: "gemm_dgrad(NN)", 11: "gemm_dgrad(NN)+gelu_bwd", 0: "gemm_wgrad(TN)",
-              2: "gemm_wgrad(TN)+accumulate", 32: "gemm_wgrad(TN) x4 grouped", 34: "gemm_wgrad(TN)+accumulate x4 grouped",
-              33: "gemm_wgrad(TN) x4 + dgrad(NN) grouped", 35: "gemm_wgrad(TN)+accumulate x4 + dgrad(NN) grouped", 100: "attn_fwd", 101: "attn_bwd"}
+              2: "gemm_wgrad(TN)+accumulate", 32: "gemm_grouped(wgrads)", 34: "gemm_grouped(wgrads)+accumulate",
+              33: "gemm_grouped(wgrads+dgrad)", 35: "gemm_grouped(wgrads+dgrad)+accumulate", 100: "attn_fwd", 101: "attn_bwd"}
 
 
 def collect_profile(cap=200000):

@@ -843,7 +843,6 @@ extern "C" int obte_gemm_grouped_bf16(const obte_gemm_args* gs, int count, obte_
         OBTE_REQUIRE(g->epilogue == OBTE_EPI_NONE || g->epilogue == OBTE_EPI_ADD, "obte_gemm_grouped_bf16: epilogue must be NONE or ADD");
         { const int vrc = validate_args(g); if (vrc != OBTE_OK) return vrc; }
         OBTE_REQUIRE(g->K >= 128, "obte_gemm_grouped_bf16: K must be >= 128 (K=%lld)", (long long)g->K);
-        OBTE_REQUIRE(g->alpha == 1.0f, "obte_gemm_grouped_bf16: alpha must be 1");
         GemmParams& p = gp.g[i];
         fill_params(g, nullptr, p);
         if (g->epilogue == OBTE_EPI_NONE) p.aux = nullptr;
@@ -851,7 +850,7 @@ extern "C" int obte_gemm_grouped_bf16(const obte_gemm_args* gs, int count, obte_
         OBTE_REQUIRE(tm * tn < (1ll << 24), "obte_gemm_grouped_bf16: too many tiles");
         p.tiles_m = (int)tm; p.tiles_n = (int)tn; p.splits = 1;
         p.k_per_split = (int)cdiv64(g->K, BKT);
-        p.alpha = 1.0f;
+        p.alpha = g->alpha;
         p.drop = make_drop(0.f, 0, 0);
         gp.layout[i] = (g->a_kmajor ? 2 : 0) + (g->b_kmajor ? 1 : 0);
         gp.first_wg[i] = wg;

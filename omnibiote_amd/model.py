@@ -159,6 +159,9 @@ class _LinearFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         dx = dw = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            dx, dw = ops.linear_bwd(dy2, x2, w, alpha=ctx.alpha, accumulate_into=_grad_slot(ctx.w_param))
+            return dx.view_as(x), dw, None
         if ctx.needs_input_grad[0]:
             dx = ops.linear_dgrad(dy2, w, alpha=ctx.alpha).view_as(x)
         if ctx.needs_input_grad[1]:

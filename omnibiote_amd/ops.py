@@ -107,7 +107,7 @@ def gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True, epilogue=L.EPI_NONE, aux=N
 def gemm_grouped(problems):
     """Up to six GEMMs in a single launch (obte_gemm_grouped_bf16).  ``problems`` is a list of dicts with keys
     a, b, M, N, K, out and optionally a_kmajor / b_kmajor (default False: the weight-gradient layout) and accumulate
-    (out += A B in place).  Put the problems with the longest K first.  Returns the outs."""
+    (out += alpha A B in place) / alpha.  Put the problems with the longest K first.  Returns the outs."""
     assert 1 <= len(problems) <= 6
     arr = (L.GemmArgs * len(problems))()
     for i, q in enumerate(problems):
@@ -117,7 +117,7 @@ def gemm_grouped(problems):
         assert a.numel() == M * K and b.numel() == N * K and out.numel() == M * N
         arr[i] = L.GemmArgs(_ptr(a), _ptr(b), _ptr(out), _ptr(out) if acc else None, None, M, N, K,
                             K if ak else M, K if bk else N, N, int(ak), int(bk),
-                            L.EPI_ADD if acc else L.EPI_NONE, 1.0, 0.0, 0, 0)
+                            L.EPI_ADD if acc else L.EPI_NONE, float(q.get("alpha", 1.0)), 0.0, 0, 0)
     L.check(L.lib().obte_gemm_grouped_bf16(arr, len(problems), _stream()), "obte_gemm_grouped_bf16")
     return [q["out"] for q in problems]
 
@@ -154,6 +154,41 @@ def linear_wgrad(dy2d, x2d, alpha=1.0, accumulate_into=None):
     if accumulate_into is not None:
         return gemm(dy2d, x2d, N, K, M, False, False, L.EPI_ADD, accumulate_into, alpha, out=accumulate_into)
     return gemm(dy2d, x2d, N, K, M, False, False, L.EPI_NONE, None, alpha)
+
+
+def _tiles256(m, n):
+    return ((m + 255) // 256) * ((n + 255) // 256)
+
+
+def linear_bwd_pair_is_grouped(M, N, K) -> bool:
+    """Whether linear_bwd (dy [M,N], x [M,K], W [N,K]) takes the single grouped launch: the input gradient has too few
+    256x256 tiles for the chip but a long K (= N), the weight gradient has many tiles of short K (= M), and the two
+    halves carry comparable work — the readout (N = vocabulary).  OBTE_GROUPED_LM=0/1 overrides."""
+    import os
+    e = os.environ.get("OBTE_GROUPED_LM", "")
+    if e in ("0", "1"):
+        return e == "1" and M >= 128 and N >= 128
+    td, tw = _tiles256(M, K), _tiles256(N, K)
+    if not (M >= 1024 and N >= 8 * M and td <= 160 and td % 8 == 0 and tw % 8 == 0 and tw >= 256):
+        return False
+    work_d, work_w = td * N, tw * M
+    return 0.5 <= work_d / work_w <= 2.0
+
+
+def linear_bwd(dy2d, x2d, w, alpha=1.0, accumulate_into=None):
+    """Both gradients of y = alpha x W^T: dx = alpha dy W, dW = alpha dy^T x (added into ``accumulate_into`` when given).
+    Returns (dx, dW or None).  One grouped launch when linear_bwd_pair_is_grouped, else the two single launches."""
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    if not linear_bwd_pair_is_grouped(M, N, K):
+        dx = linear_dgrad(dy2d, w, alpha=alpha)
+        dw = linear_wgrad(dy2d, x2d, alpha=alpha, accumulate_into=accumulate_into)
+        return dx, (None if accumulate_into is not None else dw)
+    dx = torch.empty((M, K), dtype=bf16, device=dy2d.device)
+    dw = accumulate_into if accumulate_into is not None else torch.empty((N, K), dtype=bf16, device=dy2d.device)
+    gemm_grouped([dict(a=dy2d, b=w, M=M, N=K, K=N, out=dx, a_kmajor=True, alpha=alpha),
+                  dict(a=dy2d, b=x2d, M=N, N=K, K=M, out=dw, accumulate=accumulate_into is not None, alpha=alpha)])
+    return dx, (None if accumulate_into is not None else dw)
 
 
 # --------------------------------------------------------------------------------------------------------- RoPE

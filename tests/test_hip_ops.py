@@ -484,6 +484,34 @@ def test_gemm_grouped_matches_single_launches(accumulate):
         L().check(L().lib().obte_gemm_grouped_bf16(bad, 1, None), "obte_gemm_grouped_bf16")
 
 
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_linear_bwd_grouped_pair_matches_two_launches(monkeypatch, accumulate):
+    """The readout's backward as one grouped launch (input gradient with K = vocabulary beside the weight gradient with
+    K = tokens, alpha = 1/width_mult on both) against the two single launches and fp32 references."""
+    o = ops()
+    M, N, K, alpha = 384, 2048, 256, 0.25
+    dy, x, w = rnd(M, N, seed=11, scale=0.3), rnd(M, K, seed=12), rnd(N, K, seed=13, scale=0.2)
+    base = rnd(N, K, seed=14)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OBTE_GROUPED_LM", mode)
+        assert o.linear_bwd_pair_is_grouped(M, N, K) == (mode == "1")
+        slot = base.clone().to(DEV) if accumulate else None
+        dx, dw = o.linear_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), alpha=alpha, accumulate_into=slot)
+        res[mode] = (dx.cpu(), (slot if accumulate else dw).cpu())
+    dx_ref = alpha * (dy.float() @ w.float())
+    dw_new = alpha * (dy.float().t() @ x.float())
+    dw_ref = base.float() + dw_new.to(BF).float() if accumulate else dw_new
+    for mode in ("0", "1"):
+        close(res[mode][0], dx_ref, atol=0.05, what=f"dx grouped={mode}")
+        close(res[mode][1], dw_ref, atol=0.05, what=f"dW grouped={mode}")
+    close(res["1"][0], res["0"][0].float(), atol=0.03, what="dx grouped vs single")
+    close(res["1"][1], res["0"][1].float(), atol=0.03, what="dW grouped vs single")
+    monkeypatch.delenv("OBTE_GROUPED_LM")
+    assert o.linear_bwd_pair_is_grouped(8192, 65536, 1024) and not o.linear_bwd_pair_is_grouped(8192, 65536, 2048)
+    assert not o.linear_bwd_pair_is_grouped(8192, 4096, 1024)
+
+
 def test_multi_tensor_adamw_matches_single_tensor_kernel():
     """The multi-tensor launch (<= 32 tensors per kernel, per-tensor lr / weight decay / step) must reproduce the
     single-tensor kernel bit for bit, and the multi-tensor sum of squares must equal the sum of the single ones."""
