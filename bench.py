@@ -56,6 +56,8 @@ def parse():
     p.add_argument("--dropout", type=float, default=0.0, help="0.0 = the parity regime (default); 0.1 = the reference's default")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
+    p.add_argument("--pipeline_streams", type=int, default=2, choices=[1, 2],
+                   help="2: forward of micro-batch j+1 beside the backward of micro-batch j on a second HIP stream (bitwise the same results)")
     p.add_argument("--plan_cache", default="", help="JSON file of tuned GEMM plans: loaded if present (no tuning launches), else tuned and written")
     p.add_argument("--shapes_out", default="", help="write the per-shape launch table (from the profiler step) to this file")
     return p.parse_args()
@@ -187,7 +189,7 @@ def main():
     total_iters = 1000
     opt, sched = TE.build_optimizer(m, h, total_iters)
     step = TE.TrainStep(model, opt, sched, mini_batch_size=a.mini_batch_size, n_head=cfg["n_head"],
-                        lm_head_impl="masked" if a.masked_lm_head else "dense")
+                        lm_head_impl="masked" if a.masked_lm_head else "dense", pipeline_streams=a.pipeline_streams)
     rng = np.random.default_rng(1234 + rank)
     T = cfg["ctx_len"]
     # synthetic batches resident in HBM before timing; a fresh one per step
@@ -218,11 +220,15 @@ def main():
 
     roofline = None
     if not a.no_roofline and rank == 0:
+        # per-launch durations are only meaningful when launches do not share the chip: the profiled step runs on one
+        # stream (the timed steps above overlap two micro-batches, which stretches every kernel that has company)
+        step.pipeline_streams = 1
         _lib.lib().obte_profile_enable(1)
         step(batches[0])
         torch.cuda.synchronize()
         ms, dims, kind = collect_profile()
         _lib.lib().obte_profile_enable(0)
+        step.pipeline_streams = a.pipeline_streams
         if len(ms):
             roofline = roofline_from_profile(ms, dims, kind, 1)
             if a.shapes_out:

@@ -147,7 +147,7 @@ class TrainStep:
 
     def __init__(self, model, optimizer, scheduler=None, *, mini_batch_size: int, n_head: int, use_padding: bool = False,
                  loss_impl: str = "fused", mask_impl: str = "ranges", sync_every_micro_step: bool = False,
-                 max_grad_norm: float = 1.0, lm_head_impl: str = "dense"):
+                 max_grad_norm: float = 1.0, lm_head_impl: str = "dense", pipeline_streams: int = 1):
         self.model, self.optimizer, self.scheduler = model, optimizer, scheduler
         self.mini, self.n_head, self.use_padding = mini_batch_size, n_head, use_padding
         self.loss_impl, self.mask_impl = loss_impl, mask_impl
@@ -159,8 +159,17 @@ class TrainStep:
         # contribute exact zeros) for 1/6.7 of the lm_head work and none of the 1 GiB logits tensors.
         assert lm_head_impl in ("dense", "masked")
         self.lm_head_impl = lm_head_impl
-        self._dlogits = None
+        self._dlogits = {}
         self._all_ranges = None
+        # pipeline_streams = 2: micro-batches alternate between two HIP streams so that the forward of micro-batch j+1
+        # runs beside the backward of micro-batch j (kernel tails and half-filled grids of one fill with work of the
+        # other).  The backward passes stay strictly ordered (an event per micro-batch), so every gradient buffer sees
+        # the same read-modify-write sequence as on one stream: results are bitwise those of pipeline_streams = 1.
+        assert pipeline_streams in (1, 2)
+        self.pipeline_streams = pipeline_streams
+        self._streams = None
+        self._slot = 0
+        self._prev_bwd_done = None
 
     def _inplace(self, enabled: bool):
         if self.loss_impl != "fused" or os.environ.get("OBTE_NO_INPLACE_ACCUM") == "1":   # CPU-oracle tests / A-B switch
@@ -182,9 +191,10 @@ class TrainStep:
     def _loss_backward(self, logits, targets, mask, n_accum):
         if self.loss_impl == "fused":
             from . import ops
-            if self._dlogits is None:
-                self._dlogits = ops.DLogitsBuffer()
-            loss, dlogits = ops.masked_ce(logits, targets, mask, n_accum, reuse=self._dlogits)
+            if self._slot not in self._dlogits:   # one reusable d(logits) buffer per stream in flight
+                self._dlogits[self._slot] = ops.DLogitsBuffer()
+            loss, dlogits = ops.masked_ce(logits, targets, mask, n_accum, reuse=self._dlogits[self._slot])
+            self._order_backward()
             logits.backward(dlogits)
             return loss.detach()
         # the reference's own three lines (train_encoder.py:301-305)
@@ -193,6 +203,11 @@ class TrainStep:
         loss = loss.sum() / mask.reshape(-1).sum()
         loss.backward()
         return loss.detach().float()
+
+    def _order_backward(self):
+        """Pipelined micro-batches: this backward may start only after the previous micro-batch's backward finished."""
+        if self._prev_bwd_done is not None:
+            torch.cuda.current_stream().wait_event(self._prev_bwd_done)
 
     def _masked_rows_loss_backward(self, x, y, mk, attn_mask, n_accum):
         """Readout + CE on the masked rows only.  The row indices come from the host-side MLM draw (no device sync)."""
@@ -207,6 +222,7 @@ class TrainStep:
         logits = core.lm_head(emb_rows)
         ones = torch.ones(rows.numel(), dtype=torch.bool, device=x.device)
         loss, dlogits = ops.masked_ce(logits, y.reshape(-1).index_select(0, rows), ones, n_accum)
+        self._order_backward()
         logits.backward(dlogits)
         return loss.detach()
 
@@ -225,24 +241,50 @@ class TrainStep:
         cum_loss = torch.zeros((), dtype=torch.float32, device=input_ids.device)
         from . import masks
         self._all_ranges = masks.RangeMask.from_tokens(input_ids, padding=self.use_padding, group=self.mini).key_ranges
+        pipelined = (self.pipeline_streams == 2 and input_ids.is_cuda and self.loss_impl == "fused" and n_accum > 2
+                     and not self.sync_every)
+        main = torch.cuda.current_stream() if input_ids.is_cuda else None
+        if pipelined:
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+                # gradients are produced on the side streams by design; the engine's cross-stream sync is what we want
+                warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+                if warn_off is not None:
+                    warn_off(False)
+            for st in self._streams:
+                st.wait_stream(main)
+        partial = [cum_loss, torch.zeros_like(cum_loss)] if pipelined else [cum_loss]
+        self._prev_bwd_done = None
         for j in range(n_accum):
             self._mb = j
             x = masked_ids[j * self.mini:(j + 1) * self.mini]
             y = input_ids[j * self.mini:(j + 1) * self.mini]
-            attn_mask = self._mask(y, dtype, j)
             last = j == n_accum - 1
-            ctx = contextlib.nullcontext()
-            if hasattr(self.model, "no_sync") and not last and not self.sync_every:
-                ctx = self.model.no_sync()
-            # all but the last micro-batch: nobody observes the per-micro-batch gradients, so the big matrices are
-            # accumulated by the wgrad epilogues themselves (model.accumulate_grads_inplace)
-            with ctx, self._inplace(not last and not self.sync_every):
-                mk = mask[j * self.mini:(j + 1) * self.mini]
-                if self.lm_head_impl == "masked":
-                    cum_loss += self._masked_rows_loss_backward(x, y, mk, attn_mask, n_accum)
-                else:
-                    logits = self.model(x, attn_mask=attn_mask)
-                    cum_loss += self._loss_backward(logits, y, mk, n_accum)
+            side = pipelined and not last
+            if pipelined and last:   # the last micro-batch (DDP's reducer hooks) runs on the caller's stream, after everything
+                for st in self._streams:
+                    main.wait_stream(st)
+                self._prev_bwd_done = None
+            self._slot = (j % 2) if side else 0
+            with (torch.cuda.stream(self._streams[j % 2]) if side else contextlib.nullcontext()):
+                attn_mask = self._mask(y, dtype, j)
+                ctx = contextlib.nullcontext()
+                if hasattr(self.model, "no_sync") and not last and not self.sync_every:
+                    ctx = self.model.no_sync()
+                # all but the last micro-batch: nobody observes the per-micro-batch gradients, so the big matrices are
+                # accumulated by the wgrad epilogues themselves (model.accumulate_grads_inplace)
+                with ctx, self._inplace(not last and not self.sync_every):
+                    mk = mask[j * self.mini:(j + 1) * self.mini]
+                    if self.lm_head_impl == "masked":
+                        partial[self._slot] += self._masked_rows_loss_backward(x, y, mk, attn_mask, n_accum)
+                    else:
+                        logits = self.model(x, attn_mask=attn_mask)
+                        partial[self._slot] += self._loss_backward(logits, y, mk, n_accum)
+                        del logits
+                if side:
+                    self._prev_bwd_done = torch.cuda.current_stream().record_event()
+        if pipelined:
+            cum_loss = partial[0] + partial[1]
         if isinstance(self.optimizer, FusedAdamW):
             self.optimizer.step(max_norm=self.max_grad_norm)
         else:
@@ -354,6 +396,8 @@ def parse_args(argv=None):
     # additions
     p.add_argument("--max_steps", type=int, default=0, help="stop after this many optimizer steps (0 = token budget)")
     p.add_argument("--multi_document", action="store_true", default=False, help="synthetic rows with interior EOS")
+    p.add_argument("--pipeline_streams", type=int, default=2, choices=[1, 2],
+                   help="2: overlap the forward of micro-batch j+1 with the backward of micro-batch j (same results)")
     return p.parse_args(argv)
 
 
@@ -433,7 +477,8 @@ def run(args):
     model = wrap_ddp(m, local) if world > 1 else m
     total_iters = int(args.token_budget / (world * batch_size * args.ctx_len))
     opt, sched = build_optimizer(m, args, total_iters)
-    step = TrainStep(model, opt, sched, mini_batch_size=args.mini_batch_size, n_head=args.n_head, use_padding=args.use_padding)
+    step = TrainStep(model, opt, sched, mini_batch_size=args.mini_batch_size, n_head=args.n_head, use_padding=args.use_padding,
+                     pipeline_streams=getattr(args, "pipeline_streams", 1))
     rng = np.random.default_rng(1234 + rank)
     next_batch, source = make_batch_source(args, batch_size, device, rng)
     if rank == 0:

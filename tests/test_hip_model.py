@@ -309,6 +309,48 @@ def test_masked_rows_lm_head_gives_the_dense_loss_and_gradients():
         assert rel <= 0.02, (k, rel)
 
 
+@pytest.mark.parametrize("impl", ["dense", "masked"])
+def test_two_stream_micro_batch_pipeline_is_bitwise_the_single_stream_step(impl):
+    """TrainStep(pipeline_streams=2) overlaps the forward of micro-batch j+1 with the backward of micro-batch j on a
+    second stream but keeps the backward passes ordered: loss, gradients and updated weights must equal the
+    single-stream step bit for bit (any race on a gradient or scratch buffer would show here)."""
+    from omnibiote_amd import train_encoder as TE
+    from omnibiote_amd.mup_compat import set_base_shapes
+    from omnibiote_amd.model import OmniBioTA, OmniBioTAConfig
+    C, H, Lyr, V, T, rows, mini = 256, 2, 2, 1024, 128, 24, 4     # 6 micro-batches
+    w = R.hash_weights(R.RefConfig(block_size=T, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C))
+    ids = torch.from_numpy(TE.synthetic_rows(rows, T, V, np.random.default_rng(0), single_document=False)).to(DEV)
+    out = {}
+    for streams in (1, 2):
+        c = OmniBioTAConfig(); c.block_size, c.vocab_size, c.n_layer, c.n_head, c.n_embd, c.dropout, c.flash = T, V, Lyr, H, C, 0.0, True
+        m = OmniBioTA(c)
+        cb = OmniBioTAConfig(); cb.block_size, cb.vocab_size, cb.n_layer, cb.dropout, cb.flash = T, V, Lyr, 0.0, True
+        cb.n_embd, cb.n_head = 24, 3
+        base = OmniBioTA(cb)
+        cb.n_embd, cb.n_head = 48, 12
+        delta = OmniBioTA(cb)
+        set_base_shapes(m, base, delta=delta, rescale_params=False)
+        m.load_state_dict(w, strict=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.to(BF)
+        m.to(DEV)
+        opt = TE.FusedAdamW(m.parameters(), lr=1e-3)
+        step = TE.TrainStep(m, opt, None, mini_batch_size=mini, n_head=H, lm_head_impl=impl, pipeline_streams=streams)
+        losses = []
+        for it in range(3):
+            np.random.seed(7 + it)
+            losses.append(step(ids)["loss"].item())
+        torch.cuda.synchronize()
+        out[streams] = (losses, {k: p.detach().clone() for k, p in m.named_parameters()},
+                        {k: p.grad.clone() for k, p in m.named_parameters()})
+    for a, b in zip(out[1][0], out[2][0]):   # the reported loss is summed per stream first: equal up to fp32 rounding
+        assert abs(a - b) <= 1e-5 * abs(a), (out[1][0], out[2][0])
+    for k in out[1][1]:
+        assert torch.equal(out[1][2][k], out[2][2][k]), "grad " + k
+        assert torch.equal(out[1][1][k], out[2][1][k]), "weight " + k
+
+
 def test_eval_style_usage_with_padding_mask_and_odd_length(golden_dir):
     """How the eval scripts call the model (evals/gue.py:15-21,111): a dense additive mask in which everything at and
     after the first PAD is -1e9 in both directions (so whole rows are masked), odd sequence length, CLS pooling,
