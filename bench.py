@@ -231,6 +231,16 @@ def main():
         step.pipeline_streams = a.pipeline_streams
         if len(ms):
             roofline = roofline_from_profile(ms, dims, kind, 1)
+            # HBM bytes per launch of the GEMM family: PMC counters cannot be read from inside this process, so the
+            # figure comes from the committed rocprofv3 --pmc passes over this same workload (tools/pmc_traffic.py)
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_family_traffic.json")
+            default_workload = (a.config == "small" and not a.masked_lm_head and a.dropout == 0.0 and not a.multi_document
+                                and a.rows_per_rank == 128 and a.mini_batch_size == 8)
+            if default_workload and os.path.exists(pmc):
+                with open(pmc) as f:
+                    t = json.load(f)
+                roofline["traffic"] = round(t["traffic_bytes_per_launch"])
+                roofline["traffic_unit"] = "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_gemm_family_traffic.json)"
             if a.shapes_out:
                 tab = {}
                 for t, d, k in zip(ms, dims, kind):
