@@ -1,0 +1,32 @@
+"""Attention micro-benchmark on the hot-path shape (B=8, H=8, T=1024, hs=128, single-document key ranges).
+    python tools/attn_bench.py [--reps 10] [--T 1024] [--hs 128]"""
+import argparse, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from omnibiote_amd import ops, masks
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--B", type=int, default=8); ap.add_argument("--H", type=int, default=8)
+ap.add_argument("--T", type=int, default=1024); ap.add_argument("--hs", type=int, default=128)
+a = ap.parse_args()
+B, H, T, hs = a.B, a.H, a.T, a.hs
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(0)
+qkv = torch.randn(B, T, 3 * H * hs, device=dev, generator=g).to(torch.bfloat16)
+d_o = torch.randn(B, T, H * hs, device=dev, generator=g).to(torch.bfloat16)
+tok = torch.randint(20, 100, (B, T), device=dev)
+spec = ops.MaskSpec(ranges=masks.RangeMask.from_tokens(tok).key_ranges)
+scale = 8.0 / (H * hs)
+def timeit(fn):
+    for _ in range(2): fn()
+    torch.cuda.synchronize(); ts = []
+    for _ in range(a.reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1))
+    ts.sort(); return ts[len(ts) // 2] * 1e3
+o, lse = ops.attn_fwd(qkv, B, T, H, hs, scale, spec)
+tf = timeit(lambda: ops.attn_fwd(qkv, B, T, H, hs, scale, spec))
+tb = timeit(lambda: ops.attn_bwd(qkv, o, d_o, lse, B, T, H, hs, scale, spec))
+fl = 4.0 * B * H * T * T * hs
+print(f"attn fwd {tf:8.1f} us {fl / tf / 1e6:7.1f} TFLOP/s | bwd {tb:8.1f} us {2.5 * fl / tb / 1e6:7.1f} TFLOP/s (algorithmic)", flush=True)
