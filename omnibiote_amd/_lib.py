@@ -9,7 +9,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libomnibiote_hip.so")
+LIB_PATH = os.environ.get("OBTE_LIB_PATH") or os.path.join(_HERE, "libomnibiote_hip.so")   # override: A/B builds
 
 c_bf16_p = C.c_void_p
 c_f32_p = C.c_void_p

@@ -113,10 +113,19 @@ struct TileDma {
     // g: address of the tile's first row (head column applied); bytes_left: bytes from g to the end of the rows that
     // may be read (the batch element's last row)
     __device__ __forceinline__ void issue(const bf16* g, int64_t bytes_left, char* tile, int wave) const {
+        // through inline asm (common.h lds_dma16): with the builtin hipcc drains vmcnt in front of the next LDS read,
+        // i.e. waits for the tile it was asked to prefetch before computing on the current one
+#ifdef OBTE_DMA_BUILTIN
         __amdgpu_buffer_rsrc_t rsrc = make_rsrc(g, bytes_left);
 #pragma unroll
         for (int i = 0; i < NP; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(tile + (wave + 4 * i) * 1024), 16, voff[i], 0, 0, 0);
+#else
+        const i32x4_t rsrc = make_rsrc_words(g, bytes_left);
+        const uint32_t base = lds_addr_of(tile) + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) lds_dma16(rsrc, base + 4 * i * 1024, voff[i]);
+#endif
     }
 };
 

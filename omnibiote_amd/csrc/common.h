@@ -66,6 +66,26 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, in
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
 }
 
+// LDS-DMA issued through inline asm.  With the builtin, hipcc's wait-count pass treats every later LDS read that it
+// cannot disambiguate (all ds_read_b64_tr_b16, and any read placed after an issue) as possibly aliasing the pending
+// DMA and inserts s_waitcnt vmcnt(0) in front of it — which silently turns a counted-vmcnt ring into
+// load-everything-then-compute.  Issued this way the compiler sees neither an LDS write nor a vmcnt event: ordering is
+// entirely the kernel's explicit s_waitcnt vmcnt(N) + s_barrier, which is what the ring relies on anyway.
+// rsrc: raw buffer descriptor words; lds_addr: wave-uniform LDS byte address of the 1-KiB destination (lane i lands at
+// +16 i); voff: per-lane byte offset into the buffer (out-of-range lanes write zeros).
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_t make_rsrc_words(const void* base, int64_t bytes) {
+    const uint32_t n = bytes <= 0 ? 0u : (bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)bytes);
+    const uint64_t b = (uint64_t)base;
+    return i32x4_t{(int)(uint32_t)b, (int)(uint32_t)((b >> 32) & 0xFFFFu), (int)n, 0x00020000};
+}
+__device__ __forceinline__ void lds_dma16(i32x4_t rsrc, uint32_t lds_addr, int voff) {
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");   // m0 is a reserved register: no kernel here mixes this with compiler-managed uses of it
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(p);
+}
+
 // ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a
 // 4 x 16 block of 16-bit elements; lane i receives column i of the 4 rows (row q in element q).
 __device__ __forceinline__ bf16x4 lds_read_tr16(const void* lds_addr) {

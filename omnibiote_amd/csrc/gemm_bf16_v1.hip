@@ -61,12 +61,11 @@ __device__ __forceinline__ void dma_offsets(int wave, int lane, int64_t ld, int 
 }
 
 __device__ __forceinline__ void dma_tile(const bf16* origin, int64_t elems_left, const int (&voff)[4], char* lds_tile, int wave) {
-    __amdgpu_buffer_rsrc_t rsrc = make_rsrc(origin, elems_left * 2);
+    // through inline asm (common.h lds_dma16): the builtin makes hipcc drain vmcnt in front of later LDS reads
+    const i32x4_t rsrc = make_rsrc_words(origin, elems_left * 2);
+    const uint32_t base = lds_addr_of(lds_tile) + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int slot = i * 4 + wave;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + slot * 1024), 16, voff[i], 0, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i) lds_dma16(rsrc, base + i * 4 * 1024, voff[i]);
 }
 
 // Fragment of 16 (m or n) x 32 (k) for v_mfma_f32_16x16x32_bf16: lane l holds index (l&15), k = 8*(l>>4)+j.

@@ -85,10 +85,17 @@ __device__ __forceinline__ void dma_offsets(int wave, int lane, int64_t ld, int 
 
 template <int NP>
 __device__ __forceinline__ void dma_tile(const bf16* origin, int64_t elems_left, const int (&voff)[NP], char* lds_tile, int wave) {
+#ifdef OBTE_DMA_BUILTIN
     __amdgpu_buffer_rsrc_t rsrc = make_rsrc(origin, elems_left * 2);
 #pragma unroll
     for (int i = 0; i < NP; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + (wave + 8 * i) * 1024), 16, voff[i], 0, 0, 0);
+#else
+    const i32x4_t rsrc = make_rsrc_words(origin, elems_left * 2);
+    const uint32_t base = lds_addr_of(lds_tile) + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) lds_dma16(rsrc, base + 8 * i * 1024, voff[i]);
+#endif
 }
 
 // 16 (m or n) x 32 (k) fragment for v_mfma_f32_16x16x32_bf16: lane l holds index (l&15), k = 8*(l>>4)+j.
@@ -349,8 +356,10 @@ OBTE_INST(false, false, 256)
 // first touch for its L2, so each burst sees the beyond-L2 latency).  Splitting the ring into 32-k half-stages lets the
 // refill of a slot start as soon as ITS fragments are in registers: three half-stages (96 KiB) are in flight in
 // steady state and each has three half-steps (1.5 K-tiles of MFMA work) to land.  One barrier per half-step.
-//   step u:  wait half-stage u+1 (vmcnt(8): u+2, u+3 stay in flight) | barrier | read F(u+1) | issue u+4 -> slot u&3 |
-//            MFMA F(u)
+//   step u:  wait half-stage u+1 (vmcnt(8): u+2, u+3 stay in flight) | barrier | 4 x { read 3 fragments of F(u+1),
+//            issue one LDS-DMA piece of u+4 -> slot u&3, 8 MFMAs of F(u) }
+// The LDS-DMA is issued through inline asm (common.h lds_dma16): with the builtin, hipcc put an s_waitcnt vmcnt(0) in
+// front of every transposing LDS read, i.e. drained the whole ring at each half-step for the k-strided layouts.
 // k-contiguous half image: [256 rows][32 k], 64-B rows, chunk c of row r at c ^ ((4 - (r>>2)) & 3) (conflict-free
 // ds_read_b128 for the 16x32 fragment); k-strided half image: [32 k][256], as above.
 constexpr int H_TILE = BM * 32 * 2;             // 16 KiB per operand per half-stage
@@ -446,21 +455,40 @@ __device__ __forceinline__ void v3_tile(const GemmParams& p, const int wgid, cha
     __builtin_amdgcn_s_barrier();
     load_frags(0, a0, b0);
     int u = 0;
+    // Steady state, hand-interleaved and pinned with sched_barrier: group g of half-step u = {A fragment g and
+    // B fragments 2g, 2g+1 of half-step u+1, LDS-DMA piece g of half-step u+4 (slot u&3: every wave holds F(u) in
+    // registers since the barrier), the 8 MFMAs of n sub-tiles 2g, 2g+1 of half-step u}.
+    auto istep = [&](int uu, const bf16x8 (&af)[4], const bf16x8 (&bfr)[NJ], bf16x8 (&an)[4], bf16x8 (&bn)[NJ]) {
+        const char* ta = smem + ((uu + 1) & 3) * H_STAGE;
+        const char* tb = ta + H_TILE;
+        const int64_t k0 = (int64_t)kt0 * BKT + (int64_t)(uu + 4) * 32;
+        const int64_t ao = A_KMAJOR ? (m0 * p.lda + k0) : (k0 * p.lda + m0);
+        const int64_t bo = B_KMAJOR ? (n0 * p.ldb + k0) : (k0 * p.ldb + n0);
+        const i32x4_t ra = make_rsrc_words(p.a + ao, (p.a_elems - ao) * 2);
+        const i32x4_t rb = make_rsrc_words(p.b + bo, (p.b_elems - bo) * 2);
+        const uint32_t lds_st = lds_addr_of(smem + (uu & 3) * H_STAGE) + wave * 1024;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            an[g] = load_frag_h<A_KMAJOR>(ta, wm * 64 + g * 16, lane);
+            bn[2 * g] = load_frag_h<B_KMAJOR>(tb, wn * 128 + (2 * g) * 16, lane);
+            bn[2 * g + 1] = load_frag_h<B_KMAJOR>(tb, wn * 128 + (2 * g + 1) * 16, lane);
+            if (g < 2) lds_dma16(ra, lds_st + 8 * g * 1024, voff_a[g]);
+            else lds_dma16(rb, lds_st + H_TILE + 8 * (g - 2) * 1024, voff_b[g - 2]);
+#pragma unroll
+            for (int ni = 2 * g; ni < 2 * g + 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     for (; u + 4 < nh; u += 2) {
         __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0): half-stage u+1 landed, F(u) reads complete
         __builtin_amdgcn_s_barrier();
-        load_frags(u + 1, a1, b1);
-        issue(u + 4);                         // slot u&3: every wave holds F(u) in registers since the barrier
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
+        istep(u, a0, b0, a1, b1);
         __builtin_amdgcn_s_waitcnt(0x0078);
         __builtin_amdgcn_s_barrier();
-        load_frags(u + 2, a0, b0);
-        issue(u + 5);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
+        istep(u + 1, a1, b1, a0, b0);
     }
     // last four half-steps (u == nh - 4): nothing left to issue, the waits count down
     __builtin_amdgcn_s_waitcnt(0x0078);

@@ -18,7 +18,7 @@ from . import ops
 _done: Dict[tuple, tuple] = {}
 
 
-def _time_once(a, b, M, N, K, ak, bk, epi, aux, out, reps=3) -> float:
+def _time_once(a, b, M, N, K, ak, bk, epi, aux, out, reps=6) -> float:
     ops.gemm(a, b, M, N, K, ak, bk, epi, aux, out=out)
     torch.cuda.synchronize()
     best = float("inf")
