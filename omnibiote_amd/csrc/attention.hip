@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_fwd_kernel(AttnParams 
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     const float scale2 = p.scale * LOG2E;
 
+#ifdef OBTE_ATTN_FWD_STAGE
     TileStage<D, 64> sk, sv;
     if (t_begin < t_end) {
         sk.load(kbase + (int64_t)t_begin * 64 * ld, ld, T - t_begin * 64, tid);
@@ -216,14 +217,33 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_fwd_kernel(AttnParams 
         sv.store(smem + TB, tid);
     }
     __syncthreads();
+#else
+    // K/V tiles by LDS-DMA (asm issue, see common.h): no staging registers, no ds_write — the forward is issue-bound
+    TileDma<D, 64> dma;
+    dma.init(wave, lane, ld);
+    auto issue_kv = [&](int t, int stage) {
+        const int64_t row0 = (int64_t)t * 64;
+        const int64_t rows_left = ((int64_t)T - row0) * ld;
+        char* st = smem + stage * 2 * TB;
+        dma.issue(kbase + row0 * ld, (rows_left - (C + hd * D)) * 2, st, wave);
+        dma.issue(vbase + row0 * ld, (rows_left - (2 * C + hd * D)) * 2, st + TB, wave);
+    };
+    if (t_begin < t_end) issue_kv(t_begin, 0);
+    dma_wait_all();
+    __syncthreads();
+#endif
 
     for (int t = t_begin; t < t_end; ++t) {
         const int cur = (t - t_begin) & 1;
         const bool more = t + 1 < t_end;
+#ifdef OBTE_ATTN_FWD_STAGE
         if (more) {   // issue early: the loads fly under this tile's MFMA work, the LDS write follows it
             sk.load(kbase + (int64_t)(t + 1) * 64 * ld, ld, T - (t + 1) * 64, tid);
             sv.load(vbase + (int64_t)(t + 1) * 64 * ld, ld, T - (t + 1) * 64, tid);
         }
+#else
+        if (more) issue_kv(t + 1, cur ^ 1);
+#endif
         const char* Kt = smem + cur * 2 * TB;
         const char* Vt = Kt + TB;
         const int key0 = t * 64;
@@ -294,10 +314,14 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_fwd_kernel(AttnParams 
             for (int dt = 0; dt < ND; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Vt, 16 * kk, dt, lane), pf, o[dt], 0, 0, 0);
         }
+#ifdef OBTE_ATTN_FWD_STAGE
         if (more) {
             sk.store(smem + (cur ^ 1) * 2 * TB, tid);
             sv.store(smem + (cur ^ 1) * 2 * TB + TB, tid);
         }
+#else
+        dma_wait_all();
+#endif
         __syncthreads();
     }
 
