@@ -248,26 +248,31 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_fwd_kernel(AttnParams 
         const char* Vt = Kt + TB;
         const int key0 = t * 64;
 
+        // The softmax arithmetic is what bounds this kernel (measured: ~11 VALU instructions per MFMA), so it is kept
+        // minimal: scores start from an inline-zero accumulator (no register clears), the scale is folded into the
+        // exponent's FMA (max is taken on raw scores), and the running maximum is only moved — with the rescale of O
+        // that goes with it — when some row's maximum grew by more than 2^6 (exact in exact arithmetic; P, l and O are
+        // simply carried at up to 64x their usual magnitude in fp32 / bf16, whose precision is relative).
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         f32x16 sc[2];
+        sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 0, 0, lane), qf[0], zero16, 0, 0, 0);
+        sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 32, 0, lane), qf[0], zero16, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sc[0][r] = 0.f; sc[1][r] = 0.f; }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
+        for (int s = 1; s < NS; ++s) {
             sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 0, s, lane), qf[s], sc[0], 0, 0, 0);
             sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 32, s, lane), qf[s], sc[1], 0, 0, 0);
         }
-        // scores in the log2 domain, plus mask
+        if (MODE == MASK_DENSE) {   // scores in the log2 domain, plus the additive mask
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x = sc[mt][r] * scale2;
-                if (MODE == MASK_DENSE) {
+                for (int r = 0; r < 16; ++r) {
+                    float x = sc[mt][r] * scale2;
                     const int key = key0 + 32 * mt + acc_row(r, h);
                     if (key < T) x += bf2f(mrow[key]) * LOG2E;
+                    sc[mt][r] = x;
                 }
-                sc[mt][r] = x;
-            }
+        }
         const bool inside = key0 >= ks && key0 + 64 <= ke;
         if (!__all(inside)) {
 #pragma unroll
@@ -284,15 +289,25 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_fwd_kernel(AttnParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[mt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m, mx);
-        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = fast_exp2(m - m_safe);
+        const float sx = MODE == MASK_DENSE ? 1.0f : scale2;   // what turns a stored score into log2 units
+        const float m_new = fmaxf(m, mx * sx);
+        float m_safe = m;
+        if (__any(m == -INFINITY || m_new - m > 6.0f)) {
+            m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = fast_exp2(m - m_safe);
+            l *= alpha;
+            m = m_new;
+#pragma unroll
+            for (int i = 0; i < ND; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
         float rs = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float pv = fast_exp2(sc[mt][r] - m_safe);
+                float pv = fast_exp2(__builtin_fmaf(sc[mt][r], sx, -m_safe));
                 rs += pv;   // the normaliser uses the un-dropped probabilities
                 if (DROP) {
                     const uint64_t di = (((uint64_t)b * p.H + hd) * T + q_c) * (uint64_t)T + (uint64_t)(key0 + 32 * mt + acc_row(r, h));
@@ -300,12 +315,7 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_fwd_kernel(AttnParams 
                 }
                 sc[mt][r] = pv;
             }
-        l = l * alpha + rs;
-        m = m_new;
-#pragma unroll
-        for (int i = 0; i < ND; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        l += rs;
         // O^T += V^T P^T : P^T accumulators are the B operand as they stand
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
