@@ -56,6 +56,7 @@ def parse():
     p.add_argument("--dropout", type=float, default=0.0, help="0.0 = the parity regime (default); 0.1 = the reference's default")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
+    p.add_argument("--no_variants", action="store_true", help="skip the extra masked-rows-readout measurement")
     p.add_argument("--pipeline_streams", type=int, default=2, choices=[1, 2],
                    help="2: forward of micro-batch j+1 beside the backward of micro-batch j on a second HIP stream (bitwise the same results)")
     p.add_argument("--plan_cache", default="", help="JSON file of tuned GEMM plans: loaded if present (no tuning launches), else tuned and written")
@@ -252,6 +253,27 @@ def main():
                     for (name, d0, d1, d2), (n, tt) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
                         fl = 2.0 * d0 * d1 * d2 if not name.startswith("attn") else 4.0 * d0 * d1 * d1 * d2 * (1.0 if name == "attn_fwd" else 2.5)
                         f.write(f"{name:28s} {d0:7d} {d1:7d} {d2:7d} {n:6d} {tt / n * 1e3:9.1f} {fl * n / (tt * 1e-3) / 1e12:8.1f} {tt:8.2f}\n")
+    # Not the headline: the same step with the readout and the cross entropy restricted to the ~15 % MLM-masked rows
+    # (TrainStep lm_head_impl="masked": same loss and gradients, rows outside the mask contribute exact zeros).  Reported
+    # beside `value`, which keeps the reference's full logits.
+    variants = None
+    if not a.masked_lm_head and not a.no_variants:
+        step.lm_head_impl = "masked"
+        for i in range(2):
+            step(batches[i % len(batches)])
+        sync()
+        t0 = time.perf_counter()
+        for i in range(3):
+            step(batches[i % len(batches)])
+        sync()
+        el = time.perf_counter() - t0
+        if world > 1:
+            te = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        step.lm_head_impl = "dense"
+        variants = {"masked_rows_readout": {"value": round(tokens_per_step * 3 / el, 1), "unit": "tokens/s", "steps": 3,
+                                            "note": "readout + CE on the MLM-masked rows only; identical loss and gradients; not the headline"}}
     if world > 1:
         dist.barrier()
 
@@ -270,6 +292,8 @@ def main():
             "final_loss": round(float(losses[-1].item()), 4),
             "roofline": roofline,
         }
+        if variants:
+            out["variants"] = variants
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
