@@ -130,6 +130,11 @@ struct TileDma {
 };
 
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Before the main loop: the builtin form, so that hipcc's own bookkeeping also knows every global load of the prologue
+// (the Q / dO / K fragments held in registers) has landed.  Otherwise it keeps its per-fragment `s_waitcnt vmcnt(7..0)`
+// in front of the first MFMAs INSIDE the loop — harmless for its own loads after the first iteration, but vmcnt counts
+// the asm-issued LDS-DMA too, so those waits drained the next tile's prefetch during the first MFMA phase of every tile.
+__device__ __forceinline__ void prologue_wait_all() { __builtin_amdgcn_s_waitcnt(0x0070); }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_fwd_kernel(AttnParams 
     };
     if (t_begin < t_end) issue_kv(t_begin, 0);
     dma_wait_all();
+    prologue_wait_all();
     __syncthreads();
 #endif
 
@@ -456,6 +462,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     };
     if (t_begin < t_end) issue_kv(t_begin, 0);
     dma_wait_all();
+    prologue_wait_all();
     __syncthreads();
 
     for (int t = t_begin; t < t_end; ++t) {
@@ -610,6 +617,7 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_bwd_dkdv_kernel(AttnPa
         store_stats(smem);
     }
     dma_wait_all();
+    prologue_wait_all();
     __syncthreads();
 
     for (int t = t_begin; t < t_end; ++t) {
