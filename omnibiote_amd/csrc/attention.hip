@@ -61,49 +61,23 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int krow0, int dt, i
     return join8(lo, hi);
 }
 
-// Global -> registers -> LDS staging of a ROWS x D tile by 256 threads (rows >= nvalid read as zero).  Used by the
-// forward kernel: issuing the loads before the tile's MFMA work and writing LDS after it measured 19 % faster there
-// than LDS-DMA (55 vs 66 us at B8/H8/T1024); the backward kernels need the registers more than the overlap.
-template <int D, int ROWS>
-struct TileStage {
-    static constexpr int CPR = D / 8;                 // 16-B chunks per row
-    static constexpr int N = ROWS * CPR / 256;        // chunks per thread
-    bf16x8 r[N];
-    __device__ __forceinline__ void load(const bf16* g, int64_t row_stride, int nvalid, int tid) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int cid = tid + 256 * i;
-            const int row = cid / CPR, ch = cid % CPR;
-            bf16x8 v = {};
-            if (row < nvalid) v = *reinterpret_cast<const bf16x8*>(g + (int64_t)row * row_stride + ch * 8);
-            r[i] = v;
-        }
-    }
-    __device__ __forceinline__ void store(char* tile, int tid) const {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int cid = tid + 256 * i;
-            *reinterpret_cast<bf16x8*>(tile + swz<D>(cid / CPR, cid % CPR)) = r[i];
-        }
-    }
-};
-
 // Global -> LDS staging of a ROWS x D tile by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPR round trip).
 // The DMA writes LDS linearly (wave base + lane*16), so the swizzle is applied to the SOURCE chunk each lane fetches:
 // LDS position `pos` of row r holds logical chunk pos ^ X(r) — exactly what swz<D>() reads back.  The descriptor ends
 // at the end of this batch element's rows, so rows past T arrive as zeros.  256 threads = 4 waves; wave w issues
 // pieces w, w+4, ...  Completion: the issuing wave's s_waitcnt vmcnt(0), then the workgroup barrier.
-template <int D, int ROWS>
+template <int D, int ROWS, int NW = 4>
 struct TileDma {
     static constexpr int PIECES = ROWS * 2 * D / 1024;   // 1-KiB pieces in the tile
-    static constexpr int NP = PIECES / 4;                 // per wave
+    static constexpr int NP = PIECES / NW;                // per wave
+    static_assert(NP >= 1 && NP * NW == PIECES, "tile does not split evenly over the waves");
     static constexpr int RPP = 1024 / (2 * D);            // rows per piece: 4 (D=128) or 8 (D=64)
     static constexpr int CPR = D / 8;                     // chunks per row
     int voff[NP];
     __device__ __forceinline__ void init(int wave, int lane, int64_t row_stride) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int piece = wave + 4 * i;
+            const int piece = wave + NW * i;
             const int row = piece * RPP + lane / CPR;
             const int pos = lane % CPR;
             const int x = (D == 128) ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
@@ -113,18 +87,18 @@ struct TileDma {
     // g: address of the tile's first row (head column applied); bytes_left: bytes from g to the end of the rows that
     // may be read (the batch element's last row)
     __device__ __forceinline__ void issue(const bf16* g, int64_t bytes_left, char* tile, int wave) const {
-        // through inline asm (common.h lds_dma16): with the builtin hipcc drains vmcnt in front of the next LDS read,
-        // i.e. waits for the tile it was asked to prefetch before computing on the current one
 #ifdef OBTE_DMA_BUILTIN
         __amdgpu_buffer_rsrc_t rsrc = make_rsrc(g, bytes_left);
 #pragma unroll
         for (int i = 0; i < NP; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(tile + (wave + 4 * i) * 1024), 16, voff[i], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(tile + (wave + NW * i) * 1024), 16, voff[i], 0, 0, 0);
 #else
+        // through inline asm (common.h lds_dma16): with the builtin hipcc drains vmcnt in front of the next LDS read,
+        // i.e. waits for the tile it was asked to prefetch before computing on the current one
         const i32x4_t rsrc = make_rsrc_words(g, bytes_left);
         const uint32_t base = lds_addr_of(tile) + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) lds_dma16(rsrc, base + 4 * i * 1024, voff[i]);
+        for (int i = 0; i < NP; ++i) lds_dma16(rsrc, base + NW * i * 1024, voff[i]);
 #endif
     }
 };
@@ -134,6 +108,20 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 // (the Q / dO / K fragments held in registers) has landed.  Otherwise it keeps its per-fragment `s_waitcnt vmcnt(7..0)`
 // in front of the first MFMAs INSIDE the loop — harmless for its own loads after the first iteration, but vmcnt counts
 // the asm-issued LDS-DMA too, so those waits drained the next tile's prefetch during the first MFMA phase of every tile.
+// wait until at most k of this wave's vector-memory operations (the LDS-DMA pieces) are still in flight; k uniform
+__device__ __forceinline__ void dma_wait_leave(int k) {
+    switch (k) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
 __device__ __forceinline__ void prologue_wait_all() { __builtin_amdgcn_s_waitcnt(0x0070); }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -149,26 +137,34 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int base) {
 }
 
 // min/max over the workgroup (256 threads) through a small LDS scratch of 8 ints
+template <int NW = 4>
 __device__ __forceinline__ void block_minmax(int& lo, int& hi, int* scratch, int wave, int lane) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         lo = min(lo, __shfl_xor(lo, o, 64));
         hi = max(hi, __shfl_xor(hi, o, 64));
     }
-    if (lane == 0) { scratch[wave] = lo; scratch[4 + wave] = hi; }
+    if (lane == 0) { scratch[wave] = lo; scratch[NW + wave] = hi; }
     __syncthreads();
-    lo = min(min(scratch[0], scratch[1]), min(scratch[2], scratch[3]));
-    hi = max(max(scratch[4], scratch[5]), max(scratch[6], scratch[7]));
+    lo = scratch[0]; hi = scratch[NW];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { lo = min(lo, scratch[w]); hi = max(hi, scratch[NW + w]); }
     __syncthreads();
 }
 
 // ==========================================================================================================
 // forward
 // ==========================================================================================================
-// (the dropout variants trade occupancy for registers: one wave per SIMD, no spills)
+// Queries per workgroup: 256 (eight waves, one workgroup per CU) without dropout.  Every workgroup streams the whole
+// K and V of its (batch, head) through LDS, so the L2 -> LDS traffic is inversely proportional to the query block: at
+// 128 queries the forward moved 268 MB per launch in 50 us = 5.4 TB/s, the chip-wide LDS-DMA ceiling — that, not MFMA,
+// VALU, LDS or DMA latency, was what bounded it.  The dropout variants keep 128 queries / four waves with one workgroup
+// per CU: they need the 512-register budget.
+template <bool DROP> struct FwdShape { static constexpr int NW = DROP ? 4 : 8; static constexpr int STAGES = 2; };   // a deeper ring (4 stages, 3 tiles ahead) measured slower: 48.9 vs 45.9 us
 template <int D, int MODE, bool DROP>
-__global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_fwd_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = FwdShape<DROP>::NW;
     constexpr int TB = 64 * 2 * D;  // bytes of one 64-row tile
     constexpr int NS = D / 16;      // k-steps over the head dim
     constexpr int ND = D / 32;      // 32-wide d tiles of the output
@@ -180,7 +176,7 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_fwd_kernel(AttnParams 
     const int T = (int)p.T;
     const int C = p.H * D;
     const int64_t ld = 3 * (int64_t)C;
-    const int q_row = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const int q_row = blockIdx.x * (32 * NW) + wave * 32 + (lane & 31);
     const bool q_ok = q_row < T;
     const int q_c = q_ok ? q_row : T - 1;
 
@@ -196,7 +192,7 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_fwd_kernel(AttnParams 
         ks = max(ks, 0);
     }
     int lo = ks, hi = ke;
-    if (MODE == MASK_RANGES) block_minmax(lo, hi, reinterpret_cast<int*>(smem + 4 * TB), wave, lane);
+    if (MODE == MASK_RANGES) block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 2 * FwdShape<DROP>::STAGES * TB), wave, lane);
     const int t_begin = lo / 64;
     const int t_end = hi > lo ? (hi + 63) / 64 : t_begin;
 
@@ -213,44 +209,30 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_fwd_kernel(AttnParams 
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     const float scale2 = p.scale * LOG2E;
 
-#ifdef OBTE_ATTN_FWD_STAGE
-    TileStage<D, 64> sk, sv;
-    if (t_begin < t_end) {
-        sk.load(kbase + (int64_t)t_begin * 64 * ld, ld, T - t_begin * 64, tid);
-        sv.load(vbase + (int64_t)t_begin * 64 * ld, ld, T - t_begin * 64, tid);
-        sk.store(smem, tid);
-        sv.store(smem + TB, tid);
-    }
-    __syncthreads();
-#else
     // K/V tiles by LDS-DMA (asm issue, see common.h): no staging registers, no ds_write — the forward is issue-bound
-    TileDma<D, 64> dma;
+    TileDma<D, 64, NW> dma;
     dma.init(wave, lane, ld);
-    auto issue_kv = [&](int t, int stage) {
+    // ring of R stages (K tile + V tile each), loaded R-1 tiles ahead; one workgroup per CU, so there is no second
+    // workgroup to cover a wait and the prefetch distance has to
+    constexpr int R = FwdShape<DROP>::STAGES;
+    constexpr int OPS = 2 * TileDma<D, 64, NW>::NP;   // LDS-DMA instructions per wave per stage
+    auto issue_kv = [&](int t) {
         const int64_t row0 = (int64_t)t * 64;
         const int64_t rows_left = ((int64_t)T - row0) * ld;
-        char* st = smem + stage * 2 * TB;
+        char* st = smem + ((t - t_begin) % R) * 2 * TB;
         dma.issue(kbase + row0 * ld, (rows_left - (C + hd * D)) * 2, st, wave);
         dma.issue(vbase + row0 * ld, (rows_left - (2 * C + hd * D)) * 2, st + TB, wave);
     };
-    if (t_begin < t_end) issue_kv(t_begin, 0);
-    dma_wait_all();
-    prologue_wait_all();
+    prologue_wait_all();   // the Q fragments have landed (and hipcc knows it) before the first LDS-DMA is in the queue
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i)
+        if (t_begin + i < t_end) issue_kv(t_begin + i);
+    dma_wait_leave(OPS * min(max(t_end - t_begin - 1, 0), R - 2));
     __syncthreads();
-#endif
 
     for (int t = t_begin; t < t_end; ++t) {
-        const int cur = (t - t_begin) & 1;
-        const bool more = t + 1 < t_end;
-#ifdef OBTE_ATTN_FWD_STAGE
-        if (more) {   // issue early: the loads fly under this tile's MFMA work, the LDS write follows it
-            sk.load(kbase + (int64_t)(t + 1) * 64 * ld, ld, T - (t + 1) * 64, tid);
-            sv.load(vbase + (int64_t)(t + 1) * 64 * ld, ld, T - (t + 1) * 64, tid);
-        }
-#else
-        if (more) issue_kv(t + 1, cur ^ 1);
-#endif
-        const char* Kt = smem + cur * 2 * TB;
+        if (t + R - 1 < t_end) issue_kv(t + R - 1);   // the slot of tile t-1: every wave is past the barrier that ended it
+        const char* Kt = smem + ((t - t_begin) % R) * 2 * TB;
         const char* Vt = Kt + TB;
         const int key0 = t * 64;
 
@@ -330,14 +312,7 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_fwd_kernel(AttnParams 
             for (int dt = 0; dt < ND; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Vt, 16 * kk, dt, lane), pf, o[dt], 0, 0, 0);
         }
-#ifdef OBTE_ATTN_FWD_STAGE
-        if (more) {
-            sk.store(smem + (cur ^ 1) * 2 * TB, tid);
-            sv.store(smem + (cur ^ 1) * 2 * TB + TB, tid);
-        }
-#else
-        dma_wait_all();
-#endif
+        dma_wait_leave(OPS * min(max(t_end - t - 2, 0), R - 2));   // tile t+1 landed; later ones may stay in flight
         __syncthreads();
     }
 
@@ -722,13 +697,14 @@ int mask_mode(const int32_t* ranges, const obte_bf16* mask) { return ranges ? MA
 
 template <int D>
 int launch_fwd(const AttnParams& p, int mode, hipStream_t st) {
-    const int smem = 4 * 64 * 2 * D + 64;
-    const dim3 grid((unsigned)cdiv64(p.T, 128), p.H, (unsigned)p.B), block(256);
+    const int smem = 2 * FwdShape<false>::STAGES * 64 * 2 * D + 64;   // >= the dropout variant's two stages
+    const dim3 grid_d((unsigned)cdiv64(p.T, 32 * FwdShape<true>::NW), p.H, (unsigned)p.B), block_d(64 * FwdShape<true>::NW);
+    const dim3 grid((unsigned)cdiv64(p.T, 32 * FwdShape<false>::NW), p.H, (unsigned)p.B), block(64 * FwdShape<false>::NW);
 #define GO(M)                                                                                 \
     do {                                                                                      \
         if (p.drop.thresh24) {                                                                \
             set_smem(attn_fwd_kernel<D, M, true>, smem);                                      \
-            hipLaunchKernelGGL((attn_fwd_kernel<D, M, true>), grid, block, smem, st, p);      \
+            hipLaunchKernelGGL((attn_fwd_kernel<D, M, true>), grid_d, block_d, smem, st, p);  \
         } else {                                                                              \
             set_smem(attn_fwd_kernel<D, M, false>, smem);                                     \
             hipLaunchKernelGGL((attn_fwd_kernel<D, M, false>), grid, block, smem, st, p);     \
