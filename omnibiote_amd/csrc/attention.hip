@@ -69,8 +69,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int krow0, int dt, i
 template <int D, int ROWS, int NW = 4>
 struct TileDma {
     static constexpr int PIECES = ROWS * 2 * D / 1024;   // 1-KiB pieces in the tile
-    static constexpr int NP = PIECES / NW;                // per wave
-    static_assert(NP >= 1 && NP * NW == PIECES, "tile does not split evenly over the waves");
+    static constexpr int NP = PIECES >= NW ? PIECES / NW : 1;   // per wave (a tile with fewer pieces than waves: the first PIECES waves)
+    static_assert(PIECES >= NW ? NP * NW == PIECES : true, "tile does not split evenly over the waves");
     static constexpr int RPP = 1024 / (2 * D);            // rows per piece: 4 (D=128) or 8 (D=64)
     static constexpr int CPR = D / 8;                     // chunks per row
     int voff[NP];
@@ -91,14 +91,16 @@ struct TileDma {
         __amdgpu_buffer_rsrc_t rsrc = make_rsrc(g, bytes_left);
 #pragma unroll
         for (int i = 0; i < NP; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(tile + (wave + NW * i) * 1024), 16, voff[i], 0, 0, 0);
+            if (PIECES >= NW || wave < PIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(tile + (wave + NW * i) * 1024), 16, voff[i], 0, 0, 0);
 #else
         // through inline asm (common.h lds_dma16): with the builtin hipcc drains vmcnt in front of the next LDS read,
         // i.e. waits for the tile it was asked to prefetch before computing on the current one
         const i32x4_t rsrc = make_rsrc_words(g, bytes_left);
         const uint32_t base = lds_addr_of(tile) + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) lds_dma16(rsrc, base + NW * i * 1024, voff[i]);
+        for (int i = 0; i < NP; ++i)
+            if (PIECES >= NW || wave < PIECES) lds_dma16(rsrc, base + NW * i * 1024, voff[i]);
 #endif
     }
 };
@@ -376,9 +378,11 @@ __device__ __forceinline__ void rope_inv4(float (&g)[4], const float* cos_t, con
 // backward, part 1: dQ.  Same shape as forward: 128 queries per workgroup, query on the lane.
 //   S^T = K Q^T ; P^T = exp(S^T*scale + mask - lse) ; dP^T = V dO^T ; dS^T = P^T (dP^T - delta) ; dQ^T += K^T dS^T
 // ==========================================================================================================
+// 256 queries (eight waves) per workgroup without dropout, for the same reason as the forward: K/V traffic per query.
 template <int D, int MODE, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bwd_dq_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = FwdShape<DROP>::NW;
     constexpr int TB = 64 * 2 * D;
     constexpr int NS = D / 16, ND = D / 32;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     const int T = (int)p.T;
     const int C = p.H * D;
     const int64_t ld = 3 * (int64_t)C;
-    const int q_row = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const int q_row = blockIdx.x * (32 * NW) + wave * 32 + (lane & 31);
     const bool q_ok = q_row < T;
     const int q_c = q_ok ? q_row : T - 1;
 
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
         ke = min(p.key_ranges[(b * T + q_c) * 2 + 1], T);
     }
     int lo = ks, hi = ke;
-    if (MODE == MASK_RANGES) block_minmax(lo, hi, reinterpret_cast<int*>(smem + 4 * TB), wave, lane);
+    if (MODE == MASK_RANGES) block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 4 * TB), wave, lane);
     const int t_begin = lo / 64;
     const int t_end = hi > lo ? (hi + 63) / 64 : t_begin;
 
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
     const float scale2 = p.scale * LOG2E;
 
-    TileDma<D, 64> dma;
+    TileDma<D, 64, NW> dma;
     dma.init(wave, lane, ld);
     auto issue_kv = [&](int t, int stage) {
         const int64_t row0 = (int64_t)t * 64;
@@ -508,13 +512,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 //   S = Q K^T ; P = exp(S*scale + mask - lse) ; dP = dO V^T ; dS = P (dP - delta)
 //   dV^T += dO^T P ; dK^T += Q^T dS
 // ==========================================================================================================
+// 256 keys (eight waves) per workgroup without dropout: the Q / dO tiles every workgroup streams are then shared by
+// twice as many keys (half the L2 -> LDS traffic per key).
 template <int D, int MODE, bool DROP>
-__global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_bwd_dkdv_kernel(AttnParams p) {
+__global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = FwdShape<DROP>::NW;
     constexpr int QB = 32 * 2 * D;  // bytes of one 32-row tile
     constexpr int NS = D / 16, ND = D / 32;
     constexpr int STAGE = 2 * QB + 256;  // Q tile, dO tile, 32 lse2 + 32 delta floats
-    constexpr int VB = 128 * 2 * D;      // the workgroup's own V rows, kept in LDS for the whole kernel (B operand of dP)
+    constexpr int VB = 32 * NW * 2 * D;  // the workgroup's own V rows, kept in LDS for the whole kernel (B operand of dP)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
@@ -523,7 +530,7 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_bwd_dkdv_kernel(AttnPa
     const int T = (int)p.T;
     const int C = p.H * D;
     const int64_t ld = 3 * (int64_t)C;
-    const int key = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const int key = blockIdx.x * (32 * NW) + wave * 32 + (lane & 31);
     const bool k_ok = key < T;
     const int key_c = k_ok ? key : T - 1;
 
@@ -533,9 +540,9 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_bwd_dkdv_kernel(AttnPa
     for (int s = 0; s < NS; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(kptr + 16 * s + 8 * h);
     char* Vblk = smem + 2 * STAGE;
     {
-        TileDma<D, 128> dmv;
+        TileDma<D, 32 * NW, NW> dmv;
         dmv.init(wave, lane, ld);
-        const int64_t row0 = (int64_t)blockIdx.x * 128;
+        const int64_t row0 = (int64_t)blockIdx.x * (32 * NW);
         dmv.issue(p.qkv + (b * T + row0) * ld + 2 * C + hd * D, (((int64_t)T - row0) * ld - (2 * C + hd * D)) * 2, Vblk, wave);
     }
     // by symmetry of the mask, the queries that see this key are the keys this position sees as a query
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_bwd_dkdv_kernel(AttnPa
     }
     if (!k_ok) { qs = 0; qe = 0; }
     int lo = k_ok ? qs : T, hi = k_ok ? qe : 0;
-    if (MODE == MASK_RANGES) block_minmax(lo, hi, reinterpret_cast<int*>(smem + 2 * STAGE + VB), wave, lane);
+    if (MODE == MASK_RANGES) block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 2 * STAGE + VB), wave, lane);
     else { lo = 0; hi = T; }
     const int t_begin = lo / 32;
     const int t_end = hi > lo ? (hi + 31) / 32 : t_begin;
@@ -565,7 +572,7 @@ __global__ __launch_bounds__(256, DROP ? 1 : 2) void attn_bwd_dkdv_kernel(AttnPa
         for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
     const float scale2 = p.scale * LOG2E;
 
-    TileDma<D, 32> dmq, dmd;
+    TileDma<D, 32, NW> dmq, dmd;
     dmq.init(wave, lane, ld);
     dmd.init(wave, lane, C);
     auto issue_qd = [&](int t, char* stage) {
@@ -725,12 +732,13 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
     }
     {
         const int smem = 4 * 64 * 2 * D + 64;
-        const dim3 grid((unsigned)cdiv64(p.T, 128), p.H, (unsigned)p.B), block(256);
+        const dim3 grid_d((unsigned)cdiv64(p.T, 32 * FwdShape<true>::NW), p.H, (unsigned)p.B), block_d(64 * FwdShape<true>::NW);
+        const dim3 grid((unsigned)cdiv64(p.T, 32 * FwdShape<false>::NW), p.H, (unsigned)p.B), block(64 * FwdShape<false>::NW);
 #define GO(M)                                                                                    \
     do {                                                                                         \
         if (p.drop.thresh24) {                                                                   \
             set_smem(attn_bwd_dq_kernel<D, M, true>, smem);                                      \
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<D, M, true>), grid, block, smem, st, p);      \
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<D, M, true>), grid_d, block_d, smem, st, p);  \
         } else {                                                                                 \
             set_smem(attn_bwd_dq_kernel<D, M, false>, smem);                                     \
             hipLaunchKernelGGL((attn_bwd_dq_kernel<D, M, false>), grid, block, smem, st, p);     \
@@ -741,13 +749,14 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
         OBTE_CHECK_LAUNCH("obte_attn_bwd(dq)");
     }
     {
-        const int smem = 2 * (2 * 32 * 2 * D + 256) + 128 * 2 * D + 64;
-        const dim3 grid((unsigned)cdiv64(p.T, 128), p.H, (unsigned)p.B), block(256);
+        const int smem = 2 * (2 * 32 * 2 * D + 256) + 32 * FwdShape<false>::NW * 2 * D + 64;   // >= the dropout variant's
+        const dim3 grid_d((unsigned)cdiv64(p.T, 32 * FwdShape<true>::NW), p.H, (unsigned)p.B), block_d(64 * FwdShape<true>::NW);
+        const dim3 grid((unsigned)cdiv64(p.T, 32 * FwdShape<false>::NW), p.H, (unsigned)p.B), block(64 * FwdShape<false>::NW);
 #define GO(M)                                                                                      \
     do {                                                                                           \
         if (p.drop.thresh24) {                                                                     \
             set_smem(attn_bwd_dkdv_kernel<D, M, true>, smem);                                      \
-            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, M, true>), grid, block, smem, st, p);      \
+            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, M, true>), grid_d, block_d, smem, st, p);  \
         } else {                                                                                   \
             set_smem(attn_bwd_dkdv_kernel<D, M, false>, smem);                                     \
             hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, M, false>), grid, block, smem, st, p);     \
