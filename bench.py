@@ -124,8 +124,10 @@ def roofline_from_profile(ms, dims, kind, n_steps):
     return roof
 
 
-def cpu_baseline(cfg, mini_rows=1, steps=3, warmup=1):
-    """The oracle's train step (fwd + masked CE + bwd + clip + AdamW) on the host cores, bf16 like the GPU run."""
+def cpu_baseline(cfg, mini_rows=1, steps=3, warmup=1, device="cpu", rows=None):
+    """The oracle's train step (fwd + masked CE + bwd + clip + AdamW), bf16 like the GPU run: on the host cores (the
+    `cpu_baseline` object), or — same module, same step, `device="cuda"` — as eager PyTorch-ROCm ops on the GPU the
+    HIP path just ran on (`eager_gpu_baseline`: what the reference's own op set costs on this hardware)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import omnibiote_ref as R
     from omnibiote_amd import train_encoder as TE
@@ -134,22 +136,28 @@ def cpu_baseline(cfg, mini_rows=1, steps=3, warmup=1):
     rc = R.RefConfig(block_size=cfg["ctx_len"], vocab_size=2 ** 16, n_layer=cfg["n_layer"], n_head=cfg["n_head"], n_embd=cfg["n_embd"])
     torch.manual_seed(0)
     shapes = R.param_shapes(rc)
-    w = {k: (torch.randn(s) * (1.0 if "wte" in k else 0.02) + (1.0 if "ln_" in k else 0.0)).bfloat16() for k, s in shapes.items()}
+    w = {k: (torch.randn(s) * (1.0 if "wte" in k else 0.02) + (1.0 if "ln_" in k else 0.0)).bfloat16().to(device) for k, s in shapes.items()}
     enc = R.OracleEncoder(rc, w)
-    enc.rope = R.cast_rope_table(R.rope_table(rc.n_embd // rc.n_head, rc.block_size), torch.bfloat16)
+    enc.rope = R.cast_rope_table(R.rope_table(rc.n_embd // rc.n_head, rc.block_size), torch.bfloat16).to(device)
     opt = torch.optim.AdamW(enc.parameters(), lr=1e-3)
     step = TE.TrainStep(enc, opt, None, mini_batch_size=mini_rows, n_head=rc.n_head, loss_impl="torch", mask_impl="dense")
     rng = np.random.default_rng(0)
-    ids = torch.from_numpy(TE.synthetic_rows(mini_rows, cfg["ctx_len"], 2 ** 16, rng))
+    rows = rows or mini_rows
+    ids = torch.from_numpy(TE.synthetic_rows(rows, cfg["ctx_len"], 2 ** 16, rng)).to(device)
     times = []
     for i in range(warmup + steps):
+        if device != "cpu":
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         step(ids)
+        if device != "cpu":
+            torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     t = float(np.median(times[warmup:]))
-    return {"value": round(mini_rows * cfg["ctx_len"] / t, 1), "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"oracle train step (fwd+masked CE+bwd+clip+AdamW), {mini_rows} row(s) x {cfg['ctx_len']} tokens, bf16, "
-                      f"median of {steps} steps after {warmup} warm-up; host has {os.cpu_count()} logical CPUs"}
+    where = f"host cores ({threads} threads; host has {os.cpu_count()} logical CPUs)" if device == "cpu" else "eager PyTorch-ROCm ops on cuda:0"
+    return {"value": round(rows * cfg["ctx_len"] / t, 1), "unit": "tokens/s", "cores": threads if device == "cpu" else 0, "kind": "port",
+            "sample": f"oracle train step (fwd+masked CE+bwd+clip+AdamW) on {where}, {rows} row(s) x {cfg['ctx_len']} tokens in "
+                      f"micro-batches of {mini_rows}, bf16, dense additive masks, median of {steps} steps after {warmup} warm-up"}
 
 
 def main():
@@ -296,6 +304,12 @@ def main():
             out["variants"] = variants
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
+            try:   # same oracle step as eager torch ops on this GPU (informational; never the product path)
+                del step, opt, model, m
+                torch.cuda.empty_cache()
+                out["eager_gpu_baseline"] = cpu_baseline(cfg, mini_rows=a.mini_batch_size, steps=2, warmup=1, device="cuda", rows=a.rows_per_rank)
+            except Exception as e:   # e.g. out of memory on a large config: the headline does not depend on it
+                out["eager_gpu_baseline"] = {"value": None, "note": repr(e)[:200]}
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
