@@ -351,6 +351,54 @@ def test_two_stream_micro_batch_pipeline_is_bitwise_the_single_stream_step(impl)
         assert torch.equal(out[1][1][k], out[2][1][k]), "weight " + k
 
 
+def test_ddp_wrapped_pipelined_step_equals_plain_single_stream_step():
+    """The N>1 code path on one GPU: the model wrapped in DistributedDataParallel over RCCL (world size 1), micro-batches
+    under no_sync() on two streams, reducer hooks on the last one — must reproduce the unwrapped single-stream step bit
+    for bit (a one-rank all-reduce is the identity)."""
+    import torch.distributed as dist
+    from omnibiote_amd import train_encoder as TE
+    from omnibiote_amd.mup_compat import set_base_shapes
+    from omnibiote_amd.model import OmniBioTA, OmniBioTAConfig
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        C, H, Lyr, V, T, rows, mini = 256, 2, 2, 1024, 128, 16, 4
+        w = R.hash_weights(R.RefConfig(block_size=T, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C))
+        ids = torch.from_numpy(TE.synthetic_rows(rows, T, V, np.random.default_rng(3), single_document=False)).to(DEV)
+        out = {}
+        for mode in ("plain", "ddp"):
+            c = OmniBioTAConfig(); c.block_size, c.vocab_size, c.n_layer, c.n_head, c.n_embd, c.dropout, c.flash = T, V, Lyr, H, C, 0.0, True
+            m = OmniBioTA(c)
+            cb = OmniBioTAConfig(); cb.block_size, cb.vocab_size, cb.n_layer, cb.dropout, cb.flash = T, V, Lyr, 0.0, True
+            cb.n_embd, cb.n_head = 24, 3
+            base = OmniBioTA(cb)
+            cb.n_embd, cb.n_head = 48, 12
+            delta = OmniBioTA(cb)
+            set_base_shapes(m, base, delta=delta, rescale_params=False)
+            m.load_state_dict(w, strict=False)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                m.to(BF)
+            m.to(DEV)
+            model = TE.wrap_ddp(m, torch.cuda.current_device()) if mode == "ddp" else m
+            opt = TE.FusedAdamW(m.parameters(), lr=1e-3)
+            step = TE.TrainStep(model, opt, None, mini_batch_size=mini, n_head=H, pipeline_streams=2 if mode == "ddp" else 1)
+            for it in range(2):
+                np.random.seed(11 + it)
+                step(ids)
+            torch.cuda.synchronize()
+            out[mode] = {k: p.detach().clone() for k, p in m.named_parameters()}
+        for k in out["plain"]:
+            assert torch.equal(out["plain"][k], out["ddp"][k]), k
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_eval_style_usage_with_padding_mask_and_odd_length(golden_dir):
     """How the eval scripts call the model (evals/gue.py:15-21,111): a dense additive mask in which everything at and
     after the first PAD is -1e9 in both directions (so whole rows are masked), odd sequence length, CLS pooling,
