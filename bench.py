@@ -56,6 +56,8 @@ def parse():
     p.add_argument("--dropout", type=float, default=0.0, help="0.0 = the parity regime (default); 0.1 = the reference's default")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
+    p.add_argument("--dense_mask", action="store_true",
+                   help="pass the reference's dense additive (B,H,T,T) mask (expand view) instead of key ranges")
     p.add_argument("--no_variants", action="store_true", help="skip the extra masked-rows-readout measurement")
     p.add_argument("--pipeline_streams", type=int, default=2, choices=[1, 2],
                    help="2: forward of micro-batch j+1 beside the backward of micro-batch j on a second HIP stream (bitwise the same results)")
@@ -198,7 +200,8 @@ def main():
     total_iters = 1000
     opt, sched = TE.build_optimizer(m, h, total_iters)
     step = TE.TrainStep(model, opt, sched, mini_batch_size=a.mini_batch_size, n_head=cfg["n_head"],
-                        lm_head_impl="masked" if a.masked_lm_head else "dense", pipeline_streams=a.pipeline_streams)
+                        lm_head_impl="masked" if a.masked_lm_head else "dense", pipeline_streams=a.pipeline_streams,
+                        mask_impl="dense" if a.dense_mask else "ranges")
     rng = np.random.default_rng(1234 + rank)
     T = cfg["ctx_len"]
     # synthetic batches resident in HBM before timing; a fresh one per step
