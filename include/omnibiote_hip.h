@@ -158,8 +158,23 @@ typedef struct {
     const int32_t* key_ranges; const obte_bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
     int64_t B, T; int32_t n_head, head_dim; float scale;
     float dropout_p; uint64_t dropout_seed;     /* must equal the forward call's */
+    const int32_t* query_bounds;                /* nullable; with a dense mask: int32 [B,T,2] per KEY, see obte_mask_bounds */
 } obte_attn_bwd_args;
 int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s);
+
+/* Conservative bounds of a dense additive mask, so that the dense-mask kernels can skip key tiles without changing a
+ * single value (the arithmetic still reads the mask element by element).  An entry counts as "masking" when it is
+ * <= -3e4 (its softmax weight underflows to exactly 0 beside any row that has one allowed key).
+ *   key_bounds[b,q]   = [first, last+1) over the keys some head allows for query q; (0,T) if any head's row allows none
+ *                       (the reference then gets a softmax over the raw scores, so nothing may be skipped);
+ *   query_bounds[b,k] = [first, last+1) over the queries that may give key k a non-zero weight (rows of the previous
+ *                       kind count for every key).
+ * Pass key_bounds as `key_ranges` TOGETHER with `mask` to obte_attn_fwd / obte_attn_bwd / the block descriptor (a mask
+ * with key_ranges means "dense arithmetic, ranges only bound the loops"), and query_bounds in the field of that name.
+ * row_scratch: uint8 [B*T].  Replaces nothing in the reference (training/train_encoder.py:31-57 builds the mask, and
+ * model.py:115-146 hands it to SDPA whole). */
+int obte_mask_bounds(const obte_bf16* mask, int64_t mask_sb, int64_t mask_sh, int64_t mask_sq, int64_t B, int32_t n_head,
+                     int64_t T, int32_t* key_bounds, int32_t* query_bounds, uint8_t* row_scratch, obte_stream s);
 
 /* ---- token embedding (training/model.py:203,241) ------------------------------------------------------------
  * fwd: out[r,:] = wte[idx[r],:].  bwd: dwte (dense [V,C], fully written) = scatter-add of dout rows, summed in
@@ -226,6 +241,7 @@ typedef struct {
     const float *rope_cos, *rope_sin;                                   /* [T, hs/2] */
     const int32_t* key_ranges; const obte_bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
     float dropout_p; uint64_t dropout_seed;   /* one seed per block call; sites 1-3 derive from it.  p = 0: no dropout */
+    const int32_t* query_bounds;              /* nullable: obte_mask_bounds output for a dense mask (backward only) */
 } obte_block_desc;
 int64_t obte_block_act_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head);
 int64_t obte_block_bwd_ws_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head);

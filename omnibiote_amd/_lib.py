@@ -39,7 +39,7 @@ class AttnBwdArgs(C.Structure):
                 ("key_ranges", C.c_void_p), ("mask", C.c_void_p),
                 ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
                 ("B", C.c_int64), ("T", C.c_int64), ("n_head", C.c_int32), ("head_dim", C.c_int32), ("scale", C.c_float),
-                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)]
+                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("query_bounds", C.c_void_p)]
 
 
 class BlockDesc(C.Structure):
@@ -49,7 +49,7 @@ class BlockDesc(C.Structure):
                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
                 ("key_ranges", C.c_void_p), ("mask", C.c_void_p),
                 ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
-                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)]
+                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("query_bounds", C.c_void_p)]
 
 
 MT_MAX = 32
@@ -84,6 +84,8 @@ SYMBOLS = {
     "obte_gemm_workspace_bytes_max": (C.c_int64, [C.c_int64] * 3),
     "obte_rope_qk_inplace": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, c_stream]),
     "obte_attn_fwd": (C.c_int, [C.POINTER(AttnFwdArgs), c_stream]),
+    "obte_mask_bounds": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, c_stream]),
     "obte_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), c_stream]),
     "obte_embedding_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int64, c_stream]),
     "obte_embedding_fwd_dropout": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_uint64, c_stream]),

@@ -31,6 +31,7 @@ struct AttnParams {
     const bf16* o_in; const bf16* d_o; const float* lse_in; float* delta; bf16* dqkv;   // backward
     const float* rope_cos; const float* rope_sin;               // backward: inverse RoPE on dq, dk (nullable)
     const int32_t* key_ranges; const bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
+    const int32_t* query_bounds;   // dense mode only: per-key [first, last+1) query bounds (obte_mask_bounds), nullable
     int64_t B, T; int H; float scale;
     DropCfg drop;   // attention-probability dropout (site 1); thresh24 == 0: off
 };
@@ -152,6 +153,9 @@ __device__ __forceinline__ void block_minmax(int& lo, int& hi, int* scratch, int
 #pragma unroll
     for (int w = 1; w < NW; ++w) { lo = min(lo, scratch[w]); hi = max(hi, scratch[NW + w]); }
     __syncthreads();
+    // the same value in every lane, and hipcc must know it: tile indices derived from these feed scalar operands
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
 }
 
 // ==========================================================================================================
@@ -194,6 +198,11 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_fwd_kernel(At
         ks = max(ks, 0);
     }
     int lo = ks, hi = ke;
+    if (MODE == MASK_DENSE && p.key_ranges) {   // dense arithmetic, but the loop may skip what every row masks out
+        lo = max(p.key_ranges[(b * T + q_c) * 2], 0);
+        hi = min(p.key_ranges[(b * T + q_c) * 2 + 1], T);
+        block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 2 * FwdShape<DROP>::STAGES * TB), wave, lane);
+    }
     if (MODE == MASK_RANGES) block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 2 * FwdShape<DROP>::STAGES * TB), wave, lane);
     const int t_begin = lo / 64;
     const int t_end = hi > lo ? (hi + 63) / 64 : t_begin;
@@ -321,7 +330,13 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_fwd_kernel(At
     const float l_tot = l + __shfl_xor(l, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (q_ok) {
-        if (h == 0) p.lse[(b * p.H + hd) * T + q_row] = l_tot > 0.f ? (m + __log2f(l_tot)) * LN2 : INFINITY;
+        // A row whose every key carries a -1e9-class additive mask: the forward above reproduces the reference (the scores
+        // vanish in fp32 beside the mask, the softmax is uniform), but m + log2(l) cannot hold log2(l) beside |m| ~ 1e9,
+        // so an lse-based backward would turn that row into garbage for every key.  Its lse is stored as +inf instead:
+        // the backward then gives the row exactly zero weight.  (The reference's own mask builder never produces such a
+        // row; torch's fused SDPA backends return NaN for it.)
+        const bool degenerate = m < -1.0e8f;
+        if (h == 0) p.lse[(b * p.H + hd) * T + q_row] = (l_tot > 0.f && !degenerate) ? (m + __log2f(l_tot)) * LN2 : INFINITY;
         bf16* orow = p.o + (b * T + q_row) * C + hd * D;
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt)
@@ -414,6 +429,11 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bw
         ke = min(p.key_ranges[(b * T + q_c) * 2 + 1], T);
     }
     int lo = ks, hi = ke;
+    if (MODE == MASK_DENSE && p.key_ranges) {
+        lo = max(p.key_ranges[(b * T + q_c) * 2], 0);
+        hi = min(p.key_ranges[(b * T + q_c) * 2 + 1], T);
+        block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 4 * TB), wave, lane);
+    }
     if (MODE == MASK_RANGES) block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 4 * TB), wave, lane);
     const int t_begin = lo / 64;
     const int t_end = hi > lo ? (hi + 63) / 64 : t_begin;
@@ -553,8 +573,17 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kern
     }
     if (!k_ok) { qs = 0; qe = 0; }
     int lo = k_ok ? qs : T, hi = k_ok ? qe : 0;
-    if (MODE == MASK_RANGES) block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 2 * STAGE + VB), wave, lane);
-    else { lo = 0; hi = T; }
+    if (MODE == MASK_RANGES) {
+        block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 2 * STAGE + VB), wave, lane);
+    } else if (MODE == MASK_DENSE && p.query_bounds) {
+        if (k_ok) {
+            lo = max(p.query_bounds[(b * T + key_c) * 2], 0);
+            hi = min(p.query_bounds[(b * T + key_c) * 2 + 1], T);
+        }
+        block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 2 * STAGE + VB), wave, lane);
+    } else {
+        lo = 0; hi = T;
+    }
     const int t_begin = lo / 32;
     const int t_end = hi > lo ? (hi + 31) / 32 : t_begin;
 
@@ -700,7 +729,8 @@ void set_smem(K kern, int bytes) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-int mask_mode(const int32_t* ranges, const obte_bf16* mask) { return ranges ? MASK_RANGES : (mask ? MASK_DENSE : MASK_NONE); }
+// a dense mask wins: key_ranges passed beside it only bound the loops (obte_mask_bounds)
+int mask_mode(const int32_t* ranges, const obte_bf16* mask) { return mask ? MASK_DENSE : (ranges ? MASK_RANGES : MASK_NONE); }
 
 template <int D>
 int launch_fwd(const AttnParams& p, int mode, hipStream_t st) {
@@ -777,7 +807,6 @@ static int check_common(const char* who, const void* qkv, int64_t B, int64_t T, 
     OBTE_REQUIRE(B > 0 && T > 0 && H > 0 && B < 65536 && H < 65536, "%s: bad B/T/H", who);
     OBTE_REQUIRE(D == 64 || D == 128, "%s: head_dim must be 64 or 128 (got %d)", who, D);
     OBTE_REQUIRE(T < (1 << 24), "%s: T too large", who);
-    OBTE_REQUIRE(!(ranges && mask), "%s: pass key_ranges or a dense mask, not both", who);
     return OBTE_OK;
 }
 
@@ -807,7 +836,7 @@ extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
     OBTE_REQUIRE((a->rope_cos == nullptr) == (a->rope_sin == nullptr), "obte_attn_bwd: pass both RoPE tables or neither");
     AttnParams p = {};
     p.qkv = (const bf16*)a->qkv; p.o_in = (const bf16*)a->o; p.d_o = (const bf16*)a->d_o; p.lse_in = a->lse; p.delta = a->delta;
-    p.dqkv = (bf16*)a->dqkv; p.rope_cos = a->rope_cos; p.rope_sin = a->rope_sin;
+    p.dqkv = (bf16*)a->dqkv; p.rope_cos = a->rope_cos; p.rope_sin = a->rope_sin; p.query_bounds = a->mask ? a->query_bounds : nullptr;
     p.key_ranges = a->key_ranges; p.mask = (const bf16*)a->mask; p.mask_sb = a->mask_sb; p.mask_sh = a->mask_sh; p.mask_sq = a->mask_sq;
     p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
     OBTE_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "obte_attn_bwd: dropout p must be in [0,1)");
@@ -817,4 +846,75 @@ extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
     rc = a->head_dim == 128 ? launch_bwd<128>(p, mode, (hipStream_t)s) : launch_bwd<64>(p, mode, (hipStream_t)s);
     obte_prof_end(prof, (hipStream_t)s);
     return rc;
+}
+
+
+// ---- obte_mask_bounds -------------------------------------------------------------------------------------------
+namespace {
+constexpr float MASKING = -3.0e4f;   // an additive entry at or below this is "masked": exp() of it underflows to 0
+
+// one wave per (b, q) row: [first, last+1) over the keys any head allows; (0,T) and row_full = 1 if some head allows none
+__global__ __launch_bounds__(256) void mask_row_bounds_kernel(const bf16* mask, int64_t sb, int64_t sh, int64_t sq, int64_t B, int H,
+                                                               int64_t T, int32_t* kb, uint8_t* row_full) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= B * T) return;
+    const int64_t b = row / T, q = row % T;
+    const int heads = sh == 0 ? 1 : H;
+    int lo = (int)T, hi = 0;
+    bool full = false;
+    for (int h = 0; h < heads; ++h) {
+        const bf16* r = mask + b * sb + h * sh + q * sq;
+        int l = (int)T, u = 0;
+        for (int64_t k = lane; k < T; k += 64) {
+            if (bf2f(r[k]) > MASKING) { l = min(l, (int)k); u = max(u, (int)k + 1); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { l = min(l, __shfl_xor(l, o, 64)); u = max(u, __shfl_xor(u, o, 64)); }
+        if (u == 0) full = true;
+        lo = min(lo, l); hi = max(hi, u);
+    }
+    if (full) { lo = 0; hi = (int)T; }
+    if (lane == 0) { kb[row * 2] = lo; kb[row * 2 + 1] = hi; row_full[row] = full ? 1 : 0; }
+}
+
+// thread per (b, key), grid.y chunks of 64 queries: [first, last+1) over the queries that allow the key (or are "full" rows)
+__global__ __launch_bounds__(256) void mask_col_bounds_kernel(const bf16* mask, int64_t sb, int64_t sh, int64_t sq, int64_t B, int H,
+                                                               int64_t T, const uint8_t* row_full, int32_t* qb) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t b = blockIdx.z;
+    if (k >= T) return;
+    const int heads = sh == 0 ? 1 : H;
+    const int64_t q0 = (int64_t)blockIdx.y * 64, q1 = min(q0 + 64, T);
+    int lo = (int)T, hi = 0;
+    for (int64_t q = q0; q < q1; ++q) {
+        bool ok = row_full[b * T + q] != 0;
+        for (int h = 0; h < heads && !ok; ++h) ok = bf2f(mask[b * sb + h * sh + q * sq + k]) > MASKING;
+        if (ok) { lo = min(lo, (int)q); hi = max(hi, (int)q + 1); }
+    }
+    if (hi > 0) {
+        atomicMin(&qb[(b * T + k) * 2], lo);
+        atomicMax(&qb[(b * T + k) * 2 + 1], hi);
+    }
+}
+__global__ void mask_col_init_kernel(int32_t* qb, int64_t n, int T) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { qb[i * 2] = T; qb[i * 2 + 1] = 0; }   // a key no query can see: empty [T, 0)
+}
+}  // namespace
+
+extern "C" int obte_mask_bounds(const obte_bf16* mask, int64_t mask_sb, int64_t mask_sh, int64_t mask_sq, int64_t B, int32_t n_head,
+                                int64_t T, int32_t* key_bounds, int32_t* query_bounds, uint8_t* row_scratch, obte_stream s) {
+    OBTE_REQUIRE(mask && key_bounds && query_bounds && row_scratch, "obte_mask_bounds: null pointer");
+    OBTE_REQUIRE(B > 0 && T > 0 && n_head > 0 && B < 65536 && T < (1 << 24), "obte_mask_bounds: bad B/T/H");
+    hipStream_t st = (hipStream_t)s;
+    hipLaunchKernelGGL(mask_row_bounds_kernel, dim3((unsigned)cdiv64(B * T, 4)), dim3(256), 0, st, (const bf16*)mask, mask_sb, mask_sh, mask_sq, B,
+                       (int)n_head, T, key_bounds, row_scratch);
+    OBTE_CHECK_LAUNCH("obte_mask_bounds(rows)");
+    hipLaunchKernelGGL(mask_col_init_kernel, dim3((unsigned)cdiv64(B * T, 256)), dim3(256), 0, st, query_bounds, B * T, (int)T);
+    OBTE_CHECK_LAUNCH("obte_mask_bounds(init)");
+    hipLaunchKernelGGL(mask_col_bounds_kernel, dim3((unsigned)cdiv64(T, 256), (unsigned)cdiv64(T, 64), (unsigned)B), dim3(256), 0, st,
+                       (const bf16*)mask, mask_sb, mask_sh, mask_sq, B, (int)n_head, T, (const uint8_t*)row_scratch, query_bounds);
+    OBTE_CHECK_LAUNCH("obte_mask_bounds(columns)");
+    return OBTE_OK;
 }

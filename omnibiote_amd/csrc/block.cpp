@@ -205,6 +205,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     ab.qkv = qkv; ab.o = yat; ab.d_o = dyattn; ab.lse = lse; ab.delta = delta; ab.dqkv = dqkv;
     ab.rope_cos = d->rope_cos; ab.rope_sin = d->rope_sin;
     ab.key_ranges = d->key_ranges; ab.mask = d->mask; ab.mask_sb = d->mask_sb; ab.mask_sh = d->mask_sh; ab.mask_sq = d->mask_sq;
+    ab.query_bounds = d->query_bounds;
     ab.B = d->B; ab.T = d->T; ab.n_head = H; ab.head_dim = hs; ab.scale = 8.0f / (float)C;
     ab.dropout_p = d->dropout_p; ab.dropout_seed = d->dropout_seed;
     TRY(obte_attn_bwd(&ab, s));

@@ -206,13 +206,27 @@ class MaskSpec:
     """How a mask reaches the kernels: per-query key ranges (int32 [B,T,2]) or a dense additive bf16 tensor
     (B, H|1, T, T), possibly an expand() view with stride-0 heads, last dim contiguous."""
 
-    __slots__ = ("ranges", "dense", "sb", "sh", "sq")
+    __slots__ = ("ranges", "dense", "sb", "sh", "sq", "qbounds")
 
-    def __init__(self, ranges=None, dense=None):
-        self.ranges, self.dense = ranges, dense
+    def __init__(self, ranges=None, dense=None, qbounds=None):
+        """With ``dense``: ``ranges`` / ``qbounds`` are the optional loop bounds of obte_mask_bounds (per query / per key);
+        the dense values still decide every weight."""
+        self.ranges, self.dense, self.qbounds = ranges, dense, qbounds
         self.sb = self.sh = self.sq = 0
         if dense is not None:
             self.sb, self.sh, self.sq = dense.stride(0), dense.stride(1), dense.stride(2)
+
+    @staticmethod
+    def dense_with_bounds(m):
+        """A dense additive mask (B, H, T, T) plus the conservative bounds that let the kernels skip the key tiles every
+        row masks out (one pass over the mask per model forward; shared by all layers)."""
+        B, H, T, _ = m.shape
+        kb = torch.empty((B, T, 2), dtype=torch.int32, device=m.device)
+        qb = torch.empty((B, T, 2), dtype=torch.int32, device=m.device)
+        scratch = torch.empty((B * T,), dtype=torch.uint8, device=m.device)
+        L.check(L.lib().obte_mask_bounds(_ptr(m), m.stride(0), m.stride(1), m.stride(2), B, H, T, _ptr(kb), _ptr(qb), _ptr(scratch),
+                                         _stream()), "obte_mask_bounds")
+        return MaskSpec(ranges=kb, dense=m, qbounds=qb)
 
     @staticmethod
     def from_user(attn_mask, B, T, H, device):
@@ -247,7 +261,7 @@ class MaskSpec:
                 m = m.to(bf16).contiguous()
         if m.shape[1] == 1:
             m = m.expand(B, H, T, T)
-        return MaskSpec(dense=m)
+        return MaskSpec.dense_with_bounds(m)
 
 
 def attn_fwd(qkv, B, T, H, hs, scale, mask: Optional[MaskSpec] = None, dropout_p=0.0, dropout_seed=0):
@@ -269,7 +283,7 @@ def attn_bwd(qkv, o, d_o, lse, B, T, H, hs, scale, mask: Optional[MaskSpec] = No
     cos, sin = rope if rope is not None else (None, None)
     a = L.AttnBwdArgs(_ptr(qkv), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(delta), _ptr(dqkv), _ptr(cos), _ptr(sin),
                       _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq, B, T, H, hs, float(scale),
-                      float(dropout_p), int(dropout_seed))
+                      float(dropout_p), int(dropout_seed), _ptr(mask.qbounds))
     L.check(L.lib().obte_attn_bwd(C.byref(a), _stream()), "obte_attn_bwd")
     return dqkv
 
@@ -361,7 +375,7 @@ def _block_desc(B, T, Cc, H, params, rope, mask: MaskSpec, dropout_p=0.0, dropou
     ln1, attn_w, proj_w, ln2, fc_w, mlp_w = params
     return L.BlockDesc(B, T, Cc, H, _ptr(ln1), _ptr(attn_w), _ptr(proj_w), _ptr(ln2), _ptr(fc_w), _ptr(mlp_w),
                        _ptr(rope[0]), _ptr(rope[1]), _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq,
-                       float(dropout_p), int(dropout_seed))
+                       float(dropout_p), int(dropout_seed), _ptr(mask.qbounds))
 
 
 def block_fwd(x, params, rope, H, mask: MaskSpec, dropout_p=0.0, dropout_seed=0):

@@ -232,6 +232,58 @@ def test_attention_fwd_bwd(hs, T, mode):
     close(dqkv, dref, atol=1.5e-2, rtol=2.0 ** -6, what=f"attn bwd {mode}")
 
 
+@pytest.mark.parametrize("hs", [64, 128])
+def test_attention_dense_mask_bounds_edge_cases(hs):
+    """Dense additive masks reach the kernels with conservative loop bounds (obte_mask_bounds).  The cases the bounds
+    must not break: a row that masks every key (the reference's softmax then runs over the raw scores), an asymmetric
+    mask (key-side bounds differ from query-side), masks that differ per head, a soft bias (-5) that is not a mask, and
+    large fully-masked regions that do get skipped."""
+    B, H, T = 2, 2, 320
+    C = H * hs
+    scale = 8.0 / C
+    qkv, q, k, v = _attn_case(B, T, H, hs, seed=7 * hs)
+    neg = -1e9
+    m = torch.full((B, H, T, T), neg)
+    # batch 0: two blocks [0,100) and [100,320) on both heads, but head 1 additionally lets queries 10..19 see keys 250..259
+    m[0, :, :100, :100] = 0; m[0, :, 100:, 100:] = 0
+    m[0, 1, 10:20, 250:260] = 0
+    m[0, 0, 40, :] = neg                       # a fully masked row on head 0 only
+    # batch 1: asymmetric band (query q sees keys q-30 .. q), a soft bias region, and a fully masked row on both heads
+    for qq in range(T):
+        m[1, :, qq, max(0, qq - 30):qq + 1] = 0
+    m[1, :, 200:210, 0:5] = -5.0
+    m[1, :, 77, :] = neg
+    mb = m.to(BF)
+    o = ops()
+    spec = o.MaskSpec.from_user(mb.to(DEV), B, T, H, DEV)
+    assert spec.dense is not None and spec.ranges is not None and spec.qbounds is not None
+    kb, qb = spec.ranges.cpu(), spec.qbounds.cpu()
+    assert kb[0, 40].tolist() == [0, T] and kb[1, 77].tolist() == [0, T]          # fully masked rows: nothing may be skipped
+    assert kb[0, 15].tolist() == [0, 260] and kb[0, 150].tolist() == [100, T]      # union over heads
+    assert kb[1, 300].tolist() == [270, 301] and kb[1, 205].tolist() == [0, 206]   # the -5 bias is not a mask
+    assert qb[0, 255].tolist() == [10, T] and qb[1, 0].tolist()[0] == 0 and qb[1, 0].tolist()[1] == 210
+    assert qb[1, 319].tolist() == [77, 320]                                         # only the fully masked row and itself
+    qf, kf, vf = q.requires_grad_(True), k.requires_grad_(True), v.requires_grad_(True)
+    ref = R.attention(qf, kf, vf, scale, mb.float())
+    d_o = rnd(B, T, C, seed=98)
+    # fully masked rows: the forward matches the reference (uniform softmax over scores that vanish beside -1e9); the
+    # backward gives them zero weight by contract (their lse is +inf), so the reference's upstream gradient is zeroed there
+    d_ref = d_o.reshape(B, T, H, hs).transpose(1, 2).float().clone()
+    d_ref[0, 0, 40] = 0; d_ref[1, :, 77] = 0
+    ref.backward(d_ref)
+    got, lse = o.attn_fwd(qkv.to(DEV), B, T, H, hs, scale, spec)
+    close(got, ref.transpose(1, 2).reshape(B, T, C), atol=6e-3, what="dense+bounds fwd")
+    assert torch.isinf(lse[0, 0, 40]) and torch.isinf(lse[1, :, 77]).all() and torch.isfinite(lse[0, 1, 40])
+    dqkv = o.attn_bwd(qkv.to(DEV), got, d_o.to(DEV), lse, B, T, H, hs, scale, spec)
+    dref = torch.cat([g.transpose(1, 2).reshape(B, T, C) for g in (qf.grad, kf.grad, vf.grad)], dim=2)
+    close(dqkv, dref, atol=1.5e-2, rtol=2.0 ** -6, what="dense+bounds bwd")
+    # and the bounds change nothing: bitwise the same as the dense path without them
+    plain = o.MaskSpec(dense=spec.dense)
+    got2, lse2 = o.attn_fwd(qkv.to(DEV), B, T, H, hs, scale, plain)
+    assert torch.equal(got, got2) and torch.equal(lse, lse2)
+    assert torch.equal(dqkv, o.attn_bwd(qkv.to(DEV), got2, d_o.to(DEV), lse2, B, T, H, hs, scale, plain))
+
+
 def test_attention_softmax_rescale_branch():
     """Spike one key late in the sequence so the running max jumps at a later KV tile: the online-softmax
     rescale of O and l must be exact (cdna guide rule 26)."""
