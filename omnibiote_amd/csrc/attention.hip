@@ -129,6 +129,25 @@ __device__ __forceinline__ void prologue_wait_all() { __builtin_amdgcn_s_waitcnt
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Four consecutive additive-mask values of one query row (keys k0..k0+3), times log2(e).  A lane owns a query row and its
+// 16 accumulator registers cover four runs of four consecutive keys, so the dense mask is read as four 8-byte loads per
+// 32-key half instead of sixteen 2-byte ones (each of which touches 32 to 64 different cache lines per wave).
+// vec: base pointer and all strides are multiples of 4 elements (uniform, checked once per kernel).
+__device__ __forceinline__ void mask4(const bf16* mrow, int k0, int T, bool vec, float (&out)[4]) {
+    if (vec) {
+        bf16x4 v = {};
+        if (k0 < T) v = *reinterpret_cast<const bf16x4*>(mrow + k0);   // T % 4 == 0 here: the run is inside or outside as a whole
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = bf2f(v[j]) * LOG2E;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = k0 + j < T ? bf2f(mrow[k0 + j]) * LOG2E : 0.f;
+    }
+}
+__device__ __forceinline__ bool mask_vec_ok(const AttnParams& p) {
+    return ((reinterpret_cast<uintptr_t>(p.mask) & 7) == 0) && (p.mask_sb % 4 == 0) && (p.mask_sh % 4 == 0) && (p.mask_sq % 4 == 0) && (p.T % 4 == 0);
+}
+
 // accumulator register -> row index inside the 32x32 tile, for lane half h
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
@@ -211,6 +230,7 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_fwd_kernel(At
     const bf16* vbase = kbase + C;
     const bf16* mrow = nullptr;
     if (MODE == MASK_DENSE) mrow = p.mask + b * p.mask_sb + hd * p.mask_sh + (int64_t)q_c * p.mask_sq;
+    const bool mvec = MODE == MASK_DENSE && mask_vec_ok(p);
 
     float m = -INFINITY, l = 0.f;
     f32x16 o[ND];
@@ -265,11 +285,11 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_fwd_kernel(At
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float x = sc[mt][r] * scale2;
-                    const int key = key0 + 32 * mt + acc_row(r, h);
-                    if (key < T) x += bf2f(mrow[key]) * LOG2E;
-                    sc[mt][r] = x;
+                for (int i = 0; i < 4; ++i) {
+                    float mk[4];
+                    mask4(mrow, key0 + 32 * mt + 8 * i + 4 * h, T, mvec, mk);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sc[mt][4 * i + j] = sc[mt][4 * i + j] * scale2 + mk[j];
                 }
         }
         const bool inside = key0 >= ks && key0 + 64 <= ke;
@@ -442,6 +462,7 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bw
     const bf16* vbase = kbase + C;
     const bf16* mrow = nullptr;
     if (MODE == MASK_DENSE) mrow = p.mask + b * p.mask_sb + hd * p.mask_sh + (int64_t)q_c * p.mask_sq;
+    const bool mvec = MODE == MASK_DENSE && mask_vec_ok(p);
 
     f32x16 dq[ND];
 #pragma unroll
@@ -482,18 +503,24 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bw
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vt, 32 * mt, s, lane), dof[s], dp, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + 32 * mt + acc_row(r, h);
-                float x = sc[r] * scale2 - lse2;
-                if (MODE == MASK_DENSE) { if (key < T) x += bf2f(mrow[key]) * LOG2E; }
-                float pv = fast_exp2(x);
-                if (key < ks || key >= ke) pv = 0.f;
-                float dpd = dp[r];
-                if (DROP) {
-                    const uint64_t di = (((uint64_t)b * p.H + hd) * T + q_c) * (uint64_t)T + (uint64_t)key;
-                    dpd = drop_keep(di, p.drop) ? dpd * p.drop.scale : 0.f;
+            for (int i = 0; i < 4; ++i) {
+                float mk[4] = {0.f, 0.f, 0.f, 0.f};
+                if (MODE == MASK_DENSE) mask4(mrow, key0 + 32 * mt + 8 * i + 4 * h, T, mvec, mk);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * i + j;
+                    const int key = key0 + 32 * mt + acc_row(r, h);
+                    float x = sc[r] * scale2 - lse2;
+                    if (MODE == MASK_DENSE) x += mk[j];
+                    float pv = fast_exp2(x);
+                    if (key < ks || key >= ke) pv = 0.f;
+                    float dpd = dp[r];
+                    if (DROP) {
+                        const uint64_t di = (((uint64_t)b * p.H + hd) * T + q_c) * (uint64_t)T + (uint64_t)key;
+                        dpd = drop_keep(di, p.drop) ? dpd * p.drop.scale : 0.f;
+                    }
+                    sc[r] = pv * (dpd - dl);   // dS^T (without the scale factor)
                 }
-                sc[r] = pv * (dpd - dl);   // dS^T (without the scale factor)
             }
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
