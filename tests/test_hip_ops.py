@@ -564,6 +564,26 @@ def test_linear_bwd_grouped_pair_matches_two_launches(monkeypatch, accumulate):
     assert not o.linear_bwd_pair_is_grouped(8192, 4096, 1024)
 
 
+def test_gemm_plan_cache_round_trip(tmp_path):
+    """tune -> save_plans -> plan_clear -> load_plans: the same plans are installed again without a launch, and a GEMM
+    that uses them still matches the fp32 reference."""
+    import json
+    from omnibiote_amd import tune
+    M, N, K = 512, 1024, 2048
+    v, bn, splits, ms = tune.tune_gemm(M, N, K, False, False, L().EPI_NONE)
+    path = str(tmp_path / "plans.json")
+    tune.save_plans(path)
+    rows = json.load(open(path))
+    mine = [r for r in rows if (r["M"], r["N"], r["K"], r["a_kmajor"], r["b_kmajor"]) == (M, N, K, False, False)]
+    assert len(mine) == 1 and (mine[0]["variant"], mine[0]["bn"], mine[0]["splits"]) == (v, bn, splits)
+    L().check(L().lib().obte_gemm_plan_clear(), "obte_gemm_plan_clear")
+    assert tune.load_plans(path) == len(rows)
+    dy, x = rnd(K, M, seed=3, scale=0.5), rnd(K, N, seed=4, scale=0.5)
+    close(ops().linear_wgrad(dy.to(DEV), x.to(DEV)), dy.float().t() @ x.float(), atol=0.01 * math.sqrt(K), what="wgrad under a re-loaded plan")
+    with pytest.raises(RuntimeError, match="bad plan"):
+        L().check(L().lib().obte_gemm_plan_set(0, 0, 0, M, N, K, 9, 128, 1), "obte_gemm_plan_set")
+
+
 def test_multi_tensor_adamw_matches_single_tensor_kernel():
     """The multi-tensor launch (<= 32 tensors per kernel, per-tensor lr / weight decay / step) must reproduce the
     single-tensor kernel bit for bit, and the multi-tensor sum of squares must equal the sum of the single ones."""
