@@ -370,35 +370,6 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_fwd_kernel(At
     }
 }
 
-// ==========================================================================================================
-// backward, part 0: delta[b,h,t] = sum_d dO * O   (one 8-element chunk per lane, D/8 lanes per (row, head))
-// ==========================================================================================================
-template <int D>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ d_o,
-                                                          float* __restrict__ delta, int64_t B, int64_t T, int H) {
-    constexpr int LPR = D / 8;
-    const int C = H * D;
-    const int64_t total = B * T * H * LPR;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float s = 0.f;
-    int64_t bt = 0; int hd = 0;
-    if (i < total) {
-        const int64_t item = i / LPR;
-        const int c8 = (int)(i % LPR);
-        bt = item / H; hd = (int)(item % H);
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(o + bt * C + hd * D + c8 * 8);
-        const bf16x8 g = *reinterpret_cast<const bf16x8*>(d_o + bt * C + hd * D + c8 * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += bf2f(a[j]) * bf2f(g[j]);
-    }
-#pragma unroll
-    for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (i < total && (i % LPR) == 0) {
-        const int64_t bb = bt / T, t = bt % T;
-        delta[(bb * H + hd) * T + t] = s;
-    }
-}
-
 // inverse RoPE on 4 consecutive head-dim elements (d0 multiple of 4) of a gradient row at position t
 __device__ __forceinline__ void rope_inv4(float (&g)[4], const float* cos_t, const float* sin_t, int64_t t, int D, int d0) {
     if (!cos_t) return;
@@ -441,7 +412,20 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bw
         dof[s] = *reinterpret_cast<const bf16x8*>(doptr + 16 * s + 8 * h);
     }
     const float lse2 = p.lse_in[(b * p.H + hd) * T + q_c] * LOG2E;
-    const float dl = p.delta[(b * p.H + hd) * T + q_c];
+    // delta = rowsum(O * dO), computed here from the dO fragments already in registers (it used to be a kernel of its
+    // own: one 9-us launch per layer) and published for the dK/dV kernel, which runs after this one on the same stream
+    float dl = 0.f;
+    {
+        const bf16* optr = p.o_in + (b * T + q_c) * C + hd * D;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(optr + 16 * s + 8 * h);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += bf2f(of[j]) * bf2f(dof[s][j]);
+        }
+        dl += __shfl_xor(dl, 32, 64);
+        if (h == 0 && q_ok) p.delta[(b * p.H + hd) * T + q_row] = dl;
+    }
 
     int ks = 0, ke = T;
     if (MODE == MASK_RANGES) {
@@ -782,11 +766,6 @@ int launch_fwd(const AttnParams& p, int mode, hipStream_t st) {
 
 template <int D>
 int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
-    {
-        const int64_t total = p.B * p.T * p.H * (D / 8);
-        hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, p.o_in, p.d_o, p.delta, p.B, p.T, p.H);
-        OBTE_CHECK_LAUNCH("obte_attn_bwd(delta)");
-    }
     {
         const int smem = 4 * 64 * 2 * D + 64;
         const dim3 grid_d((unsigned)cdiv64(p.T, 32 * FwdShape<true>::NW), p.H, (unsigned)p.B), block_d(64 * FwdShape<true>::NW);
