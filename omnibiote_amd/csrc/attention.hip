@@ -148,6 +148,18 @@ __device__ __forceinline__ bool mask_vec_ok(const AttnParams& p) {
     return ((reinterpret_cast<uintptr_t>(p.mask) & 7) == 0) && (p.mask_sb % 4 == 0) && (p.mask_sh % 4 == 0) && (p.mask_sq % 4 == 0) && (p.T % 4 == 0);
 }
 
+// Workgroup -> (row block, head, batch).  The grid is one-dimensional and remapped so that the workgroups an XCD
+// receives (block id % 8) cover a CONTIGUOUS range of work ids, with the row blocks of one (batch, head) adjacent: the
+// blocks that stream the same K/V (or Q/dO) through LDS then share one L2 instead of pulling it into up to four.
+struct BlockId { int blk, hd; int64_t b; };
+__device__ __forceinline__ BlockId block_id(int nblk, int H) {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int pair = w / nblk;
+    return BlockId{w % nblk, pair % H, (int64_t)(pair / H)};
+}
+
 // accumulator register -> row index inside the 32x32 tile, for lane half h
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
@@ -196,12 +208,13 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_fwd_kernel(At
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    const int hd = blockIdx.y;
-    const int64_t b = blockIdx.z;
+    const BlockId bid_ = block_id((int)((p.T + 32 * NW - 1) / (32 * NW)), p.H);
+    const int hd = bid_.hd;
+    const int64_t b = bid_.b;
     const int T = (int)p.T;
     const int C = p.H * D;
     const int64_t ld = 3 * (int64_t)C;
-    const int q_row = blockIdx.x * (32 * NW) + wave * 32 + (lane & 31);
+    const int q_row = bid_.blk * (32 * NW) + wave * 32 + (lane & 31);
     const bool q_ok = q_row < T;
     const int q_c = q_ok ? q_row : T - 1;
 
@@ -394,12 +407,13 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bw
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    const int hd = blockIdx.y;
-    const int64_t b = blockIdx.z;
+    const BlockId bid_ = block_id((int)((p.T + 32 * NW - 1) / (32 * NW)), p.H);
+    const int hd = bid_.hd;
+    const int64_t b = bid_.b;
     const int T = (int)p.T;
     const int C = p.H * D;
     const int64_t ld = 3 * (int64_t)C;
-    const int q_row = blockIdx.x * (32 * NW) + wave * 32 + (lane & 31);
+    const int q_row = bid_.blk * (32 * NW) + wave * 32 + (lane & 31);
     const bool q_ok = q_row < T;
     const int q_c = q_ok ? q_row : T - 1;
 
@@ -556,12 +570,13 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kern
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    const int hd = blockIdx.y;
-    const int64_t b = blockIdx.z;
+    const BlockId bid_ = block_id((int)((p.T + 32 * NW - 1) / (32 * NW)), p.H);
+    const int hd = bid_.hd;
+    const int64_t b = bid_.b;
     const int T = (int)p.T;
     const int C = p.H * D;
     const int64_t ld = 3 * (int64_t)C;
-    const int key = blockIdx.x * (32 * NW) + wave * 32 + (lane & 31);
+    const int key = bid_.blk * (32 * NW) + wave * 32 + (lane & 31);
     const bool k_ok = key < T;
     const int key_c = k_ok ? key : T - 1;
 
@@ -573,7 +588,7 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kern
     {
         TileDma<D, 32 * NW, NW> dmv;
         dmv.init(wave, lane, ld);
-        const int64_t row0 = (int64_t)blockIdx.x * (32 * NW);
+        const int64_t row0 = (int64_t)bid_.blk * (32 * NW);
         dmv.issue(p.qkv + (b * T + row0) * ld + 2 * C + hd * D, (((int64_t)T - row0) * ld - (2 * C + hd * D)) * 2, Vblk, wave);
     }
     // by symmetry of the mask, the queries that see this key are the keys this position sees as a query
@@ -746,8 +761,8 @@ int mask_mode(const int32_t* ranges, const obte_bf16* mask) { return mask ? MASK
 template <int D>
 int launch_fwd(const AttnParams& p, int mode, hipStream_t st) {
     const int smem = 2 * FwdShape<false>::STAGES * 64 * 2 * D + 64;   // >= the dropout variant's two stages
-    const dim3 grid_d((unsigned)cdiv64(p.T, 32 * FwdShape<true>::NW), p.H, (unsigned)p.B), block_d(64 * FwdShape<true>::NW);
-    const dim3 grid((unsigned)cdiv64(p.T, 32 * FwdShape<false>::NW), p.H, (unsigned)p.B), block(64 * FwdShape<false>::NW);
+    const dim3 grid_d((unsigned)(cdiv64(p.T, 32 * FwdShape<true>::NW) * p.H * p.B)), block_d(64 * FwdShape<true>::NW);
+    const dim3 grid((unsigned)(cdiv64(p.T, 32 * FwdShape<false>::NW) * p.H * p.B)), block(64 * FwdShape<false>::NW);
 #define GO(M)                                                                                 \
     do {                                                                                      \
         if (p.drop.thresh24) {                                                                \
@@ -768,8 +783,8 @@ template <int D>
 int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
     {
         const int smem = 4 * 64 * 2 * D + 64;
-        const dim3 grid_d((unsigned)cdiv64(p.T, 32 * FwdShape<true>::NW), p.H, (unsigned)p.B), block_d(64 * FwdShape<true>::NW);
-        const dim3 grid((unsigned)cdiv64(p.T, 32 * FwdShape<false>::NW), p.H, (unsigned)p.B), block(64 * FwdShape<false>::NW);
+        const dim3 grid_d((unsigned)(cdiv64(p.T, 32 * FwdShape<true>::NW) * p.H * p.B)), block_d(64 * FwdShape<true>::NW);
+        const dim3 grid((unsigned)(cdiv64(p.T, 32 * FwdShape<false>::NW) * p.H * p.B)), block(64 * FwdShape<false>::NW);
 #define GO(M)                                                                                    \
     do {                                                                                         \
         if (p.drop.thresh24) {                                                                   \
@@ -786,8 +801,8 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
     }
     {
         const int smem = 2 * (2 * 32 * 2 * D + 256) + 32 * FwdShape<false>::NW * 2 * D + 64;   // >= the dropout variant's
-        const dim3 grid_d((unsigned)cdiv64(p.T, 32 * FwdShape<true>::NW), p.H, (unsigned)p.B), block_d(64 * FwdShape<true>::NW);
-        const dim3 grid((unsigned)cdiv64(p.T, 32 * FwdShape<false>::NW), p.H, (unsigned)p.B), block(64 * FwdShape<false>::NW);
+        const dim3 grid_d((unsigned)(cdiv64(p.T, 32 * FwdShape<true>::NW) * p.H * p.B)), block_d(64 * FwdShape<true>::NW);
+        const dim3 grid((unsigned)(cdiv64(p.T, 32 * FwdShape<false>::NW) * p.H * p.B)), block(64 * FwdShape<false>::NW);
 #define GO(M)                                                                                      \
     do {                                                                                           \
         if (p.drop.thresh24) {                                                                     \
@@ -813,6 +828,7 @@ static int check_common(const char* who, const void* qkv, int64_t B, int64_t T, 
     OBTE_REQUIRE(B > 0 && T > 0 && H > 0 && B < 65536 && H < 65536, "%s: bad B/T/H", who);
     OBTE_REQUIRE(D == 64 || D == 128, "%s: head_dim must be 64 or 128 (got %d)", who, D);
     OBTE_REQUIRE(T < (1 << 24), "%s: T too large", who);
+    OBTE_REQUIRE(B * H * ((T + 127) / 128) < (1ll << 30), "%s: too many (batch, head, row block) workgroups", who);
     return OBTE_OK;
 }
 
