@@ -15,19 +15,20 @@ _lib.lib()
 h = bench.harness_args(cfg, a, 1)
 tune.tune_model_shapes(8 * 1024, 1024, 2 ** 16, device=dev)
 reps = []
-for r in range(2):
+NREP = int(os.environ.get('NREP', '2'))
+for r in range(NREP):
     torch.manual_seed(1234 + r)
     with contextlib.redirect_stdout(io.StringIO()):
         m = TE.build_model(h, dev)
     opt, sched = TE.build_optimizer(m, h, 1000)
-    reps.append(TE.TrainStep(m, opt, sched, mini_batch_size=8, n_head=8))
+    reps.append(TE.TrainStep(m, opt, sched, mini_batch_size=8, n_head=8, pipeline_streams=1))
 rng = np.random.default_rng(0)
 batch = torch.from_numpy(TE.synthetic_rows(128, 1024, 2 ** 16, rng, single_document=True)).to(dev)
-streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+streams = [torch.cuda.Stream() for _ in range(NREP)]
 def run(concurrent, steps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps):
-        for r in range(2):
+        for r in range(NREP):
             s = streams[r] if concurrent else streams[0]
             with torch.cuda.stream(s):
                 reps[r](batch)
@@ -35,4 +36,4 @@ def run(concurrent, steps):
 run(False, 1); run(True, 1)
 for name, c in (("sequential", False), ("concurrent", True), ("sequential", False), ("concurrent", True)):
     t = run(c, 3)
-    print(f"{name}: {t * 1e3:.1f} ms per pair of steps -> {2 * 128 * 1024 / t:.0f} tokens/s", flush=True)
+    print(f"{name}: {t * 1e3:.1f} ms per {NREP} steps -> {NREP * 128 * 1024 / t:.0f} tokens/s", flush=True)
