@@ -365,6 +365,41 @@ def test_masked_ce(rows, V):
     assert dl.float().sum(1).abs().max().item() < 1e-3
 
 
+def test_full_size_properties_of_the_memory_bound_kernels():
+    """BASELINE config 2 sizes (8192 rows, 1024 features, 65536 classes), size-independent properties:
+    LayerNorm rows have zero mean / unit variance for w = 1 and its input gradient is orthogonal to the all-ones vector
+    and to x_hat; cross-entropy gradient rows vanish off the mask and sum to zero on it, and the loss of uniform logits is
+    log V; an embedding round trip conserves mass."""
+    o = ops()
+    M, Cc, V = 8192, 1024, 65536
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = (torch.randn(M, Cc, device=DEV, generator=g) * 3 + 1).to(BF)
+    w = torch.ones(Cc, device=DEV, dtype=BF)
+    y, mean, rstd = o.layernorm_fwd(x, w)
+    yf = y.float()
+    assert yf.mean(1).abs().max().item() < 2e-2 and (yf.var(1, unbiased=False) - 1).abs().max().item() < 3e-2
+    dy = torch.randn(M, Cc, device=DEV, generator=g).to(BF)
+    dx, dw = o.layernorm_bwd(dy, x, w, mean, rstd)
+    xhat = (x.float() - mean[:, None]) * rstd[:, None]
+    assert dx.float().sum(1).abs().max().item() < 0.3 and (dx.float() * xhat).sum(1).abs().max().item() < 1.0   # bf16 rows of ~1e3 terms
+    close(dw, (dy.float() * xhat).sum(0), atol=2.5, rtol=2.0 ** -6, what="ln dw full size")
+    # cross entropy: uniform logits -> loss = log V exactly; gradient structure
+    tgt = torch.randint(0, V, (M,), device=DEV, generator=g)
+    mask = torch.rand(M, device=DEV, generator=g) < 0.15
+    logits = torch.zeros(M, V, device=DEV, dtype=BF)
+    loss, dl = o.masked_ce(logits, tgt, mask, 1)
+    assert abs(loss.item() - math.log(V)) < 1e-3
+    assert (dl[~mask] == 0).all()
+    rows = dl[mask].float()
+    assert rows.sum(1).abs().max().item() < 1e-4 and (rows.min(1).values < 0).all()     # one negative entry (the target) per row
+    del logits, dl, rows
+    # embedding: scatter-add of all-ones rows gives the token histogram
+    idx = torch.randint(0, V, (M,), device=DEV, generator=g)
+    dwte = o.embedding_bwd(idx, torch.ones(M, Cc, device=DEV, dtype=BF), V)
+    hist = torch.bincount(idx, minlength=V).float()
+    assert torch.equal(dwte[:, 0].float(), hist) and torch.equal(dwte[:, -1].float(), hist)
+
+
 def test_adamw_matches_fp32_formula():
     n = 4096 + 8
     p, g = rnd(n, seed=1), rnd(n, seed=2, scale=0.1)
