@@ -394,7 +394,7 @@ __device__ __forceinline__ void rope_inv4(float (&g)[4], const float* cos_t, con
 }
 
 // ==========================================================================================================
-// backward, part 1: dQ.  Same shape as forward: 128 queries per workgroup, query on the lane.
+// backward, part 1: dQ (and delta).  Same shape as forward: 256 queries per workgroup (128 with dropout), query on the lane.
 //   S^T = K Q^T ; P^T = exp(S^T*scale + mask - lse) ; dP^T = V dO^T ; dS^T = P^T (dP^T - delta) ; dQ^T += K^T dS^T
 // ==========================================================================================================
 // 256 queries (eight waves) per workgroup without dropout, for the same reason as the forward: K/V traffic per query.
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bw
 }
 
 // ==========================================================================================================
-// backward, part 2: dK and dV.  128 keys per workgroup (32 per wave), key on the lane; queries stream through
+// backward, part 2: dK and dV.  256 keys per workgroup (128 with dropout; 32 per wave), key on the lane; queries stream through
 // LDS in 32-row tiles (Q and dO, plus their lse/delta).
 //   S = Q K^T ; P = exp(S*scale + mask - lse) ; dP = dO V^T ; dS = P (dP - delta)
 //   dV^T += dO^T P ; dK^T += Q^T dS
