@@ -58,7 +58,7 @@ def parse():
     p.add_argument("--no_roofline", action="store_true")
     p.add_argument("--dense_mask", action="store_true",
                    help="pass the reference's dense additive (B,H,T,T) mask (expand view) instead of key ranges")
-    p.add_argument("--no_variants", action="store_true", help="skip the extra masked-rows-readout measurement")
+    p.add_argument("--no_variants", action="store_true", help="skip the extra measurements (masked-rows readout, dropout 0.1, dense-mask calling convention)")
     p.add_argument("--pipeline_streams", type=int, default=2, choices=[1, 2],
                    help="2: forward of micro-batch j+1 beside the backward of micro-batch j on a second HIP stream (bitwise the same results)")
     p.add_argument("--plan_cache", default="", help="JSON file of tuned GEMM plans: loaded if present (no tuning launches), else tuned and written")
@@ -80,7 +80,28 @@ def harness_args(cfg, a, world):
 KIND_NAMES = {12: "gemm_fwd(NT)", 13: "gemm_fwd(NT)+gelu", 14: "gemm_fwd(NT)+residual", 16: "gemm_fwd(NT)+residual+dropout",
               17: "gemm_fwd(NT)+rope", 8: "gemm_dgrad(NN)", 11: "gemm_dgrad(NN)+gelu_bwd", 0: "gemm_wgrad(TN)",
               2: "gemm_wgrad(TN)+accumulate", 32: "gemm_grouped(wgrads)", 34: "gemm_grouped(wgrads)+accumulate",
-              33: "gemm_grouped(wgrads+dgrad)", 35: "gemm_grouped(wgrads+dgrad)+accumulate", 100: "attn_fwd", 101: "attn_bwd"}
+              33: "gemm_grouped(wgrads+dgrad)", 35: "gemm_grouped(wgrads+dgrad)+accumulate", 100: "attn_fwd", 101: "attn_bwd",
+              102: "lm_head+CE fused fwd", 103: "lm_head+CE fused bwd"}
+# profiler kind = code above + 1000 * kernel structure: the name rocprofv3 --kernel-trace shows for that launch
+STRUCT_NAMES = {1: "gemm_bf16_kernel", 2: "gemm_v2_kernel", 3: "gemm_v3_kernel"}
+GEMM_FAMILY = "bf16 MFMA GEMM family: gemm_bf16_kernel, gemm_v2_kernel, gemm_v3_kernel, gemm_v3_group_kernel"
+
+
+def rocprof_name(k: int) -> str:
+    code, struct = int(k) % 1000, int(k) // 1000
+    if code >= 100:
+        return KIND_NAMES.get(code, str(code))
+    if 32 <= code < 40:
+        return "gemm_v3_group_kernel"
+    return STRUCT_NAMES.get(struct, "gemm_v2_kernel")
+
+
+def launch_flops(code: int, d0, d1, d2) -> float:
+    if code in (100, 101):   # attention: fwd 4*T*T*D per (b,h); bwd 2.5x (five products) — algorithmic, recompute not counted
+        return 4.0 * d0 * d1 * d1 * d2 * (1.0 if code == 100 else 2.5)
+    if code in (102, 103):   # fused readout + CE: forward 2*M*V*C, backward twice that (recompute not counted)
+        return 2.0 * d0 * d1 * d2 * (1.0 if code == 102 else 2.0)
+    return 2.0 * d0 * d1 * d2
 
 
 def collect_profile(cap=200000):
@@ -94,59 +115,57 @@ def collect_profile(cap=200000):
 
 
 def roofline_from_profile(ms, dims, kind, n_steps):
-    """Group launches by kernel family; the dominant family (largest total time) becomes ``roofline``."""
-    fam = {}
+    """Group launches by kernel family; the dominant family (largest total time) becomes ``roofline``; inside it every
+    kernel is also listed under the name rocprofv3 shows for it, with the dominant single kernel named."""
+    fam, by_kind, by_kernel = {}, {}, {}
     for t, (d0, d1, d2), k in zip(ms, dims, kind):
-        if k >= 100:
-            # attention: fwd 4*T*T*D per (b,h) ; bwd 2.5x that (five products) — algorithmic, recompute not counted
-            flops = 4.0 * d0 * d1 * d1 * d2 * (1.0 if k == 100 else 2.5)
-            name = KIND_NAMES[int(k)]
-        else:
-            flops = 2.0 * d0 * d1 * d2
-            name = "gemm_bf16_kernel"
-        f = fam.setdefault(name, dict(time_ms=0.0, flops=0.0, launches=0))
-        f["time_ms"] += float(t); f["flops"] += flops; f["launches"] += 1
-    by_kind = {}
-    for t, (d0, d1, d2), k in zip(ms, dims, kind):
-        e = by_kind.setdefault(KIND_NAMES.get(int(k), str(int(k))), dict(time_ms=0.0, flops=0.0, launches=0))
-        e["time_ms"] += float(t); e["launches"] += 1
-        e["flops"] += 2.0 * d0 * d1 * d2 if k < 100 else 4.0 * d0 * d1 * d1 * d2 * (1.0 if k == 100 else 2.5)
+        code = int(k) % 1000
+        flops = launch_flops(code, d0, d1, d2)
+        name = GEMM_FAMILY if code < 100 else KIND_NAMES.get(code, str(code))
+        for table, key in ((fam, name), (by_kind, KIND_NAMES.get(code, str(code))), (by_kernel, rocprof_name(k))):
+            e = table.setdefault(key, dict(time_ms=0.0, flops=0.0, launches=0))
+            e["time_ms"] += float(t); e["flops"] += flops; e["launches"] += 1
     dom = max(fam, key=lambda n: fam[n]["time_ms"])
     f = fam[dom]
     achieved = f["flops"] / (f["time_ms"] * 1e-3) / 1e12
+    n_steps = max(n_steps, 1)
+
+    def row(e):
+        tf = e["flops"] / (e["time_ms"] * 1e-3) / 1e12
+        return {"ms_per_step": round(e["time_ms"] / n_steps, 3), "tflops": round(tf, 1), "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+                "launches_per_step": e["launches"] // n_steps, "avg_launch_us": round(e["time_ms"] / e["launches"] * 1e3, 1)}
+    kernels = {n: row(e) for n, e in sorted(by_kernel.items(), key=lambda kv: -kv[1]["time_ms"])}
+    gemm_kernels = [n for n in kernels if n.startswith("gemm")]
     roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-            "launches_per_step": f["launches"] // max(n_steps, 1),
+            "launches_per_step": f["launches"] // n_steps,
             "avg_launch_ms": round(f["time_ms"] / f["launches"], 4),
             "avg_launch_gflop": round(f["flops"] / f["launches"] / 1e9, 3),
             "share_of_profiled_time": round(f["time_ms"] / sum(x["time_ms"] for x in fam.values()), 3),
-            "breakdown": {n: {"ms_per_step": round(e["time_ms"] / max(n_steps, 1), 3),
-                               "tflops": round(e["flops"] / (e["time_ms"] * 1e-3) / 1e12, 1),
-                               "launches_per_step": e["launches"] // max(n_steps, 1)} for n, e in sorted(by_kind.items())}}
+            "dominant_kernel_by_rocprof_name": gemm_kernels[0] if (dom == GEMM_FAMILY and gemm_kernels) else dom,
+            "by_rocprof_kernel": kernels,
+            "breakdown": {n: row(e) for n, e in sorted(by_kind.items())}}
     return roof
 
 
-def cpu_baseline(cfg, mini_rows=1, steps=3, warmup=1, device="cpu", rows=None):
-    """The oracle's train step (fwd + masked CE + bwd + clip + AdamW), bf16 like the GPU run: on the host cores (the
-    `cpu_baseline` object), or — same module, same step, `device="cuda"` — as eager PyTorch-ROCm ops on the GPU the
-    HIP path just ran on (`eager_gpu_baseline`: what the reference's own op set costs on this hardware)."""
+def oracle_step_rate(cfg, mini_rows, steps, warmup, device, rows, dtype, threads, budget_s=45.0):
+    """tokens/s of the oracle's train step (fwd + masked CE + bwd + clip + AdamW) on ``device``; median of the timed steps.
+    ``budget_s`` bounds the sample: timing stops early (never below 3 timed steps) once that much wall time is spent."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import omnibiote_ref as R
     from omnibiote_amd import train_encoder as TE
-    threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     rc = R.RefConfig(block_size=cfg["ctx_len"], vocab_size=2 ** 16, n_layer=cfg["n_layer"], n_head=cfg["n_head"], n_embd=cfg["n_embd"])
     torch.manual_seed(0)
     shapes = R.param_shapes(rc)
-    w = {k: (torch.randn(s) * (1.0 if "wte" in k else 0.02) + (1.0 if "ln_" in k else 0.0)).bfloat16().to(device) for k, s in shapes.items()}
+    w = {k: (torch.randn(s) * (1.0 if "wte" in k else 0.02) + (1.0 if "ln_" in k else 0.0)).to(dtype).to(device) for k, s in shapes.items()}
     enc = R.OracleEncoder(rc, w)
-    enc.rope = R.cast_rope_table(R.rope_table(rc.n_embd // rc.n_head, rc.block_size), torch.bfloat16).to(device)
+    enc.rope = R.cast_rope_table(R.rope_table(rc.n_embd // rc.n_head, rc.block_size), dtype).to(device)
     opt = torch.optim.AdamW(enc.parameters(), lr=1e-3)
     step = TE.TrainStep(enc, opt, None, mini_batch_size=mini_rows, n_head=rc.n_head, loss_impl="torch", mask_impl="dense")
     rng = np.random.default_rng(0)
-    rows = rows or mini_rows
     ids = torch.from_numpy(TE.synthetic_rows(rows, cfg["ctx_len"], 2 ** 16, rng)).to(device)
-    times = []
+    times, t_begin = [], time.perf_counter()
     for i in range(warmup + steps):
         if device != "cpu":
             torch.cuda.synchronize()
@@ -155,24 +174,70 @@ def cpu_baseline(cfg, mini_rows=1, steps=3, warmup=1, device="cpu", rows=None):
         if device != "cpu":
             torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
-    t = float(np.median(times[warmup:]))
-    where = f"host cores ({threads} threads; host has {os.cpu_count()} logical CPUs)" if device == "cpu" else "eager PyTorch-ROCm ops on cuda:0"
-    return {"value": round(rows * cfg["ctx_len"] / t, 1), "unit": "tokens/s", "cores": threads if device == "cpu" else 0, "kind": "port",
-            "sample": f"oracle train step (fwd+masked CE+bwd+clip+AdamW) on {where}, {rows} row(s) x {cfg['ctx_len']} tokens in "
-                      f"micro-batches of {mini_rows}, bf16, dense additive masks, median of {steps} steps after {warmup} warm-up"}
+        if len(times) - warmup >= 3 and time.perf_counter() - t_begin > budget_s:
+            break
+    timed = times[warmup:]
+    return rows * cfg["ctx_len"] / float(np.median(timed)), len(timed)
+
+
+def cpu_baseline(cfg, mini_rows=8, steps=5, warmup=2, device="cpu", rows=None):
+    """SURVEY.md §8(d) protocol: the oracle's train step on the host cores at the workload's own micro-batch (the
+    largest B the step ever sees), every core this process may use, median of >= 5 steps after 2 warm-ups (fewer, never
+    below 3, if the time budget runs out), in bf16 (the regime of the GPU run: `value`) and in fp32 (`fp32`).
+    With device="cuda" the same module runs as eager PyTorch-ROCm ops (`eager_gpu_baseline`, informational)."""
+    rows = rows or mini_rows
+    if device != "cpu":
+        v, n = oracle_step_rate(cfg, mini_rows, steps, warmup, device, rows, torch.bfloat16, torch.get_num_threads())
+        return {"value": round(v, 1), "unit": "tokens/s", "cores": 0, "kind": "port",
+                "sample": f"oracle train step as eager PyTorch-ROCm ops on cuda:0, {rows} rows x {cfg['ctx_len']} tokens in micro-batches of "
+                          f"{mini_rows}, bf16, dense additive masks, median of {n} steps after {warmup} warm-up"}
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    threads = max(1, usable)
+    v16, n16 = oracle_step_rate(cfg, mini_rows, steps, warmup, "cpu", rows, torch.bfloat16, threads)
+    v32, n32 = oracle_step_rate(cfg, mini_rows, steps, warmup, "cpu", rows, torch.float32, threads)
+    return {"value": round(v16, 1), "unit": "tokens/s", "cores": threads, "kind": "port", "dtype": "bf16",
+            "fp32": {"value": round(v32, 1), "unit": "tokens/s", "steps": n32},
+            "host": {"logical_cpus": os.cpu_count(), "usable_by_this_process": usable, "torch_threads": threads},
+            "sample": f"oracle (oracle/omnibiote_ref.py) train step fwd+masked CE+bwd+clip+AdamW on the host cores, one micro-batch of "
+                      f"{mini_rows} rows x {cfg['ctx_len']} tokens per step, dense additive masks, dropout 0; bf16: median of {n16} steps, "
+                      f"fp32: median of {n32} steps, each after {warmup} warm-ups"}
+
+
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process group (one rank per GPU,
+    `python -m torch.distributed.run`, rendezvous on 127.0.0.1) before this process has made any HIP call, pass the
+    child's output through (rank 0 prints the JSON line) and return its exit code.  No exec: the parent only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's intra-node transport needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n_gpus, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     a = parse()
     cfg = CONFIGS[a.config]
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        dist.init_process_group("nccl")   # RCCL
-    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    if a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; drop WORLD_SIZE (bench.py then starts its own ranks) or "
+                         f"launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)   # RCCL; device_id binds the communicator to this rank's GPU up front
     from omnibiote_amd import _lib
     from omnibiote_amd import train_encoder as TE
     _lib.lib()   # fail loudly, before any timing, if the HIP library is missing
@@ -189,7 +254,14 @@ def main():
     if a.plan_cache and os.path.exists(a.plan_cache):
         tune.load_plans(a.plan_cache)
     else:
+        # every rank times the candidates on its own GPU (in parallel), then all adopt rank 0's table, so that the N
+        # replicas run the same kernels (same arithmetic, same speed)
         tune.tune_model_shapes(a.mini_batch_size * cfg["ctx_len"], cfg["n_embd"], 2 ** 16, device=dev, verbose=(rank == 0 and bool(a.shapes_out)))
+        if world > 1:
+            box = [tune.export_plans() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            if rank != 0:
+                tune.import_plans(box[0])
         if a.plan_cache and rank == 0:
             tune.save_plans(a.plan_cache)
     force_ddp = os.environ.get("OBTE_FORCE_DDP") == "1"   # rehearse the N>1 code path on one GPU
@@ -245,36 +317,43 @@ def main():
             roofline = roofline_from_profile(ms, dims, kind, 1)
             # HBM bytes per launch of the GEMM family: PMC counters cannot be read from inside this process, so the
             # figure comes from the committed rocprofv3 --pmc passes over this same workload (tools/pmc_traffic.py)
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_family_traffic.json")
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_gemm_family_traffic.json", "r01_pmc_gemm_family_traffic.json"))
+                        if os.path.exists(q)), "")
             default_workload = (a.config == "small" and not a.masked_lm_head and a.dropout == 0.0 and not a.multi_document
                                 and a.rows_per_rank == 128 and a.mini_batch_size == 8)
-            if default_workload and os.path.exists(pmc):
+            if default_workload and pmc:
                 with open(pmc) as f:
                     t = json.load(f)
                 roofline["traffic"] = round(t["traffic_bytes_per_launch"])
-                roofline["traffic_unit"] = "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_gemm_family_traffic.json)"
+                roofline["traffic_unit"] = "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE)"
+                roofline["traffic_source"] = f"committed PMC pass ({os.path.basename(pmc)}): a static, pre-recorded figure, not measured in this run"
             if a.shapes_out:
                 tab = {}
                 for t, d, k in zip(ms, dims, kind):
-                    key = (KIND_NAMES.get(int(k), str(int(k))), int(d[0]), int(d[1]), int(d[2]))
+                    key = (KIND_NAMES.get(int(k) % 1000, str(int(k))) + " [" + rocprof_name(k) + "]", int(d[0]), int(d[1]), int(d[2]), int(k) % 1000)
                     e = tab.setdefault(key, [0, 0.0])
                     e[0] += 1; e[1] += float(t)
                 with open(a.shapes_out, "w") as f:
-                    f.write(f"{'kernel':28s} {'d0':>7s} {'d1':>7s} {'d2':>7s} {'calls':>6s} {'avg_us':>9s} {'TFLOP/s':>8s} {'ms/step':>8s}\n")
-                    for (name, d0, d1, d2), (n, tt) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
-                        fl = 2.0 * d0 * d1 * d2 if not name.startswith("attn") else 4.0 * d0 * d1 * d1 * d2 * (1.0 if name == "attn_fwd" else 2.5)
-                        f.write(f"{name:28s} {d0:7d} {d1:7d} {d2:7d} {n:6d} {tt / n * 1e3:9.1f} {fl * n / (tt * 1e-3) / 1e12:8.1f} {tt:8.2f}\n")
-    # Not the headline: the same step with the readout and the cross entropy restricted to the ~15 % MLM-masked rows
-    # (TrainStep lm_head_impl="masked": same loss and gradients, rows outside the mask contribute exact zeros).  Reported
-    # beside `value`, which keeps the reference's full logits.
+                    f.write(f"{'launch [rocprof kernel name]':62s} {'d0':>7s} {'d1':>7s} {'d2':>7s} {'calls':>6s} {'avg_us':>9s} {'TFLOP/s':>8s} {'ms/step':>8s}\n")
+                    for (name, d0, d1, d2, code), (n, tt) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
+                        fl = launch_flops(code, d0, d1, d2)
+                        f.write(f"{name:62s} {d0:7d} {d1:7d} {d2:7d} {n:6d} {tt / n * 1e3:9.1f} {fl * n / (tt * 1e-3) / 1e12:8.1f} {tt:8.2f}\n")
+    # Not the headline — the same step in the other regimes a user of the reference meets, each timed over 3 steps after
+    # 2 warm-ups and reported beside `value`:
+    #   masked_rows_readout  readout + CE restricted to the ~15 % MLM-masked rows (TrainStep lm_head_impl="masked": same
+    #                        loss and gradients, rows outside the mask contribute exact zeros);
+    #   dropout_0.1          the reference's default --dropout (train_encoder.py:445); `value` is quoted at dropout 0,
+    #                        the parity regime;
+    #   dense_mask_calling_convention   the mask handed over as the reference's additive (B,H,T,T) expand() view
+    #                        (train_encoder.py:290-292) instead of key ranges.
     variants = None
-    if not a.masked_lm_head and not a.no_variants:
-        step.lm_head_impl = "masked"
-        for i in range(2):
+
+    def timed_variant(n=3, w=2):
+        for i in range(w):
             step(batches[i % len(batches)])
         sync()
         t0 = time.perf_counter()
-        for i in range(3):
+        for i in range(n):
             step(batches[i % len(batches)])
         sync()
         el = time.perf_counter() - t0
@@ -282,9 +361,25 @@ def main():
             te = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             el = float(te.item())
-        step.lm_head_impl = "dense"
-        variants = {"masked_rows_readout": {"value": round(tokens_per_step * 3 / el, 1), "unit": "tokens/s", "steps": 3,
-                                            "note": "readout + CE on the MLM-masked rows only; identical loss and gradients; not the headline"}}
+        return round(tokens_per_step * n / el, 1)
+
+    if not a.no_variants:
+        variants = {}
+        if not a.masked_lm_head:
+            step.lm_head_impl = "masked"
+            variants["masked_rows_readout"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
+                                               "note": "readout + CE on the MLM-masked rows only; identical loss and gradients; not the headline"}
+            step.lm_head_impl = "dense"
+        if a.dropout == 0.0:
+            TE.set_dropout(m, 0.1)
+            variants["dropout_0.1"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
+                                       "note": "the reference's default --dropout 0.1 (fused counter-based masks at all four sites)"}
+            TE.set_dropout(m, 0.0)
+        if not a.dense_mask:
+            step.mask_impl = "dense"
+            variants["dense_mask_calling_convention"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
+                                                         "note": "attn_mask passed as the reference's dense additive (B,H,T,T) expand() view"}
+            step.mask_impl = "ranges"
     if world > 1:
         dist.barrier()
 
@@ -297,7 +392,9 @@ def main():
                                    f"{a.rows_per_rank} rows/rank = {a.rows_per_rank // a.mini_batch_size} micro-batches of {a.mini_batch_size}, "
                                    f"{'masked-rows-only' if a.masked_lm_head else 'full'} 65536-way logits, dropout {a.dropout:g}, {'multi' if a.multi_document else 'single'}-document rows",
                        "global_batch_rows": a.rows_per_rank * world, "mini_batch_size": a.mini_batch_size, "seq_len": T,
-                       "parallelism": f"dp{world}", "dropout": a.dropout, "vocab": 65536},
+                       "parallelism": f"dp{world}", "dropout": a.dropout, "vocab": 65536,
+                       "collectives": (f"RCCL ({dist.get_backend()}) over {world} ranks: one bucketed gradient all-reduce per optimizer step"
+                                       if world > 1 else "none (single rank)")},
             "flops_per_token": fpt,
             "mfma_fraction_whole_step": round(value * fpt / (PEAK_BF16_TFLOPS * 1e12 * world), 4),
             "final_loss": round(float(losses[-1].item()), 4),

@@ -38,6 +38,13 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ qkv, const
 // ---------------------------------------------------------------------------------------------------------
 // Embedding gather (training/model.py:241).
 // ---------------------------------------------------------------------------------------------------------
+// Token ids outside [0, vocab) are clamped to the nearest valid row — in the forward gather AND in both backward
+// kernels, so a bad id can never address memory outside wte / dwte (the reference raises a device-side assert instead;
+// nothing on the host validates ids here, that would cost a sync).  The gradient of a clamped id lands on the row its
+// forward read.  The stable argsort the backward receives is over the raw ids: every id < 0 sorts next to 0 and every
+// id >= vocab next to vocab-1, so runs of equal clamped ids stay contiguous.
+__device__ __forceinline__ int64_t clamp_tok(int64_t tok, int64_t vocab) { return tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok); }
+
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ idx, const bf16* __restrict__ wte,
                                                          bf16* __restrict__ out, int64_t rows, int cols, int64_t vocab, DropCfg dc) {
     const int cpr = cols / 8;
@@ -45,8 +52,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / cpr;
         const int c = (int)(i % cpr) * 8;
-        int64_t tok = idx[r];
-        tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);  // memory safety; the host wrapper validates ids
+        const int64_t tok = clamp_tok(idx[r], vocab);
         bf16x8 v = *reinterpret_cast<const bf16x8*>(wte + tok * cols + c);
         if (dc.thresh24) {
 #pragma unroll
@@ -92,7 +98,7 @@ __device__ __forceinline__ void embed_store_row(bf16* dst, const float (&acc)[8]
 template <bool ACC>
 __global__ __launch_bounds__(128) void embed_bwd_chunk_kernel(const int64_t* __restrict__ idx, const int32_t* __restrict__ order,
                                                                const bf16* __restrict__ dout, bf16* __restrict__ dwte,
-                                                               float* __restrict__ slab, int64_t rows, int cols, DropCfg dc) {
+                                                               float* __restrict__ slab, int64_t rows, int cols, int64_t vocab, DropCfg dc) {
     __shared__ int32_t s_row[EMB_CHUNK];
     __shared__ int64_t s_tok[EMB_CHUNK + 2];  // [0] = token before the chunk (or -1), [1..n] chunk, [n+1] = token after (or -1)
     const int64_t c = blockIdx.x;
@@ -101,10 +107,10 @@ __global__ __launch_bounds__(128) void embed_bwd_chunk_kernel(const int64_t* __r
     if (threadIdx.x < n) {
         const int32_t r = order[p0 + threadIdx.x];
         s_row[threadIdx.x] = r;
-        s_tok[threadIdx.x + 1] = idx[r];
+        s_tok[threadIdx.x + 1] = clamp_tok(idx[r], vocab);
     }
-    if (threadIdx.x == 64) s_tok[0] = p0 > 0 ? idx[order[p0 - 1]] : -1;
-    if (threadIdx.x == 65) s_tok[n + 1] = (p0 + n < rows) ? idx[order[p0 + n]] : -1;
+    if (threadIdx.x == 64) s_tok[0] = p0 > 0 ? clamp_tok(idx[order[p0 - 1]], vocab) : -1;
+    if (threadIdx.x == 65) s_tok[n + 1] = (p0 + n < rows) ? clamp_tok(idx[order[p0 + n]], vocab) : -1;
     __syncthreads();
     const bool left_open = s_tok[0] == s_tok[1];
     const bool right_open = s_tok[n + 1] == s_tok[n];
@@ -144,14 +150,14 @@ __global__ __launch_bounds__(128) void embed_bwd_chunk_kernel(const int64_t* __r
 template <bool ACC>
 __global__ __launch_bounds__(128) void embed_bwd_span_kernel(const int64_t* __restrict__ idx, const int32_t* __restrict__ order,
                                                               bf16* __restrict__ dwte, const float* __restrict__ slab,
-                                                              int64_t rows, int cols, int64_t nchunks) {
+                                                              int64_t rows, int cols, int64_t nchunks, int64_t vocab) {
     const int64_t c = blockIdx.x;
     const int64_t p0 = c * EMB_CHUNK;
     const int64_t p1 = (p0 + EMB_CHUNK < rows) ? p0 + EMB_CHUNK : rows;
-    const int64_t first = idx[order[p0]], last = idx[order[p1 - 1]];
+    const int64_t first = clamp_tok(idx[order[p0]], vocab), last = clamp_tok(idx[order[p1 - 1]], vocab);
     const bool single = first == last;
-    const bool left_open = p0 > 0 && idx[order[p0 - 1]] == first;
-    const bool right_open = p1 < rows && idx[order[p1]] == last;
+    const bool left_open = p0 > 0 && clamp_tok(idx[order[p0 - 1]], vocab) == first;
+    const bool right_open = p1 < rows && clamp_tok(idx[order[p1]], vocab) == last;
     if (!right_open || (single && left_open)) return;  // no spanning run starts in this chunk
     const int slot0 = single ? 0 : 1;
     for (int col = threadIdx.x * 8; col < cols; col += 128 * 8) {
@@ -162,11 +168,11 @@ __global__ __launch_bounds__(128) void embed_bwd_span_kernel(const int64_t* __re
         for (int64_t cc = c + 1; cc < nchunks; ++cc) {
             const int64_t q0 = cc * EMB_CHUNK;
             const int64_t q1 = (q0 + EMB_CHUNK < rows) ? q0 + EMB_CHUNK : rows;
-            if (idx[order[q0]] != last) break;
+            if (clamp_tok(idx[order[q0]], vocab) != last) break;
             const float* s2 = slab + ((cc * 2) * cols + col);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] += s2[j];
-            if (idx[order[q1 - 1]] != last) break;  // the run ended inside chunk cc
+            if (clamp_tok(idx[order[q1 - 1]], vocab) != last) break;  // the run ended inside chunk cc
         }
         embed_store_row<ACC>(dwte + last * cols + col, acc);
     }
@@ -421,17 +427,17 @@ extern "C" int obte_embedding_bwd_dropout(const int64_t* idx, const int32_t* ord
     const int64_t nchunks = cdiv64(rows, EMB_CHUNK);
     if (accumulate)
         hipLaunchKernelGGL(embed_bwd_chunk_kernel<true>, dim3((unsigned)nchunks), dim3(128), 0, st, idx, order, (const bf16*)dout,
-                           (bf16*)dwte, (float*)ws, rows, cols, dc);
+                           (bf16*)dwte, (float*)ws, rows, cols, vocab, dc);
     else
         hipLaunchKernelGGL(embed_bwd_chunk_kernel<false>, dim3((unsigned)nchunks), dim3(128), 0, st, idx, order, (const bf16*)dout,
-                           (bf16*)dwte, (float*)ws, rows, cols, dc);
+                           (bf16*)dwte, (float*)ws, rows, cols, vocab, dc);
     OBTE_CHECK_LAUNCH("obte_embedding_bwd(chunk)");
     if (accumulate)
         hipLaunchKernelGGL(embed_bwd_span_kernel<true>, dim3((unsigned)nchunks), dim3(128), 0, st, idx, order, (bf16*)dwte,
-                           (const float*)ws, rows, cols, nchunks);
+                           (const float*)ws, rows, cols, nchunks, vocab);
     else
         hipLaunchKernelGGL(embed_bwd_span_kernel<false>, dim3((unsigned)nchunks), dim3(128), 0, st, idx, order, (bf16*)dwte,
-                           (const float*)ws, rows, cols, nchunks);
+                           (const float*)ws, rows, cols, nchunks, vocab);
     OBTE_CHECK_LAUNCH("obte_embedding_bwd(span)");
     return OBTE_OK;
 }

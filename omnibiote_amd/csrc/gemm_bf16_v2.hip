@@ -815,13 +815,15 @@ static void fill_params(const obte_gemm_args* g, void* workspace, GemmParams& p)
 extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64_t workspace_bytes, obte_stream s) {
     { const int vrc = validate_args(g); if (vrc != OBTE_OK) return vrc; }
     hipStream_t st = (hipStream_t)s;
-    const int prof = obte_prof_begin(st, (g->a_kmajor ? 8 : 0) + (g->b_kmajor ? 4 : 0) + g->epilogue, g->M, g->N, g->K);
     int rc;
     const bool can_split = workspace && (g->epilogue == OBTE_EPI_NONE || g->epilogue == OBTE_EPI_ADD) && g->ldd == g->N;
     Plan pl;
     if (!lookup_plan(g, &pl)) pl = make_plan(g->M, g->N, g->K, can_split);
     if (pl.splits > 1 && (!can_split || (int64_t)pl.splits * g->M * g->N * 4 > workspace_bytes)) pl = make_plan(g->M, g->N, g->K, false);
+    // profiler record kind = layout/epilogue code + 1000 * kernel structure (1: gemm_bf16_kernel, 2: gemm_v2_kernel, 3: gemm_v3_kernel)
+    const int kind0 = (g->a_kmajor ? 8 : 0) + (g->b_kmajor ? 4 : 0) + g->epilogue;
     if (use_v1() || pl.variant == 1) {
+        const int prof = obte_prof_begin(st, kind0 + 1000, g->M, g->N, g->K);
         rc = obte_gemm_bf16_v1(g, s);
         obte_prof_end(prof, st);
         return rc;
@@ -839,6 +841,7 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     p.rope_cos = g->rope_cos; p.rope_sin = g->rope_sin; p.rope_T = g->rope_T; p.rope_hs = g->rope_head_dim;
     p.drop = make_drop(g->epilogue == OBTE_EPI_ADD_DROPOUT ? g->dropout_p : 0.f, g->dropout_seed, (uint32_t)g->dropout_site);
     const bool v3 = use_v3(pl.variant) && pl.bn == 256 && p.k_per_split >= 2 && nk - (int64_t)(p.splits - 1) * p.k_per_split >= 2;
+    const int prof = obte_prof_begin(st, kind0 + (v3 ? 3000 : 2000), g->M, g->N, g->K);
     if (v3) {
         if (g->a_kmajor && g->b_kmajor) rc = dispatch3<true, true>(p, g->epilogue, st);
         else if (g->a_kmajor && !g->b_kmajor) rc = dispatch3<true, false>(p, g->epilogue, st);

@@ -88,13 +88,18 @@ def get_batch(generators: Sequence[Iterator[np.ndarray]], train_ints: Sequence[i
         yield torch.from_numpy(batch).to(device) if return_pt else batch
 
 
-def data_loader_parallel(batch_queue: "queue.Queue", batch_generator, device) -> None:
+def data_loader_parallel(batch_queue: "queue.Queue", batch_generator, device, stop=None) -> None:
     """Thread target: move batches to ``device`` ahead of the training loop.  On a GPU the batch is staged in pinned memory
     and copied on a dedicated stream; it is published only after that copy has completed, so the consumer may use it on
-    any stream."""
+    any stream.  ``stop`` (a threading.Event, optional): set it and drain the queue to make the thread return, so that it
+    can be joined before the process group and the HIP context are torn down."""
+    import queue as _queue
     dev = torch.device(device)
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)   # the current device is per thread and defaults to 0: without this every rank would
+                                     # create a context (and pin memory) on GPU 0
     copy_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-    while True:
+    while stop is None or not stop.is_set():
         try:
             data = next(batch_generator)
         except StopIteration:
@@ -106,7 +111,13 @@ def data_loader_parallel(batch_queue: "queue.Queue", batch_generator, device) ->
             copy_stream.synchronize()
         else:
             data = data.to(dev)
-        batch_queue.put(data)
+        while True:   # bounded queue (train_encoder.py:141): wait for room, but notice a stop request
+            try:
+                batch_queue.put(data, timeout=0.2)
+                break
+            except _queue.Full:
+                if stop is not None and stop.is_set():
+                    return
 
 
 def batch_split(batch_size: int, proportions: Sequence[float]) -> List[int]:

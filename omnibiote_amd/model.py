@@ -116,11 +116,13 @@ class accumulate_grads_inplace:
 
 
 def _grad_slot(param):
-    """The existing bf16 gradient of ``param`` if in-place accumulation is on and applicable, else None."""
+    """The existing gradient of ``param`` if in-place accumulation is on and applicable, else None.  (The HIP entry
+    points that receive it insist on bf16 themselves; the protocol is dtype-agnostic so that the CPU multi-process tests
+    can drive it with a stub model.)"""
     if not _ACCUMULATE_INPLACE:
         return None
     g = getattr(param, "grad", None)
-    if g is None or g.dtype != torch.bfloat16 or not g.is_contiguous() or g.shape != param.shape:
+    if g is None or g.dtype != param.dtype or not g.is_contiguous() or g.shape != param.shape:
         return None
     return g
 

@@ -147,7 +147,12 @@ class TrainStep:
 
     def __init__(self, model, optimizer, scheduler=None, *, mini_batch_size: int, n_head: int, use_padding: bool = False,
                  loss_impl: str = "fused", mask_impl: str = "ranges", sync_every_micro_step: bool = False,
-                 max_grad_norm: float = 1.0, lm_head_impl: str = "dense", pipeline_streams: int = 1):
+                 max_grad_norm: float = 1.0, lm_head_impl: str = "dense", pipeline_streams: int = 1,
+                 fused_loss_fn: Optional[Callable] = None):
+        """fused_loss_fn: ``(logits, targets, mlm_mask, n_accum) -> (loss, dlogits)`` used by loss_impl="fused" instead of
+        the HIP kernel (ops.masked_ce) — lets the CPU multi-process tests drive the product scheduling (in-place
+        accumulation, no_sync, hand-delivered d(logits)) with a stub model and a torch loss."""
+        self.fused_loss_fn = fused_loss_fn
         self.model, self.optimizer, self.scheduler = model, optimizer, scheduler
         self.mini, self.n_head, self.use_padding = mini_batch_size, n_head, use_padding
         self.loss_impl, self.mask_impl = loss_impl, mask_impl
@@ -189,6 +194,10 @@ class TrainStep:
         return rm.dense(dtype).unsqueeze(1).expand(-1, self.n_head, -1, -1)   # train_encoder.py:292
 
     def _loss_backward(self, logits, targets, mask, n_accum):
+        if self.loss_impl == "fused" and self.fused_loss_fn is not None:
+            loss, dlogits = self.fused_loss_fn(logits, targets, mask, n_accum)
+            logits.backward(dlogits)
+            return loss.detach()
         if self.loss_impl == "fused":
             from . import ops
             if self._slot not in self._dlogits:   # one reusable d(logits) buffer per stream in flight
@@ -214,11 +223,14 @@ class TrainStep:
         from . import ops
         emb = self.model(x, attn_mask=attn_mask, return_embeddings=True)
         rows = self._mask_rows_host[self._mb]            # int64 tensor on the device, built from the NumPy draw
+        core = self.model.module if hasattr(self.model, "module") else self.model
         if rows.numel() == 0:
-            (emb.sum() * 0).backward()
+            # nothing masked in this micro-batch: still hand EVERY parameter a (zero) gradient — lm_head included — or
+            # DDP's reducer would wait for it forever when this is the synchronising micro-batch
+            self._order_backward()
+            (emb.sum() * 0 + core.lm_head.weight.sum() * 0).backward()
             return torch.zeros((), dtype=torch.float32, device=x.device)
         emb_rows = emb.reshape(-1, emb.shape[-1]).index_select(0, rows)
-        core = self.model.module if hasattr(self.model, "module") else self.model
         logits = core.lm_head(emb_rows)
         ones = torch.ones(rows.numel(), dtype=torch.bool, device=x.device)
         loss, dlogits = ops.masked_ce(logits, y.reshape(-1).index_select(0, rows), ones, n_accum)
@@ -226,12 +238,18 @@ class TrainStep:
         logits.backward(dlogits)
         return loss.detach()
 
-    def __call__(self, input_ids: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def __call__(self, input_ids: torch.Tensor, mlm_mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """mlm_mask (optional, bool (rows, T)): the positions to corrupt instead of the host Bernoulli draw of
+        train_encoder.py:273-274 (PAD/EOS are still excluded) — lets tests hand two runs the same corruption."""
         rows = input_ids.shape[0] // self.mini * self.mini
         input_ids = input_ids[:rows]
         n_accum = rows // self.mini
         self.optimizer.zero_grad(set_to_none=True)
-        masked_ids, mask = mlm_corrupt(input_ids)
+        if mlm_mask is None:
+            masked_ids, mask = mlm_corrupt(input_ids)
+        else:
+            mask = mlm_mask[:rows].to(input_ids.device) & (input_ids != PAD_TOKEN) & (input_ids != EOS_TOKEN)
+            masked_ids = input_ids.masked_fill(mask, MASK_TOKEN)
         if self.lm_head_impl == "masked":
             # per-micro-batch row indices of the masked positions; mlm_corrupt drew the mask on the host, but PAD/EOS
             # exclusions were applied on the device, so fetch the final mask once per optimizer step (one small D2H copy)
@@ -297,6 +315,18 @@ class TrainStep:
 
 
 # ------------------------------------------------------------------------------------------------- model set-up
+def set_dropout(model, p: float) -> None:
+    """Change the dropout probability of a built model (config.dropout feeds four sites: model.py:83-84,160,204)."""
+    core = model.module if hasattr(model, "module") else model
+    core.config.dropout = p
+    core.transformer.drop.p = p
+    for blk in core.transformer.h:
+        blk.attn.dropout = p
+        blk.attn.attn_dropout.p = p
+        blk.attn.resid_dropout.p = p
+        blk.mlp.dropout.p = p
+
+
 def build_model(args, device, dtype=torch.bfloat16, vocab_size: int = 2 ** 16):
     """train_encoder.py:145-170: target model, muP base/delta models sharing ONE mutated config object,
     set_base_shapes, cast, move."""
@@ -398,6 +428,11 @@ def parse_args(argv=None):
     p.add_argument("--multi_document", action="store_true", default=False, help="synthetic rows with interior EOS")
     p.add_argument("--pipeline_streams", type=int, default=2, choices=[1, 2],
                    help="2: overlap the forward of micro-batch j+1 with the backward of micro-batch j (same results)")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="torch.distributed backend: nccl (= RCCL over xGMI, the production path) or gloo (plumbing runs: "
+                        "BASELINE config 1; gradients then cross the host)")
+    p.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                   help="cpu only exercises the harness plumbing: the model itself has no CPU path and says so at the first forward")
     return p.parse_args(argv)
 
 
@@ -417,10 +452,18 @@ TRAIN_TYPES = {   # train_encoder.py:72-93
     "mixed": (["genbank/train", "uniref100/train"], [0.80, 0.20]),
     "halfnhalf": (["genbank/train", "uniref100/train"], [0.50, 0.50]),
 }
+TEST_SETS = {     # train_encoder.py:72-93: (test_dirs, test_names)
+    "protein": (["uniref100/val"], ["uniref100"]),
+    "nucleotide": (["genbank/val"], ["genbank"]),
+    "mixed": (["genbank/val", "uniref100/val"], ["genbank", "uniref100"]),
+    "halfnhalf": (["genbank/val", "uniref100/val"], ["genbank", "uniref100"]),
+}
 
 
 def make_batch_source(args, batch_size: int, device, rng):
-    """A callable ``rows -> LongTensor (rows, ctx_len)`` on ``device``.  Real shards when --base_dir has them, else synthetic."""
+    """``(next_batch, description, close)``: ``next_batch(rows) -> LongTensor (rows, ctx_len)`` on ``device``; real shards
+    when --base_dir has them, else synthetic.  ``close()`` stops and joins the loader thread (call it before tearing the
+    process group down)."""
     if args.train_type not in TRAIN_TYPES:
         raise ValueError("Invalid train_type. Must be one of 'protein', 'nucleotide', 'mixed', or 'halfnhalf'")
     dirs, props = TRAIN_TYPES[args.train_type]
@@ -434,7 +477,9 @@ def make_batch_source(args, batch_size: int, device, rng):
         gens = [LD.get_sequence(r, args.ctx_len, args.use_padding) for r in readers]
         batches = LD.get_batch(gens, LD.batch_split(batch_size, props), return_pt=True)
         q = queue.Queue(maxsize=2)                                   # train_encoder.py:140-142
-        threading.Thread(target=LD.data_loader_parallel, args=(q, batches, device), daemon=True).start()
+        stop = threading.Event()
+        th = threading.Thread(target=LD.data_loader_parallel, args=(q, batches, device, stop), daemon=True)
+        th.start()
         pool = [q.get(block=True)]
 
         def real(rows):
@@ -443,23 +488,93 @@ def make_batch_source(args, batch_size: int, device, rng):
             cat = torch.cat(pool, dim=0) if len(pool) > 1 else pool[0]
             pool[:] = [cat[rows:]]
             return cat[:rows]
-        return real, "shards under " + args.base_dir
+
+        def close():
+            stop.set()
+            while th.is_alive():
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                th.join(timeout=0.1)
+        return real, "shards under " + args.base_dir, close
     if args.base_dir:
         print(f"note: no token shards under {args.base_dir}; training on synthetic rows")
 
     def synth(rows):
         return torch.from_numpy(synthetic_rows(rows, args.ctx_len, 2 ** 16, rng, single_document=not args.multi_document)).to(device)
-    return synth, "synthetic rows"
+    return synth, "synthetic rows", (lambda: None)
+
+
+def make_test_sources(args, device, rng):
+    """Held-out generators for the periodic evaluation (train_encoder.py:131-133): ``[(name, next_rows)]`` where
+    ``next_rows(n) -> LongTensor (n, ctx_len)``.  The ``*/val`` shard directories when --base_dir has them, else one
+    synthetic stream from its own RNG."""
+    dirs, names = TEST_SETS[args.train_type]
+    dirs = [os.path.join(args.base_dir, d) for d in dirs] if args.base_dir else []
+    out = []
+    if dirs and all(os.path.isdir(d) and os.listdir(d) for d in dirs):
+        from . import loader as LD
+        for d, name in zip(dirs, names):
+            files = sorted(os.path.join(d, f) for f in os.listdir(d))
+            gen = LD.get_sequence(LD.line_reader(files, banned_tokens=[args.banned_token]), args.ctx_len, args.use_padding)
+
+            def rows_from(n, gen=gen):
+                arr = np.concatenate([np.asarray(next(gen)).reshape(1, -1) for _ in range(n)])   # :376-379
+                return torch.as_tensor(arr, dtype=torch.long, device=device)
+            out.append((name, rows_from))
+        return out
+    trng = np.random.default_rng(int(rng.integers(1 << 31)) + 7919)
+
+    def synth(n):
+        return torch.from_numpy(synthetic_rows(n, args.ctx_len, 2 ** 16, trng, single_document=not args.multi_document)).to(device)
+    return [("synthetic", synth)]
+
+
+@torch.no_grad()
+def evaluate(model, test_sources, args, world: int, device) -> Dict[str, float]:
+    """The held-out pass of train_encoder.py:371-410: model.eval(), one mini-batch per test set, the same MLM corruption
+    and attention mask as training, loss = sum_masked(CE) / n_masked / world on every rank, summed over ranks."""
+    from . import masks, ops
+    core = model.module if hasattr(model, "module") else model
+    was_training = core.training
+    model.eval()
+    out = {}
+    for name, next_rows in test_sources:
+        test_batch = next_rows(args.mini_batch_size)
+        masked_ids, mask = mlm_corrupt(test_batch)
+        attn = masks.RangeMask.from_tokens(test_batch, padding=args.use_padding)
+        logits = model(masked_ids, attn_mask=attn)
+        if logits.is_cuda and logits.dtype == torch.bfloat16:
+            loss, _ = ops.masked_ce(logits, test_batch, mask, 1)
+        else:
+            ce = F.cross_entropy(logits.view(-1, logits.size(-1)).float(), test_batch.view(-1), reduction="none")
+            loss = (ce * mask.view(-1).float()).sum() / mask.view(-1).sum()
+        loss = loss.float() / world
+        if world > 1:
+            dist.all_reduce(loss)
+        out[name] = float(loss.item())
+    model.train(was_training)
+    return out
 
 
 def run(args):
     if args.FSDP:
         raise NotImplementedError("--FSDP is outside this build's scope (the north star names DDP)")
-    dist.init_process_group("nccl")   # RCCL on ROCm
+    backend = getattr(args, "backend", "nccl")
+    on_gpu = getattr(args, "device", "cuda") == "cuda"
+    if backend == "nccl" and not on_gpu:
+        raise SystemExit("--backend nccl (RCCL) needs --device cuda; use --backend gloo for a CPU plumbing run")
+    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+        os.environ.setdefault(k, v)   # a bare `python train_encoder.py` is a world of one
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if on_gpu:
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    else:
+        device = torch.device("cpu")
+    dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))   # nccl = RCCL on ROCm
     rank, world = dist.get_rank(), dist.get_world_size()
-    local = int(os.environ.get("LOCAL_RANK", rank % max(torch.cuda.device_count(), 1)))
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
     assert args.batch_size % world == 0, "Batch size must be divisible by the number of processes."
     batch_size = args.batch_size // world
     np.random.seed(1234 + rank)
@@ -472,20 +587,27 @@ def run(args):
         print(f"Loaded model from {args.resume_from} token checkpoint")
     torch.manual_seed(1234 + rank)   # per-rank dropout streams from here on
     n_params = m.get_num_params()
-    from . import tune
-    tune.tune_model_shapes(args.mini_batch_size * args.ctx_len, args.n_embd, 2 ** 16, device=device, verbose=(rank == 0))
-    model = wrap_ddp(m, local) if world > 1 else m
+    if on_gpu:
+        from . import tune
+        tune.tune_model_shapes(args.mini_batch_size * args.ctx_len, args.n_embd, 2 ** 16, device=device, verbose=(rank == 0))
+        if world > 1:   # every rank adopts rank 0's plan table: the replicas then run the same kernels
+            box = [tune.export_plans() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            if rank != 0:
+                tune.import_plans(box[0])
+    model = wrap_ddp(m, local if on_gpu else None) if world > 1 else m
     total_iters = int(args.token_budget / (world * batch_size * args.ctx_len))
-    opt, sched = build_optimizer(m, args, total_iters)
+    opt, sched = build_optimizer(m, args, total_iters, fused=on_gpu)
     step = TrainStep(model, opt, sched, mini_batch_size=args.mini_batch_size, n_head=args.n_head, use_padding=args.use_padding,
                      pipeline_streams=getattr(args, "pipeline_streams", 1))
     rng = np.random.default_rng(1234 + rank)
-    next_batch, source = make_batch_source(args, batch_size, device, rng)
+    next_batch, source, close_source = make_batch_source(args, batch_size, device, rng)
+    test_sources = make_test_sources(args, device, rng)
     if rank == 0:
-        print(f"data: {source}")
-    trained, last_save, start = 0, 0, 0
+        print(f"data: {source}; backend {backend}, world {world}, device {device}")
+    trained, last_save, last_test, start = 0, 0, 0, 0
     if args.resume_from > 0:   # train_encoder.py:210-223 (optimizer/scheduler as state_dicts, not whole objects)
-        trained = last_save = args.resume_from
+        trained = last_save = last_test = args.resume_from
         start = int(total_iters * (trained / args.token_budget))
         st = torch.load(f"{args.save_name}_optimizer_{args.resume_from}.pt", map_location=device, weights_only=False)
         opt.load_state_dict(st["optimizer"]); sched.load_state_dict(st["scheduler"])
@@ -497,32 +619,44 @@ def run(args):
         save_checkpoint(model, f"{args.save_name}{tag}.pt")
         torch.save({"optimizer": opt.state_dict(), "scheduler": sched.state_dict()}, f"{args.save_name}_optimizer{tag}.pt")
 
-    for i in range(start, n_steps):
-        t0 = time.time()
-        rows = effective_batch(i, total_iters, args, batch_size)
-        ids = next_batch(rows)
-        out = step(ids)
-        stats = torch.stack([out["loss"], out["tokens"].float()])
-        if world > 1:
-            dist.all_reduce(stats)
-        torch.cuda.synchronize()
-        dt = time.time() - t0
-        loss, toks = stats[0].item() / world, int(stats[1].item())
-        trained += toks
-        if rank == 0:
-            lrs = [g["lr"] for g in opt.param_groups]
-            print(f"step {i} loss {loss:.4f} lr {lrs[0]:.5f}|{lrs[-1]:.5f} tokens/s {toks / dt:,.0f} "
-                  f"MFMA-frac {toks / dt * fpt / (2.5e15 * world) * 100:.1f}% trained {trained / 1e6:.2f}M", flush=True)
-            if trained - last_save > args.save_freq:   # train_encoder.py:412-423: keep only the newest
+    history = []
+    try:
+        for i in range(start, n_steps):
+            t0 = time.time()
+            rows = effective_batch(i, total_iters, args, batch_size)
+            ids = next_batch(rows)
+            out = step(ids)
+            stats = torch.stack([out["loss"], out["tokens"].float()])
+            if world > 1:
+                dist.all_reduce(stats)
+            if on_gpu:
+                torch.cuda.synchronize()
+            dt = time.time() - t0
+            loss, toks = stats[0].item() / world, int(stats[1].item())
+            trained += toks
+            history.append(loss)
+            if rank == 0:
+                lrs = [g["lr"] for g in opt.param_groups]
+                print(f"step {i} loss {loss:.4f} lr {lrs[0]:.5f}|{lrs[-1]:.5f} tokens/s {toks / dt:,.0f} "
+                      f"MFMA-frac {toks / dt * fpt / (2.5e15 * world) * 100:.1f}% trained {trained / 1e6:.2f}M", flush=True)
+            if trained - last_test > args.test_freq:            # train_encoder.py:371-410
+                for name, v in evaluate(model, test_sources, args, world, device).items():
+                    if rank == 0:
+                        print(f"test_loss/{name} {v:.4f} at {trained / 1e6:.2f}M tokens", flush=True)
+                last_test = trained
+            if rank == 0 and trained - last_save > args.save_freq:   # train_encoder.py:412-423: keep only the newest
                 save(f"_{trained}")
                 if last_save > 0:
                     for f in (f"{args.save_name}_{last_save}.pt", f"{args.save_name}_optimizer_{last_save}.pt"):
                         if os.path.exists(f):
                             os.remove(f)
                 last_save = trained
-    if rank == 0 and args.save_name:
-        save("")                                        # train_encoder.py:429-432
-    dist.destroy_process_group()
+        if rank == 0 and args.save_name:
+            save("")                                        # train_encoder.py:429-432
+    finally:
+        close_source()
+        dist.destroy_process_group()
+    return history
 
 
 if __name__ == "__main__":

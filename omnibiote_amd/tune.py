@@ -105,21 +105,28 @@ def tune_model_shapes(rows: int, n_embd: int, vocab: int, device="cuda", verbose
     torch.cuda.empty_cache()
 
 
+def export_plans() -> list:
+    """The plans chosen so far as plain rows (JSON-able; also what rank 0 broadcasts to the other ranks)."""
+    return [{"M": k[0], "N": k[1], "K": k[2], "a_kmajor": bool(k[3]), "b_kmajor": bool(k[4]), "epilogue": int(k[5]),
+             "variant": v[0], "bn": v[1], "splits": v[2], "ms": v[3]} for k, v in sorted(_done.items())]
+
+
 def save_plans(path: str) -> None:
     """Write the plans chosen so far as JSON (one object per GEMM shape) — tune once per device, reuse afterwards."""
     import json
-    rows = [{"M": k[0], "N": k[1], "K": k[2], "a_kmajor": bool(k[3]), "b_kmajor": bool(k[4]), "epilogue": int(k[5]),
-             "variant": v[0], "bn": v[1], "splits": v[2], "ms": v[3]} for k, v in sorted(_done.items())]
     with open(path, "w") as f:
-        json.dump(rows, f, indent=1)
+        json.dump(export_plans(), f, indent=1)
 
 
 def load_plans(path: str) -> int:
     """Install plans written by ``save_plans`` into the library's table; returns how many.  No launches."""
     import json
-    lib = L.lib()
     with open(path) as f:
-        rows = json.load(f)
+        return import_plans(json.load(f))
+
+
+def import_plans(rows: list) -> int:
+    lib = L.lib()
     for r in rows:
         L.check(lib.obte_gemm_plan_set(int(r["a_kmajor"]), int(r["b_kmajor"]), int(r["epilogue"]), int(r["M"]), int(r["N"]), int(r["K"]),
                                        int(r["variant"]), int(r["bn"]), int(r["splits"])), "obte_gemm_plan_set")

@@ -119,3 +119,126 @@ def test_two_ranks_match_one_process_on_the_whole_batch(tmp_path):
     for p, g in zip(enc.parameters(), want):
         torch.testing.assert_close(p.grad, g, rtol=1e-5, atol=1e-7)
     assert int(out["tokens"]) == ids.numel()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The PRODUCT scheduling of TrainStep under two real ranks: loss_impl="fused" (hand-delivered d(logits)), gradient
+# accumulation done in place by the model's own backward while DDP's no_sync() is active (backward returns None for
+# those parameters), the last micro-batch through autograd's AccumulateGrad so that the reducer's hooks fire.  The HIP
+# kernels need a GPU, so the model here is a stub that follows the same protocol (omnibiote_amd.model._grad_slot /
+# accumulate_grads_inplace) with torch CPU arithmetic in fp64, and the fused loss is a torch function with the same
+# contract as ops.masked_ce.  tests/test_hip_model.py runs the same comparison with the real HIP model on a GPU.
+# ------------------------------------------------------------------------------------------------------------------
+def _stub_model(seed=3, V=64, C=16):
+    sys.path.insert(0, ROOT)
+    from omnibiote_amd import model as M
+
+    class InplaceLinear(torch.autograd.Function):
+        calls = {"inplace": 0, "returned": 0}
+
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            ctx.w_param = w
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+            dx = dy @ w
+            dw = dy.reshape(-1, dy.shape[-1]).t() @ x.reshape(-1, x.shape[-1])
+            slot = M._grad_slot(ctx.w_param)
+            if slot is not None:                       # what the wgrad epilogue does on the GPU
+                slot.add_(dw)
+                InplaceLinear.calls["inplace"] += 1
+                return dx, None
+            InplaceLinear.calls["returned"] += 1
+            return dx, dw
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(seed)
+            self.wte = torch.nn.Parameter(torch.randn(V, C, generator=g, dtype=torch.float64))
+            self.w1 = torch.nn.Parameter(torch.randn(C, C, generator=g, dtype=torch.float64) * 0.3)
+            self.head = torch.nn.Parameter(torch.randn(V, C, generator=g, dtype=torch.float64) * 0.3)
+
+        def forward(self, idx, attn_mask=None, return_embeddings=False):
+            x = torch.nn.functional.embedding(idx, self.wte)
+            x = x + torch.tanh(InplaceLinear.apply(x, self.w1)).cumsum(dim=1) / idx.shape[1]   # some mixing along T
+            return InplaceLinear.apply(x, self.head)
+    return Stub(), InplaceLinear
+
+
+def _torch_fused_loss(logits, targets, mask, n_accum):
+    """Contract of ops.masked_ce: (loss, dlogits) with loss = sum_masked(CE) / n_accum / count."""
+    lg = logits.detach().double().requires_grad_(True)
+    ce = torch.nn.functional.cross_entropy(lg.view(-1, lg.size(-1)), targets.reshape(-1), reduction="none") / n_accum
+    loss = (ce * mask.reshape(-1).double()).sum() / mask.reshape(-1).sum()
+    (dl,) = torch.autograd.grad(loss, lg)
+    return loss.detach().float(), dl.to(logits.dtype)
+
+
+def _stub_data(rows=8, T=12, V=64):
+    rng = np.random.default_rng(11)
+    ids = torch.from_numpy(rng.integers(20, V, size=(rows, T)))
+    mlm = torch.from_numpy(rng.random((rows, T)) < 0.3)
+    mlm[:, 0] = True      # every micro-batch has masked tokens
+    return ids, mlm
+
+
+def _product_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from omnibiote_amd import train_encoder as TE
+    stub, fn = _stub_model()
+    model = TE.wrap_ddp(stub, None, bucket_cap_mb=1)
+    opt = torch.optim.SGD(stub.parameters(), lr=0.05)
+    step = TE.TrainStep(model, opt, None, mini_batch_size=1, n_head=1, loss_impl="fused", fused_loss_fn=_torch_fused_loss,
+                        max_grad_norm=1e9)
+    ids, mlm = _stub_data()
+    per = ids.shape[0] // world
+    losses = []
+    for s in range(2):
+        out = step(ids[rank * per:(rank + 1) * per], mlm_mask=mlm[rank * per:(rank + 1) * per])
+        t = out["loss"].clone()
+        dist.all_reduce(t)
+        losses.append(t.item() / world)
+    if rank == 0:
+        torch.save({"losses": losses, "w": [p.detach().clone() for p in stub.parameters()],
+                    "g": [p.grad.detach().clone() for p in stub.parameters()], "calls": dict(fn.calls)}, out_path)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_product_scheduling_two_ranks_match_one_rank_on_the_concatenated_batch(tmp_path):
+    out = os.path.join(str(tmp_path), "prod.pt")
+    mp.spawn(_product_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    two = torch.load(out, weights_only=False)
+    # 4 micro-batches per rank and step: the first delivers .grad through autograd, 2 accumulate in place under no_sync,
+    # the last goes through autograd again (reducer hooks) -> per step and Linear: 2 in place, 2 returned
+    assert two["calls"]["inplace"] == 2 * 2 * 2 and two["calls"]["returned"] == 2 * 2 * 2, two["calls"]
+
+    sys.path.insert(0, ROOT)
+    from omnibiote_amd import train_encoder as TE
+    stub, fn = _stub_model()
+    opt = torch.optim.SGD(stub.parameters(), lr=0.05)
+    step = TE.TrainStep(stub, opt, None, mini_batch_size=1, n_head=1, loss_impl="fused", fused_loss_fn=_torch_fused_loss, max_grad_norm=1e9)
+    ids, mlm = _stub_data()
+    losses = [step(ids, mlm_mask=mlm)["loss"].item() for _ in range(2)]
+    np.testing.assert_allclose(two["losses"], losses, rtol=1e-6)
+    for a, b in zip(two["g"], [p.grad for p in stub.parameters()]):
+        torch.testing.assert_close(a, b, rtol=1e-9, atol=1e-12)
+    for a, b in zip(two["w"], stub.parameters()):
+        torch.testing.assert_close(a, b.detach(), rtol=1e-9, atol=1e-12)
+
+    # and both equal plain autograd with the reference's three loss lines (no in-place accumulation, no fused loss)
+    ref, _ = _stub_model()
+    opt = torch.optim.SGD(ref.parameters(), lr=0.05)
+    step = TE.TrainStep(ref, opt, None, mini_batch_size=1, n_head=1, loss_impl="torch", max_grad_norm=1e9)
+    for _ in range(2):
+        step(ids, mlm_mask=mlm)
+    for a, b in zip(two["w"], ref.parameters()):
+        torch.testing.assert_close(a, b.detach(), rtol=1e-7, atol=1e-9)
