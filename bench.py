@@ -180,6 +180,38 @@ def oracle_step_rate(cfg, mini_rows, steps, warmup, device, rows, dtype, threads
     return rows * cfg["ctx_len"] / float(np.median(timed)), len(timed)
 
 
+def usable_cores() -> int:
+    """Cores this process may actually run on: the affinity mask, capped by the cgroup CPU quota (a container sees all
+    of the host's logical CPUs in os.cpu_count() but is throttled to its share; oversubscribing that share with one
+    thread per logical CPU is an order of magnitude slower than matching it)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]) + 0.5)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, int(q / int(f2.read().split()[0]) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def log(msg: str) -> None:
+    """Progress on stderr (rank 0): the JSON line stays the only thing on stdout."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(cfg, mini_rows=8, steps=5, warmup=2, device="cpu", rows=None):
     """SURVEY.md §8(d) protocol: the oracle's train step on the host cores at the workload's own micro-batch (the
     largest B the step ever sees), every core this process may use, median of >= 5 steps after 2 warm-ups (fewer, never
@@ -191,10 +223,7 @@ def cpu_baseline(cfg, mini_rows=8, steps=5, warmup=2, device="cpu", rows=None):
         return {"value": round(v, 1), "unit": "tokens/s", "cores": 0, "kind": "port",
                 "sample": f"oracle train step as eager PyTorch-ROCm ops on cuda:0, {rows} rows x {cfg['ctx_len']} tokens in micro-batches of "
                           f"{mini_rows}, bf16, dense additive masks, median of {n} steps after {warmup} warm-up"}
-    try:
-        usable = len(os.sched_getaffinity(0))
-    except AttributeError:
-        usable = os.cpu_count() or 1
+    usable = usable_cores()
     threads = max(1, usable)
     v16, n16 = oracle_step_rate(cfg, mini_rows, steps, warmup, "cpu", rows, torch.bfloat16, threads)
     v32, n32 = oracle_step_rate(cfg, mini_rows, steps, warmup, "cpu", rows, torch.float32, threads)
@@ -226,8 +255,8 @@ def self_launch(n_gpus: int) -> int:
 def main():
     a = parse()
     cfg = CONFIGS[a.config]
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(a.gpus))
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("OBTE_BENCH_FORCE_LAUNCH") == "1"):
+        sys.exit(self_launch(a.gpus))   # (OBTE_BENCH_FORCE_LAUNCH=1: rehearse the child launch with one rank on a one-GPU box)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -285,6 +314,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f"model built, plans ready; timing {a.warmup}+{a.steps} steps")
     losses = []
     for i in range(a.warmup):
         losses.append(step(batches[i % len(batches)])["loss"])
@@ -302,6 +332,7 @@ def main():
     value = tokens_per_step * a.steps / elapsed
     fpt = TE.flops_per_token(n_params, cfg["n_layer"], cfg["n_embd"], T)
 
+    log(f"timed region done: {value:,.0f} tokens/s")
     roofline = None
     if not a.no_roofline and rank == 0:
         # per-launch durations are only meaningful when launches do not share the chip: the profiled step runs on one
@@ -364,6 +395,7 @@ def main():
         return round(tokens_per_step * n / el, 1)
 
     if not a.no_variants:
+        log("variants")
         variants = {}
         if not a.masked_lm_head:
             step.lm_head_impl = "masked"
@@ -403,7 +435,9 @@ def main():
         if variants:
             out["variants"] = variants
         if world == 1 and not a.no_cpu_baseline:
+            log(f"cpu_baseline on {usable_cores()} cores")
             out["cpu_baseline"] = cpu_baseline(cfg)
+            log("eager_gpu_baseline")
             try:   # same oracle step as eager torch ops on this GPU (informational; never the product path)
                 del step, opt, model, m
                 torch.cuda.empty_cache()

@@ -428,3 +428,26 @@ def test_eval_style_usage_with_padding_mask_and_odd_length(golden_dir):
         mx, mean = stats(out[b, :min(p + 1, T)], ref[b, :min(p + 1, T)].numpy())
         assert mx <= 0.12 and mean <= 6e-3, (b, mx, mean)
     assert torch.isfinite(out.float()).all()
+
+
+def test_config1_tiny_through_the_cli_harness_on_gloo(tmp_path, monkeypatch, capsys):
+    """BASELINE config 1 (tiny 2L/128d/2h ctx=128, world_size 1, --disable_flash) through train_encoder.run() — the
+    reference's entry point — with --backend gloo: process group, muP set-up, tuner, loop, periodic evaluation, saving."""
+    from omnibiote_amd import train_encoder as TE
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29537")
+    name = str(tmp_path / "tiny")
+    args = TE.parse_args(["--n_layer", "2", "--n_embd", "128", "--n_head", "2", "--ctx_len", "128", "--batch_size", "16", "--mini_batch_size", "8",
+                          "--disable_flash", "--backend", "gloo", "--dropout", "0.0", "--max_steps", "6", "--save_name", name,
+                          "--test_freq", "4000", "--lr", "1e-2"])
+    hist = TE.run(args)
+    out = capsys.readouterr().out
+    assert len(hist) == 6 and all(np.isfinite(hist)), hist
+    assert abs(hist[0] - np.log(65536)) < 1.5, hist          # random init: near ln V
+    assert "test_loss/synthetic" in out                       # --test_freq evaluation ran (train_encoder.py:371-410)
+    assert os.path.exists(name + ".pt") and os.path.exists(name + "_optimizer.pt")
+    from omnibiote_amd.checkpoint import load_checkpoint
+    m = load_checkpoint(name + ".pt", map_location="cuda")
+    assert m.config.n_layer == 2 and m.config.n_embd == 128

@@ -191,3 +191,20 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     # argument validation happens on the host, before any launch (no GPU needed): NULL descriptor -> EINVAL
     assert lib.obte_gemm_bf16(None, None) == -1
     assert b"null" in lib.obte_last_error()
+
+
+def test_config1_cpu_gloo_harness_is_launchable_and_fails_loudly_at_the_model(tmp_path, monkeypatch):
+    """BASELINE config 1 (tiny 2L/128d/2h ctx=128, CPU torchrun world_size=1, --disable_flash): the harness itself —
+    process group on gloo, muP model set-up, optimizer groups, scheduler, data source, step loop — must start on a CPU
+    world; the model has no CPU path by design and must say so at its first forward instead of computing something."""
+    import torch.distributed as dist
+    from omnibiote_amd import train_encoder as TE
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29533")
+    args = TE.parse_args(["--n_layer", "2", "--n_embd", "128", "--n_head", "2", "--ctx_len", "128", "--batch_size", "16", "--mini_batch_size", "8",
+                          "--disable_flash", "--backend", "gloo", "--device", "cpu", "--max_steps", "2", "--save_name", ""])
+    with pytest.raises(RuntimeError, match="no CPU\\s+fallback|needs GPU tensors"):
+        TE.run(args)
+    assert not dist.is_initialized()      # torn down on the way out
