@@ -39,7 +39,8 @@ int obte_struct_sizes(int64_t* out, int cap);
  * While enabled, every obte_gemm_bf16 / obte_attn_fwd / obte_attn_bwd call is bracketed by two hipEvents on the
  * caller's stream.  obte_profile_collect synchronises those events and returns up to cap records:
  * ms[i] = elapsed milliseconds, dims[3*i..] = (M,N,K) for a GEMM or (B*H, T, head_dim) for attention,
- * kind[i] = a_kmajor*8 + b_kmajor*4 + epilogue for a GEMM, 100 = attention forward, 101 = attention backward.
+ * kind[i] = a_kmajor*8 + b_kmajor*4 + epilogue (+ 32.. for a grouped launch) + 1000 * kernel structure (1 gemm_bf16_kernel,
+ * 2 gemm_v2_kernel, 3 gemm_v3_kernel) for a GEMM, 100 = attention forward, 101 = attention backward.
  * Returns the number of records written (records are cleared). */
 int obte_profile_enable(int on);
 int obte_profile_collect(double* ms, int64_t* dims, int32_t* kind, int cap);
@@ -231,6 +232,16 @@ typedef struct {
 } obte_mt_args;
 int obte_adamw_multi_bf16(const obte_mt_args* t, float beta1, float beta2, float eps, const float* clip_coef, obte_stream s);
 int obte_sumsq_multi_bf16(const obte_mt_args* t, float* out, obte_stream s);
+/* out[i] += sum of squares of tensor i (fp32 [count]): per-tensor norms, as torch's clip_grad_norm_ forms them before it
+ * combines them (it rounds each to the gradients' dtype first: train_encoder.py:316 on bf16 gradients). */
+int obte_sumsq_multi_bf16_each(const obte_mt_args* t, float* out, obte_stream s);
+/* The same step with the reference's own rounding sequence: torch.optim.AdamW (which MuAdamW is underneath,
+ * train_encoder.py:195-199) on bf16 tensors rounds after EVERY tensor op — clip scaling, p.mul_, exp_avg.lerp_,
+ * exp_avg_sq.mul_().addcmul_(), sqrt, / sqrt(bias_correction2), + eps, addcdiv_ — where obte_adamw_multi_bf16 rounds each
+ * state once.  This is the form the harness uses (FusedAdamW(rounding="reference")) so that loss curves track the
+ * reference's step for step; scalars (1 - lr*wd, lr/bias_correction1, sqrt(bias_correction2)) are formed in double like
+ * Python does. */
+int obte_adamw_multi_bf16_ref(const obte_mt_args* t, float beta1, float beta2, float eps, const float* clip_coef, obte_stream s);
 
 /* ---- whole transformer block (training/model.py:170-181), forward and backward, dropout 0 --------------------
  * One host call enqueues every kernel of the block, so Python crosses the boundary once per block and pass.

@@ -278,12 +278,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const bf16* __restrict__ g, 
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
-
 // ---- multi-tensor forms: workgroup b serves chunk (b - first[t]) of tensor t; chunks of 16384 elements -----------
 constexpr int MT_CHUNK = 16384;
 struct MtTable {
     bf16* p[OBTE_MT_MAX]; const bf16* g[OBTE_MT_MAX]; bf16* m[OBTE_MT_MAX]; bf16* v[OBTE_MT_MAX];
     int64_t n[OBTE_MT_MAX]; float lr[OBTE_MT_MAX]; float wd[OBTE_MT_MAX]; float bc1[OBTE_MT_MAX]; float bc2s[OBTE_MT_MAX];
+    float decay[OBTE_MT_MAX]; float step_size[OBTE_MT_MAX];   // 1 - lr*wd and lr / bias_correction1, formed in double on the host
     int first[OBTE_MT_MAX + 1];
     int count;
 };
@@ -317,7 +317,47 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(MtTable t, float b1, f
     }
 }
 
-__global__ __launch_bounds__(256) void sumsq_multi_kernel(MtTable t, float* __restrict__ out) {
+// The reference's arithmetic, rounding for rounding: torch.optim.AdamW on bf16 parameters with bf16 moments
+// (train_encoder.py:170,195-199) evaluates each tensor op in fp32 and rounds its result to bf16 before the next op
+// (torch/optim/adamw.py, both the for-loop and the foreach form):
+//     g   = bf16(g * clip)                        clip_grad_norm_'s in-place scaling (train_encoder.py:316)
+//     p   = bf16(p * (1 - lr*wd))                 param.mul_
+//     m   = bf16(m + (g - m) * (1 - beta1))       exp_avg.lerp_
+//     v   = bf16(v * beta2);  v = bf16(v + (1 - beta2) * g * g)          exp_avg_sq.mul_().addcmul_()
+//     d   = bf16(sqrt(v));  d = bf16(d / sqrt(bias_correction2));  d = bf16(d + eps)
+//     p   = bf16(p + (-lr / bias_correction1) * (m / d))                  param.addcdiv_
+// adamw_multi_kernel above rounds each state once per step instead (more accurate, not what the reference computes).
+__global__ __launch_bounds__(256) void adamw_multi_ref_kernel(MtTable t, float b1, float b2, float eps, const float* __restrict__ clip) {
+    const int ti = mt_find(t, blockIdx.x);
+    const int64_t base = (int64_t)(blockIdx.x - t.first[ti]) * MT_CHUNK;
+    const int64_t end = min(base + (int64_t)MT_CHUNK, t.n[ti]);
+    const float decay = t.decay[ti], step_size = t.step_size[ti], bc2s = t.bc2s[ti];
+    const float w1 = 1.0f - b1, w2 = 1.0f - b2;
+    const bool clipped = clip != nullptr;
+    const float cc = clipped ? clip[0] : 1.0f;
+    bf16* p = t.p[ti]; const bf16* g = t.g[ti]; bf16* m = t.m[ti]; bf16* v = t.v[ti];
+    for (int64_t i = base + threadIdx.x * 8; i < end; i += 256 * 8) {
+        bf16x8 pp = *reinterpret_cast<bf16x8*>(p + i), mm = *reinterpret_cast<bf16x8*>(m + i), vv = *reinterpret_cast<bf16x8*>(v + i);
+        const bf16x8 gg = *reinterpret_cast<const bf16x8*>(g + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gj = clipped ? bf2f(f2bf(bf2f(gg[j]) * cc)) : bf2f(gg[j]);
+            float pj = bf2f(f2bf(bf2f(pp[j]) * decay));
+            const float mj = bf2f(f2bf(bf2f(mm[j]) + w1 * (gj - bf2f(mm[j]))));
+            float vj = bf2f(f2bf(bf2f(vv[j]) * b2));
+            vj = bf2f(f2bf(vj + w2 * gj * gj));
+            float d = bf2f(f2bf(sqrtf(vj)));
+            d = bf2f(f2bf(d / bc2s));
+            d = bf2f(f2bf(d + eps));
+            pj = pj + (-step_size) * (mj / d);
+            pp[j] = f2bf(pj); mm[j] = f2bf(mj); vv[j] = f2bf(vj);
+        }
+        *reinterpret_cast<bf16x8*>(p + i) = pp; *reinterpret_cast<bf16x8*>(m + i) = mm; *reinterpret_cast<bf16x8*>(v + i) = vv;
+    }
+}
+
+// each != 0: one sum per tensor (out[tensor index]) instead of one for all of them
+__global__ __launch_bounds__(256) void sumsq_multi_kernel(MtTable t, float* __restrict__ out, int each) {
     __shared__ float red[4];
     const int ti = mt_find(t, blockIdx.x);
     const int64_t base = (int64_t)(blockIdx.x - t.first[ti]) * MT_CHUNK;
@@ -332,7 +372,7 @@ __global__ __launch_bounds__(256) void sumsq_multi_kernel(MtTable t, float* __re
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) atomicAdd(out + (each ? ti : 0), red[0] + red[1] + red[2] + red[3]);
 }
 
 int mt_build(const obte_mt_args* a, float beta1, float beta2, MtTable* t, const char* who, bool need_state) {
@@ -347,6 +387,8 @@ int mt_build(const obte_mt_args* a, float beta1, float beta2, MtTable* t, const 
         const int st = a->step[i] < 1 ? 1 : a->step[i];
         t->bc1[i] = 1.0f - powf(beta1, (float)st);
         t->bc2s[i] = sqrtf(1.0f - powf(beta2, (float)st));
+        t->decay[i] = (float)(1.0 - (double)a->lr[i] * (double)a->weight_decay[i]);
+        t->step_size[i] = (float)((double)a->lr[i] / (1.0 - pow((double)beta1, (double)st)));
         t->first[i] = blocks;
         blocks += (int)cdiv64(a->n[i], MT_CHUNK);
     }
@@ -500,12 +542,32 @@ extern "C" int obte_adamw_multi_bf16(const obte_mt_args* a, float beta1, float b
     return OBTE_OK;
 }
 
+extern "C" int obte_adamw_multi_bf16_ref(const obte_mt_args* a, float beta1, float beta2, float eps, const float* clip_coef, obte_stream s) {
+    MtTable t;
+    const int blocks = mt_build(a, beta1, beta2, &t, "obte_adamw_multi_bf16_ref", true);
+    if (blocks < 0) return blocks;
+    for (int i = 0; i < a->count; ++i) t.bc2s[i] = (float)sqrt(1.0 - pow((double)beta2, (double)(a->step[i] < 1 ? 1 : a->step[i])));
+    hipLaunchKernelGGL(adamw_multi_ref_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, t, beta1, beta2, eps, clip_coef);
+    OBTE_CHECK_LAUNCH("obte_adamw_multi_bf16_ref");
+    return OBTE_OK;
+}
+
 extern "C" int obte_sumsq_multi_bf16(const obte_mt_args* a, float* out, obte_stream s) {
     OBTE_REQUIRE(out, "obte_sumsq_multi_bf16: null output");
     MtTable t;
     const int blocks = mt_build(a, 0.9f, 0.999f, &t, "obte_sumsq_multi_bf16", false);
     if (blocks < 0) return blocks;
-    hipLaunchKernelGGL(sumsq_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, t, out);
+    hipLaunchKernelGGL(sumsq_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, t, out, 0);
     OBTE_CHECK_LAUNCH("obte_sumsq_multi_bf16");
+    return OBTE_OK;
+}
+
+extern "C" int obte_sumsq_multi_bf16_each(const obte_mt_args* a, float* out, obte_stream s) {
+    OBTE_REQUIRE(out, "obte_sumsq_multi_bf16_each: null output");
+    MtTable t;
+    const int blocks = mt_build(a, 0.9f, 0.999f, &t, "obte_sumsq_multi_bf16_each", false);
+    if (blocks < 0) return blocks;
+    hipLaunchKernelGGL(sumsq_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, t, out, 1);
+    OBTE_CHECK_LAUNCH("obte_sumsq_multi_bf16_each");
     return OBTE_OK;
 }

@@ -93,8 +93,13 @@ class FusedAdamW(torch.optim.Optimizer):
     squared norm is accumulated on the device and the coefficient min(1, max_norm/(norm+1e-6)) is consumed by the
     update kernel directly."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, rounding: str = "reference"):
+        """rounding="reference" (default): every tensor op of torch.optim.AdamW's bf16 update is rounded to bf16 exactly
+        where the reference's optimizer rounds it (obte_adamw_multi_bf16_ref), so trajectories track the reference's;
+        "single": fp32 arithmetic per element with one rounding per state (more accurate, not the reference's numbers)."""
+        assert rounding in ("reference", "single")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.rounding = rounding
         self._norm_sq = None
 
     @torch.no_grad()
@@ -127,18 +132,32 @@ class FusedAdamW(torch.optim.Optimizer):
         if not batches:
             return None
         clip = None
-        if max_norm is not None:
+        if max_norm is not None and self.rounding == "reference":
+            # clip_grad_norm_ on bf16 gradients (train_encoder.py:316): per-tensor norms rounded to bf16, their 2-norm
+            # rounded to bf16, the coefficient max_norm / (total + 1e-6) formed and clamped in bf16
             dev = torch.device("cuda", torch.cuda.current_device())
-            if self._norm_sq is None or self._norm_sq.device != dev:
+            n_tensors = sum(a.count for a, _, _ in batches)
+            if self._norm_sq is None or self._norm_sq.device != dev or self._norm_sq.numel() != n_tensors:
+                self._norm_sq = torch.zeros(n_tensors, dtype=torch.float32, device=dev)
+            self._norm_sq.zero_()
+            off = 0
+            for a, _, _ in batches:
+                L.check(lib.obte_sumsq_multi_bf16_each(C.byref(a), self._norm_sq.data_ptr() + 4 * off, stream), "obte_sumsq_multi_bf16_each")
+                off += a.count
+            total = torch.linalg.vector_norm(self._norm_sq.sqrt().to(torch.bfloat16))
+            clip = torch.clamp(max_norm / (total + 1e-6), max=1.0).float().reshape(1)
+        elif max_norm is not None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            if self._norm_sq is None or self._norm_sq.device != dev or self._norm_sq.numel() != 1:
                 self._norm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
             self._norm_sq.zero_()
             for a, _, _ in batches:
                 L.check(lib.obte_sumsq_multi_bf16(C.byref(a), self._norm_sq.data_ptr(), stream), "obte_sumsq_multi_bf16")
             clip = torch.clamp(max_norm / (self._norm_sq.sqrt() + 1e-6), max=1.0)
+        fn = lib.obte_adamw_multi_bf16_ref if self.rounding == "reference" else lib.obte_adamw_multi_bf16
         for a, (b1, b2), eps in batches:
-            L.check(lib.obte_adamw_multi_bf16(C.byref(a), b1, b2, eps, None if clip is None else clip.data_ptr(), stream),
-                    "obte_adamw_multi_bf16")
-        return None if clip is None else self._norm_sq
+            L.check(fn(C.byref(a), b1, b2, eps, None if clip is None else clip.data_ptr(), stream), "obte_adamw_multi_bf16")
+        return None if clip is None else self._norm_sq.sum()
 
 
 # --------------------------------------------------------------------------------------------------- train step

@@ -451,3 +451,50 @@ def test_config1_tiny_through_the_cli_harness_on_gloo(tmp_path, monkeypatch, cap
     from omnibiote_amd.checkpoint import load_checkpoint
     m = load_checkpoint(name + ".pt", map_location="cuda")
     assert m.config.n_layer == 2 and m.config.n_embd == 128
+
+
+def test_hip_training_trajectory_tracks_the_reference_run(golden_dir):
+    """The north star's "MLM loss curves track the reference step-for-step", against the reference ITSELF: the fixture
+    holds 30 optimizer steps of the imported reference model in its own regime (bf16 parameters and moments, torch AdamW
+    with the muP groups, clip 1.0, LinearLR, its loss lines and mask builder — oracle/gen_golden_trajectory.py).  The
+    HIP model + fused CE + FusedAdamW(rounding="reference") runs the same stream.  Bar per step: 2^-5 = 0.031, twice the
+    spread between the reference's own two runs (SDPA vs manual attention: 2^-6, one bf16 ulp of a micro-batch loss —
+    the reference's losses are themselves bf16-quantised, the HIP path's CE is fp32)."""
+    from omnibiote_amd import train_encoder as TE
+    from omnibiote_amd.mup_compat import mu_param_groups, set_base_shapes
+    from omnibiote_amd.model import OmniBioTA, OmniBioTAConfig
+    g = load(golden_dir, "trajectory_tiny_bf16")
+    bs, V, Lyr, H, C, _ = [int(v) for v in g["cfg"]]
+    lr, wd, b1, b2, eps, total_iters, rows, mini, T, steps, n_batches = g["hyper"]
+    total_iters, rows, mini, T, steps, n_batches = int(total_iters), int(rows), int(mini), int(T), int(steps), int(n_batches)
+    spread = float(np.abs(g["losses_flash"] - g["losses_manual"]).max())
+    c = OmniBioTAConfig(); c.block_size, c.vocab_size, c.n_layer, c.n_head, c.n_embd, c.dropout, c.flash = bs, V, Lyr, H, C, 0.0, True
+    m = OmniBioTA(c)
+    cb = OmniBioTAConfig(); cb.block_size, cb.vocab_size, cb.n_layer, cb.dropout, cb.flash = bs, V, Lyr, 0.0, True
+    cb.n_embd, cb.n_head = 24, 3
+    base = OmniBioTA(cb)
+    cb.n_embd, cb.n_head = 48, 12
+    delta = OmniBioTA(cb)
+    set_base_shapes(m, base, delta=delta, rescale_params=False)
+    m.load_state_dict(R.hash_weights(R.RefConfig(block_size=bs, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C)), strict=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.to(BF)
+    m.to(DEV)
+    opt = TE.FusedAdamW(mu_param_groups(list(m.parameters()), lr, wd), lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, rounding="reference")
+    sched = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1.0, end_factor=0.0, total_iters=total_iters)
+    step = TE.TrainStep(m, opt, sched, mini_batch_size=mini, n_head=H)
+    losses = []
+    for i in range(steps):
+        ids = torch.from_numpy(g["tokens"][i % n_batches]).to(DEV)
+        losses.append(step(ids, mlm_mask=torch.from_numpy(g["mlm_draw"][i]).to(DEV))["loss"].item())
+    losses = np.array(losses)
+    dev = np.abs(losses - g["losses_flash"])
+    print("HIP vs reference loss curve: max", dev.max(), "mean", dev.mean(), "(reference's own spread", spread, ")")
+    assert dev.max() <= 2.0 ** -5, (losses, g["losses_flash"])
+    assert losses[-5:].mean() < losses[:5].mean() - 0.1
+    stride = int(g["param_stride"])
+    for k, p in m.named_parameters():
+        d = np.abs(p.detach().float().flatten()[::stride].cpu().numpy() - g["final_flash/" + k])
+        dd = np.abs(g["final_manual/" + k] - g["final_flash/" + k])
+        assert d.mean() <= 3.0 * dd.mean() + 2e-3 and d.max() <= 0.06, (k, d.mean(), d.max(), dd.mean(), dd.max())

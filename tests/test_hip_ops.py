@@ -829,3 +829,50 @@ def test_masked_ce_reused_gradient_buffer():
         loss_a, fresh = o.masked_ce(logits, tgt, mask, 2)
         loss_b, reused = o.masked_ce(logits, tgt, mask, 2, reuse=buf)
         assert torch.equal(fresh, reused) and loss_a.item() == loss_b.item()
+
+
+def test_fused_adamw_reference_rounding_is_torch_adamw_on_bf16_tensors():
+    """What the reference literally runs: torch.optim.AdamW (MuAdamW underneath, train_encoder.py:195-199) on bf16
+    parameters with bf16 moments, preceded by clip_grad_norm_ (:316).  FusedAdamW(rounding="reference") must reproduce it
+    over several steps — not a formula typed into the test, the optimizer itself on CPU bf16 tensors.  Bar: after 12 steps
+    at least 99 % of all parameter and moment elements are bit-identical and none is further than 2 bf16 ulps away (the
+    only differences left: fp32 evaluation order inside single ops, e.g. value * m / d, and the bf16 rounding of the
+    total gradient norm in clip_grad_norm_)."""
+    from omnibiote_amd import train_encoder as TE
+    shapes = [(256, 128), (1024,), (64, 512), (8,)]
+    steps = 12
+    gen = torch.Generator().manual_seed(5)
+    p0 = [torch.randn(s, generator=gen).to(BF) for s in shapes]
+    grads = [[(torch.randn(s, generator=gen) * (0.3 if t % 3 else 3.0)).to(BF) for s in shapes] for t in range(steps)]   # some steps clip, some do not
+    lr, wd, betas, eps = 3e-3, 1e-2, (0.9, 0.999), 1e-8
+    cpu = [torch.nn.Parameter(x.clone()) for x in p0]
+    gpu = [torch.nn.Parameter(x.clone().to(DEV)) for x in p0]
+    groups = lambda ps: [{"params": ps[:2], "lr": lr / 4, "weight_decay": wd * 4}, {"params": ps[2:], "lr": lr, "weight_decay": wd}]
+    ref = torch.optim.AdamW(groups(cpu), lr=lr, betas=betas, eps=eps, weight_decay=wd)
+    fused = TE.FusedAdamW(groups(gpu), lr=lr, betas=betas, eps=eps, weight_decay=wd, rounding="reference")
+    sched_r = torch.optim.lr_scheduler.LinearLR(ref, start_factor=1.0, end_factor=0.0, total_iters=40)
+    sched_f = torch.optim.lr_scheduler.LinearLR(fused, start_factor=1.0, end_factor=0.0, total_iters=40)
+    for t in range(steps):
+        for q, r, gq in zip(cpu, gpu, grads[t]):
+            q.grad = gq.clone()
+            r.grad = gq.clone().to(DEV)
+        torch.nn.utils.clip_grad_norm_(cpu, 1.0)
+        ref.step(); sched_r.step()
+        fused.step(max_norm=1.0); sched_f.step()
+    total = same = 0
+    worst = {"p": 0.0, "exp_avg": 0.0, "exp_avg_sq": 0.0}
+    for q, r in zip(cpu, gpu):
+        states = [("p", q.data, r.data), ("exp_avg", ref.state[q]["exp_avg"], fused.state[r]["exp_avg"]),
+                  ("exp_avg_sq", ref.state[q]["exp_avg_sq"], fused.state[r]["exp_avg_sq"])]
+        for kind, a, b in states:
+            a, b = a.float(), b.float().cpu()
+            total += a.numel()
+            same += int((a == b).sum())
+            ulp = torch.maximum(a.abs(), b.abs()) * 2.0 ** -7 + 1e-30
+            # a parameter is the running sum of updates of size ~lr: near zero its own ulp is far finer than one ulp of an
+            # update, so parameters get an absolute allowance of 2 % of one lr-sized step on top of the two ulps
+            slack = 0.02 * lr if kind == "p" else 0.0
+            worst[kind] = max(worst[kind], ((a - b).abs() / (2.0 * ulp + slack)).max().item())
+    print("fused AdamW (reference rounding) vs torch.optim.AdamW on bf16 CPU tensors:", same, "of", total, "elements identical; worst / bar:", worst)
+    assert max(worst.values()) <= 1.0, worst
+    assert same >= 0.99 * total, (same, total)

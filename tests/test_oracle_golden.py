@@ -140,3 +140,48 @@ def test_rope_and_gelu_helpers(golden_dir):
     x = torch.from_numpy(g["gelu_x"])
     np.testing.assert_allclose(R.gelu_erf(x).numpy(), g["gelu_y"], atol=1e-7)
     np.testing.assert_array_equal(R.gelu_erf(x.bfloat16()).float().numpy(), g["gelu_y_bf16"])
+
+
+def _trajectory_setup(golden_dir):
+    g = np.load(os.path.join(golden_dir, "trajectory_tiny_bf16.npz"))
+    bs, V, Lyr, H, C, _ = [int(v) for v in g["cfg"]]
+    hyper = dict(zip(["lr", "wd", "b1", "b2", "eps", "total_iters", "rows", "mini", "T", "steps", "n_batches"], g["hyper"]))
+    for k in ("total_iters", "rows", "mini", "T", "steps", "n_batches"):
+        hyper[k] = int(hyper[k])
+    return g, R.RefConfig(block_size=bs, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C), hyper
+
+
+def test_oracle_training_trajectory_tracks_the_reference_run(golden_dir):
+    """tests/golden/trajectory_tiny_bf16.npz holds 30 optimizer steps of the IMPORTED reference model in its own regime
+    (bf16 parameters and moments, torch.optim.AdamW with the muP groups passed explicitly, clip 1.0, LinearLR, the
+    reference's loss lines and mask builder; oracle/gen_golden_trajectory.py), once through SDPA and once through its
+    manual attention path.  The two reference runs differ by at most one bf16 ulp of a micro-batch loss (2^-6 = 0.0156);
+    the oracle, run the same way, must stay within that spread of the reference at every step."""
+    from omnibiote_amd import train_encoder as TE
+    g, cfg, h = _trajectory_setup(golden_dir)
+    spread = float(np.abs(g["losses_flash"] - g["losses_manual"]).max())
+    assert spread <= 2.0 ** -6 + 1e-9
+    w = {k: v.to(torch.bfloat16) for k, v in R.hash_weights(cfg).items()}
+    enc = R.OracleEncoder(cfg, w)
+    enc.rope = R.cast_rope_table(R.rope_table(cfg.n_embd // cfg.n_head, cfg.block_size), torch.bfloat16)
+    named = enc.named_weights()
+    mats = [p for n, p in named.items() if p.dim() == 2 and "wte" not in n and "lm_head" not in n]
+    vecs = [p for n, p in named.items() if not (p.dim() == 2 and "wte" not in n and "lm_head" not in n)]
+    wm = cfg.n_embd / R.MUP_BASE_WIDTH
+    opt = torch.optim.AdamW([{"params": mats, "lr": h["lr"] / wm, "weight_decay": h["wd"] * wm}, {"params": vecs, "lr": h["lr"], "weight_decay": h["wd"]}],
+                            lr=h["lr"], betas=(h["b1"], h["b2"]), eps=h["eps"], weight_decay=h["wd"])
+    sched = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1.0, end_factor=0.0, total_iters=h["total_iters"])
+    step = TE.TrainStep(enc, opt, sched, mini_batch_size=h["mini"], n_head=cfg.n_head, loss_impl="torch", mask_impl="dense")
+    losses = []
+    for i in range(h["steps"]):
+        ids = torch.from_numpy(g["tokens"][i % h["n_batches"]])
+        losses.append(step(ids, mlm_mask=torch.from_numpy(g["mlm_draw"][i]))["loss"].item())
+    losses = np.array(losses)
+    assert np.abs(losses - g["losses_flash"]).max() <= 2.0 ** -6 + 1e-6, (losses, g["losses_flash"])
+    assert losses[-5:].mean() < losses[:5].mean() - 0.1                       # it trains
+    stride = int(g["param_stride"])
+    for k, p in named.items():
+        d = np.abs(p.detach().float().flatten()[::stride].numpy() - g["final_flash/" + k])
+        dd = np.abs(g["final_manual/" + k] - g["final_flash/" + k])
+        # bar: the spread between the reference's own two runs (dd), plus two bf16 ulps at 1.0 spread over the tensor
+        assert d.mean() <= 3.0 * dd.mean() + 2e-3 and d.max() <= 0.06, (k, d.mean(), d.max(), dd.mean(), dd.max())
