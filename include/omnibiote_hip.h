@@ -241,7 +241,7 @@ int obte_sumsq_multi_bf16_each(const obte_mt_args* t, float* out, obte_stream s)
  * state once.  This is the form the harness uses (FusedAdamW(rounding="reference")) so that loss curves track the
  * reference's step for step; scalars (1 - lr*wd, lr/bias_correction1, sqrt(bias_correction2)) are formed in double like
  * Python does. */
-int obte_adamw_multi_bf16_ref(const obte_mt_args* t, float beta1, float beta2, float eps, const float* clip_coef, obte_stream s);
+int obte_adamw_multi_bf16_ref(const obte_mt_args* t, double beta1, double beta2, double eps, const float* clip_coef, obte_stream s);
 
 /* ---- whole transformer block (training/model.py:170-181), forward and backward, dropout 0 --------------------
  * One host call enqueues every kernel of the block, so Python crosses the boundary once per block and pass.

@@ -101,7 +101,7 @@ SYMBOLS = {
     "obte_adamw_multi_bf16": (C.c_int, [C.POINTER(MtArgs), C.c_float, C.c_float, C.c_float, C.c_void_p, c_stream]),
     "obte_sumsq_multi_bf16": (C.c_int, [C.POINTER(MtArgs), C.c_void_p, c_stream]),
     "obte_sumsq_multi_bf16_each": (C.c_int, [C.POINTER(MtArgs), C.c_void_p, c_stream]),
-    "obte_adamw_multi_bf16_ref": (C.c_int, [C.POINTER(MtArgs), C.c_float, C.c_float, C.c_float, C.c_void_p, c_stream]),
+    "obte_adamw_multi_bf16_ref": (C.c_int, [C.POINTER(MtArgs), C.c_double, C.c_double, C.c_double, C.c_void_p, c_stream]),
     "obte_block_act_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "obte_block_bwd_ws_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "obte_block_fwd": (C.c_int, [C.POINTER(BlockDesc), C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),

@@ -327,12 +327,18 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(MtTable t, float b1, f
 //     d   = bf16(sqrt(v));  d = bf16(d / sqrt(bias_correction2));  d = bf16(d + eps)
 //     p   = bf16(p + (-lr / bias_correction1) * (m / d))                  param.addcdiv_
 // adamw_multi_kernel above rounds each state once per step instead (more accurate, not what the reference computes).
-__global__ __launch_bounds__(256) void adamw_multi_ref_kernel(MtTable t, float b1, float b2, float eps, const float* __restrict__ clip) {
+// Ties are COMMON here (m, g sit on coarse bf16 grids, so 0.9 m + 0.1 g lands exactly between two bf16 values in
+// about 1.6 % of the elements), which makes the last fp32 bit — fused or unfused multiply-add, the association of
+// value * m / d, 0.1f vs 1.0f - 0.9f — decide a whole bf16 ulp.  The sequence below is torch's CPU kernels', checked
+// element for element against torch.optim.AdamW (tests/test_hip_ops.py): lerp = fma(w, g - m, m) (LerpKernel's
+// vec::fmadd), addcmul = fma(w * g, g, v), addcdiv = p + ((value * m) / d); contraction is switched off so that hipcc
+// fuses nothing else.  Measured: parameters and both moments bit-identical to torch's after every step.  w1 = float(1 - beta1), w2 = float(1 - beta2) are formed in double by the host.
+__global__ __launch_bounds__(256) void adamw_multi_ref_kernel(MtTable t, float b2, float w1, float w2, float eps, const float* __restrict__ clip) {
+#pragma clang fp contract(off)
     const int ti = mt_find(t, blockIdx.x);
     const int64_t base = (int64_t)(blockIdx.x - t.first[ti]) * MT_CHUNK;
     const int64_t end = min(base + (int64_t)MT_CHUNK, t.n[ti]);
-    const float decay = t.decay[ti], step_size = t.step_size[ti], bc2s = t.bc2s[ti];
-    const float w1 = 1.0f - b1, w2 = 1.0f - b2;
+    const float decay = t.decay[ti], neg_step = -t.step_size[ti], bc2s = t.bc2s[ti];
     const bool clipped = clip != nullptr;
     const float cc = clipped ? clip[0] : 1.0f;
     bf16* p = t.p[ti]; const bf16* g = t.g[ti]; bf16* m = t.m[ti]; bf16* v = t.v[ti];
@@ -343,13 +349,17 @@ __global__ __launch_bounds__(256) void adamw_multi_ref_kernel(MtTable t, float b
         for (int j = 0; j < 8; ++j) {
             const float gj = clipped ? bf2f(f2bf(bf2f(gg[j]) * cc)) : bf2f(gg[j]);
             float pj = bf2f(f2bf(bf2f(pp[j]) * decay));
-            const float mj = bf2f(f2bf(bf2f(mm[j]) + w1 * (gj - bf2f(mm[j]))));
+            const float m0 = bf2f(mm[j]);
+            const float mj = bf2f(f2bf(__builtin_fmaf(w1, gj - m0, m0)));
             float vj = bf2f(f2bf(bf2f(vv[j]) * b2));
-            vj = bf2f(f2bf(vj + w2 * gj * gj));
+            const float wg = w2 * gj;
+            vj = bf2f(f2bf(__builtin_fmaf(wg, gj, vj)));
             float d = bf2f(f2bf(sqrtf(vj)));
             d = bf2f(f2bf(d / bc2s));
             d = bf2f(f2bf(d + eps));
-            pj = pj + (-step_size) * (mj / d);
+            const float num = neg_step * mj;
+            const float upd = num / d;
+            pj = pj + upd;
             pp[j] = f2bf(pj); mm[j] = f2bf(mj); vv[j] = f2bf(vj);
         }
         *reinterpret_cast<bf16x8*>(p + i) = pp; *reinterpret_cast<bf16x8*>(m + i) = mm; *reinterpret_cast<bf16x8*>(v + i) = vv;
@@ -542,12 +552,17 @@ extern "C" int obte_adamw_multi_bf16(const obte_mt_args* a, float beta1, float b
     return OBTE_OK;
 }
 
-extern "C" int obte_adamw_multi_bf16_ref(const obte_mt_args* a, float beta1, float beta2, float eps, const float* clip_coef, obte_stream s) {
+extern "C" int obte_adamw_multi_bf16_ref(const obte_mt_args* a, double beta1, double beta2, double eps, const float* clip_coef, obte_stream s) {
     MtTable t;
-    const int blocks = mt_build(a, beta1, beta2, &t, "obte_adamw_multi_bf16_ref", true);
+    const int blocks = mt_build(a, (float)beta1, (float)beta2, &t, "obte_adamw_multi_bf16_ref", true);
     if (blocks < 0) return blocks;
-    for (int i = 0; i < a->count; ++i) t.bc2s[i] = (float)sqrt(1.0 - pow((double)beta2, (double)(a->step[i] < 1 ? 1 : a->step[i])));
-    hipLaunchKernelGGL(adamw_multi_ref_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, t, beta1, beta2, eps, clip_coef);
+    for (int i = 0; i < a->count; ++i) {   // Python forms these in double before they reach a kernel as fp32 scalars
+        const double st = (double)(a->step[i] < 1 ? 1 : a->step[i]);
+        t.bc2s[i] = (float)sqrt(1.0 - pow(beta2, st));
+        t.step_size[i] = (float)((double)a->lr[i] / (1.0 - pow(beta1, st)));
+    }
+    const float w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2);
+    hipLaunchKernelGGL(adamw_multi_ref_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, t, (float)beta2, w1, w2, (float)eps, clip_coef);
     OBTE_CHECK_LAUNCH("obte_adamw_multi_bf16_ref");
     return OBTE_OK;
 }

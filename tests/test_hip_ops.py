@@ -834,10 +834,9 @@ def test_masked_ce_reused_gradient_buffer():
 def test_fused_adamw_reference_rounding_is_torch_adamw_on_bf16_tensors():
     """What the reference literally runs: torch.optim.AdamW (MuAdamW underneath, train_encoder.py:195-199) on bf16
     parameters with bf16 moments, preceded by clip_grad_norm_ (:316).  FusedAdamW(rounding="reference") must reproduce it
-    over several steps — not a formula typed into the test, the optimizer itself on CPU bf16 tensors.  Bar: after 12 steps
-    at least 99 % of all parameter and moment elements are bit-identical and none is further than 2 bf16 ulps away (the
-    only differences left: fp32 evaluation order inside single ops, e.g. value * m / d, and the bf16 rounding of the
-    total gradient norm in clip_grad_norm_)."""
+    over several steps — not a formula typed into the test, the optimizer itself on CPU bf16 tensors.  Integer-grade bar:
+    after 12 steps (clipping active, LinearLR, two parameter groups) at least 99.9 % of all parameter and moment elements
+    are BIT-identical (measured: all of them) and none is further than 2 bf16 ulps away."""
     from omnibiote_amd import train_encoder as TE
     shapes = [(256, 128), (1024,), (64, 512), (8,)]
     steps = 12
@@ -875,4 +874,4 @@ def test_fused_adamw_reference_rounding_is_torch_adamw_on_bf16_tensors():
             worst[kind] = max(worst[kind], ((a - b).abs() / (2.0 * ulp + slack)).max().item())
     print("fused AdamW (reference rounding) vs torch.optim.AdamW on bf16 CPU tensors:", same, "of", total, "elements identical; worst / bar:", worst)
     assert max(worst.values()) <= 1.0, worst
-    assert same >= 0.99 * total, (same, total)
+    assert same >= 0.999 * total, (same, total)

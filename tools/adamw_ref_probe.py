@@ -27,3 +27,24 @@ for t in range(steps):
     for i, (q, r) in enumerate(zip(cpu, gpu)):
         f = lambda a, b: float((a.float() == b.float().cpu()).float().mean())
         print(f"   tensor {i}: p {f(q.data, r.data):.5f} m {f(ref.state[q]['exp_avg'], fused.state[r]['exp_avg']):.5f} v {f(ref.state[q]['exp_avg_sq'], fused.state[r]['exp_avg_sq']):.5f}")
+
+# ---- one more step with full diagnostics on tensor 0
+t = steps
+gq = (torch.randn(shapes[0], generator=gen) * 0.3).to(BF)
+m_old = ref.state[cpu[0]]["exp_avg"].clone(); m_old_g = fused.state[gpu[0]]["exp_avg"].clone()
+print("m_old identical before:", float((m_old.float() == m_old_g.float().cpu()).float().mean()))
+fused.state[gpu[0]]["exp_avg"].copy_(m_old.cuda()); fused.state[gpu[0]]["exp_avg_sq"].copy_(ref.state[cpu[0]]["exp_avg_sq"].cuda()); gpu[0].data.copy_(cpu[0].data.cuda())
+for i, (q, r) in enumerate(zip(cpu, gpu)):
+    q.grad = (gq.clone() if i == 0 else torch.zeros_like(q)); r.grad = q.grad.clone().cuda()
+tn = torch.nn.utils.clip_grad_norm_(cpu, 1.0)
+g_clipped = cpu[0].grad.clone()
+ref.step(); fused.step(max_norm=1.0)
+m_c, m_g = ref.state[cpu[0]]["exp_avg"].float(), fused.state[gpu[0]]["exp_avg"].float().cpu()
+bad = (m_c != m_g).nonzero()
+print("after resync, one step: m identical", float((m_c == m_g).float().mean()), "n bad", len(bad))
+emu = (m_old.float() + torch.tensor(0.1, dtype=torch.float32) * (g_clipped.float() - m_old.float())).to(BF).float()
+print("emu vs cpu", float((emu == m_c).float().mean()), "emu vs gpu", float((emu == m_g).float().mean()))
+for ix in bad[:6]:
+    ix = tuple(ix.tolist())
+    print(ix, "m_old", m_old[ix].item(), "g_clipped(cpu)", g_clipped[ix].item(), "g", gq[ix].item(), "cpu", m_c[ix].item(), "gpu", m_g[ix].item(),
+          "exact", m_old[ix].double().item() + 0.1 * (g_clipped[ix].double().item() - m_old[ix].double().item()))
