@@ -34,6 +34,8 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 METRIC = "MLM train tokens/sec, small (8L/1024d) ctx=1024 at 1/2/4/8 MI355X"
 
+READOUT_TEXT = {"dense": "full 65536-way logits for every position in the forward, readout backward over the MLM-masked rows (the other rows of d(logits) are exact zeros)",
+                "dense_full": "full 65536-way logits and dense d(logits)", "masked": "masked-rows-only 65536-way logits"}
 CONFIGS = {
     "small": dict(n_layer=8, n_embd=1024, n_head=8, ctx_len=1024),
     "small4k": dict(n_layer=8, n_embd=1024, n_head=8, ctx_len=4096),
@@ -51,8 +53,12 @@ def parse():
     p.add_argument("--rows_per_rank", type=int, default=128, help="rows per rank per optimizer step (batch_size / world)")
     p.add_argument("--mini_batch_size", type=int, default=8)
     p.add_argument("--multi_document", action="store_true", help="rows with interior EOS (block-diagonal masks)")
-    p.add_argument("--masked_lm_head", action="store_true",
-                   help="readout + CE on the MLM-masked rows only (SURVEY §8f rank 1; same loss/gradients, not the headline)")
+    p.add_argument("--readout", default="dense", choices=["dense", "dense_full", "masked"],
+                   help="dense (default): logits of every position in the forward, as the reference computes them; the backward "
+                        "contracts over the MLM-masked rows only (the other rows of d(logits) are exact zeros).  dense_full: also "
+                        "the dense [M,V] d(logits) and full-size backward products (the reference's literal graph).  masked: "
+                        "readout + CE on the masked rows only in the forward too (SURVEY §8f rank 1; not the headline)")
+    p.add_argument("--masked_lm_head", action="store_true", help="alias of --readout masked")
     p.add_argument("--dropout", type=float, default=0.0, help="0.0 = the parity regime (default); 0.1 = the reference's default")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
@@ -254,6 +260,8 @@ def self_launch(n_gpus: int) -> int:
 
 def main():
     a = parse()
+    if a.masked_lm_head:
+        a.readout = "masked"
     cfg = CONFIGS[a.config]
     if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("OBTE_BENCH_FORCE_LAUNCH") == "1"):
         sys.exit(self_launch(a.gpus))   # (OBTE_BENCH_FORCE_LAUNCH=1: rehearse the child launch with one rank on a one-GPU box)
@@ -301,7 +309,7 @@ def main():
     total_iters = 1000
     opt, sched = TE.build_optimizer(m, h, total_iters)
     step = TE.TrainStep(model, opt, sched, mini_batch_size=a.mini_batch_size, n_head=cfg["n_head"],
-                        lm_head_impl="masked" if a.masked_lm_head else "dense", pipeline_streams=a.pipeline_streams,
+                        lm_head_impl=a.readout, pipeline_streams=a.pipeline_streams,
                         mask_impl="dense" if a.dense_mask else "ranges")
     rng = np.random.default_rng(1234 + rank)
     T = cfg["ctx_len"]
@@ -350,7 +358,7 @@ def main():
             # figure comes from the committed rocprofv3 --pmc passes over this same workload (tools/pmc_traffic.py)
             pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r02_pmc_gemm_family_traffic.json", "r01_pmc_gemm_family_traffic.json"))
                         if os.path.exists(q)), "")
-            default_workload = (a.config == "small" and not a.masked_lm_head and a.dropout == 0.0 and not a.multi_document
+            default_workload = (a.config == "small" and a.readout == "dense" and a.dropout == 0.0 and not a.multi_document
                                 and a.rows_per_rank == 128 and a.mini_batch_size == 8)
             if default_workload and pmc:
                 with open(pmc) as f:
@@ -397,11 +405,17 @@ def main():
     if not a.no_variants:
         log("variants")
         variants = {}
-        if not a.masked_lm_head:
+        if a.readout != "masked":
             step.lm_head_impl = "masked"
             variants["masked_rows_readout"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
-                                               "note": "readout + CE on the MLM-masked rows only; identical loss and gradients; not the headline"}
-            step.lm_head_impl = "dense"
+                                               "note": "readout + CE on the MLM-masked rows only, forward included; identical loss and gradients; not the headline"}
+            step.lm_head_impl = a.readout
+        if a.readout != "dense_full":
+            step.lm_head_impl = "dense_full"
+            variants["dense_dlogits_full_backward"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
+                                                       "note": "the reference's literal graph: dense [M,V] d(logits) and full-size readout backward products "
+                                                               "(85 % of those rows are exact zeros); identical loss and gradients"}
+            step.lm_head_impl = a.readout
         if a.dropout == 0.0:
             TE.set_dropout(m, 0.1)
             variants["dropout_0.1"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
@@ -422,7 +436,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"OmniBioTA {a.config} ({cfg['n_layer']}L/{cfg['n_embd']}d/{cfg['n_head']}h) ctx={T} MLM train step: "
                                    f"{a.rows_per_rank} rows/rank = {a.rows_per_rank // a.mini_batch_size} micro-batches of {a.mini_batch_size}, "
-                                   f"{'masked-rows-only' if a.masked_lm_head else 'full'} 65536-way logits, dropout {a.dropout:g}, {'multi' if a.multi_document else 'single'}-document rows",
+                                   f"{READOUT_TEXT[a.readout]}, dropout {a.dropout:g}, {'multi' if a.multi_document else 'single'}-document rows",
                        "global_batch_rows": a.rows_per_rank * world, "mini_batch_size": a.mini_batch_size, "seq_len": T,
                        "parallelism": f"dp{world}", "dropout": a.dropout, "vocab": 65536,
                        "collectives": (f"RCCL ({dist.get_backend()}) over {world} ranks: one bucketed gradient all-reduce per optimizer step"

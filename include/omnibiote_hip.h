@@ -213,6 +213,15 @@ int obte_masked_ce_fwd_bwd_reuse(const obte_bf16* logits, const int64_t* target,
                                  const uint8_t* prev_mask, const float* grad_scale, float row_scale, float* row_loss,
                                  obte_bf16* dlogits, int64_t rows, int64_t vocab, obte_stream s);
 
+/* Compact form: the loss looks at the MLM-masked positions only (loss *= mask, train_encoder.py:304), so every other row of
+ * d(logits) is an exact zero.  row_index: int64 [n_rows], ascending positions (rows of the dense [total_rows, vocab]
+ * logits) that are masked; target is indexed by position; row_loss [n_rows] and dlogits_rows [n_rows, vocab] are
+ * compact.  The readout's backward then contracts over n_rows instead of total_rows — the zero rows it leaves out
+ * contribute nothing to either gradient. */
+int obte_masked_ce_rows(const obte_bf16* logits, const int64_t* target, const int64_t* row_index, const float* grad_scale,
+                        float row_scale, float* row_loss, obte_bf16* dlogits_rows, int64_t n_rows, int64_t total_rows,
+                        int64_t vocab, obte_stream s);
+
 /* ---- fused AdamW step, bf16 params/grads/moments as the reference trains (train_encoder.py:170,199,316-317) ---
  * One launch per tensor: p -= lr*(m_hat/(sqrt(v_hat)+eps) + wd*p), grads pre-multiplied by clip_coef[0]
  * (device fp32, 1.0 if no clipping).  step is 1-based.  */

@@ -188,19 +188,23 @@ __global__ __launch_bounds__(128) void embed_bwd_span_kernel(const int64_t* __re
 __global__ __launch_bounds__(256) void masked_ce_kernel(const bf16* __restrict__ logits, const int64_t* __restrict__ target,
                                                          const uint8_t* __restrict__ mlm_mask, const uint8_t* __restrict__ prev_mask,
                                                          const float* __restrict__ grad_scale, float row_scale,
-                                                         float* __restrict__ row_loss, bf16* __restrict__ dlogits, int64_t vocab) {
+                                                         float* __restrict__ row_loss, bf16* __restrict__ dlogits, int64_t vocab,
+                                                         const int64_t* __restrict__ row_index) {
+    // row_index (nullable): compact form — workgroup r serves logits row row_index[r] (a masked position) and writes
+    // gradient row r of a [n_masked, vocab] buffer; mlm_mask / prev_mask are not consulted
     __shared__ float red[8];
     const int64_t r = blockIdx.x;
+    const int64_t src = row_index ? row_index[r] : r;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bf16* drow = dlogits + r * vocab;
-    if (!mlm_mask[r]) {
+    if (!row_index && !mlm_mask[r]) {
         if (threadIdx.x == 0 && row_loss) row_loss[r] = 0.f;
         if (prev_mask && !prev_mask[r]) return;   // still zero from before
         const bf16x8 z = {};
         for (int64_t c = (int64_t)threadIdx.x * 8; c < vocab; c += 256 * 8) *reinterpret_cast<bf16x8*>(drow + c) = z;
         return;
     }
-    const bf16* lrow = logits + r * vocab;
+    const bf16* lrow = logits + src * vocab;
     // pass 1: online max / sum-exp (per thread), then combine
     float m = -INFINITY, l = 0.f;
     for (int64_t c = (int64_t)threadIdx.x * 8; c < vocab; c += 256 * 8) {
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) void masked_ce_kernel(const bf16* __restrict__
     const float bm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const float bl = red[4] * __expf(red[0] - bm) + red[5] * __expf(red[1] - bm) + red[6] * __expf(red[2] - bm) + red[7] * __expf(red[3] - bm);
     const float lse = bm + __logf(bl);
-    int64_t tgt = target[r];
+    int64_t tgt = target[src];
     tgt = tgt < 0 ? 0 : (tgt >= vocab ? vocab - 1 : tgt);
     if (threadIdx.x == 0 && row_loss) row_loss[r] = (lse - bf2f(lrow[tgt])) * row_scale;
     // pass 2 (row is L2-resident): gradient
@@ -510,8 +514,20 @@ extern "C" int obte_masked_ce_fwd_bwd_reuse(const obte_bf16* logits, const int64
     OBTE_REQUIRE(logits && target && mlm_mask && grad_scale && dlogits, "obte_masked_ce_fwd_bwd: null pointer");
     OBTE_REQUIRE(rows > 0 && rows < (1ll << 31) && vocab > 0 && vocab % 8 == 0, "obte_masked_ce_fwd_bwd: vocab must be a multiple of 8");
     hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)s, (const bf16*)logits, target, mlm_mask,
-                       prev_mask, grad_scale, row_scale, row_loss, (bf16*)dlogits, vocab);
+                       prev_mask, grad_scale, row_scale, row_loss, (bf16*)dlogits, vocab, (const int64_t*)nullptr);
     OBTE_CHECK_LAUNCH("obte_masked_ce_fwd_bwd");
+    return OBTE_OK;
+}
+
+extern "C" int obte_masked_ce_rows(const obte_bf16* logits, const int64_t* target, const int64_t* row_index, const float* grad_scale,
+                                   float row_scale, float* row_loss, obte_bf16* dlogits_rows, int64_t n_rows, int64_t total_rows,
+                                   int64_t vocab, obte_stream s) {
+    OBTE_REQUIRE(logits && target && row_index && grad_scale && dlogits_rows && row_loss, "obte_masked_ce_rows: null pointer");
+    OBTE_REQUIRE(n_rows > 0 && n_rows <= total_rows && total_rows < (1ll << 31) && vocab > 0 && vocab % 8 == 0,
+                 "obte_masked_ce_rows: need 0 < n_rows <= total_rows and vocab %% 8 == 0");
+    hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)s, (const bf16*)logits, target,
+                       (const uint8_t*)nullptr, (const uint8_t*)nullptr, grad_scale, row_scale, row_loss, (bf16*)dlogits_rows, vocab, row_index);
+    OBTE_CHECK_LAUNCH("obte_masked_ce_rows");
     return OBTE_OK;
 }
 

@@ -174,6 +174,29 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw, None
 
 
+class _ReadoutRowsGradFn(torch.autograd.Function):
+    """Backward-only node of the readout for a loss that looks at a subset of the positions (the masked-LM loss:
+    train_encoder.py:301-305).  ``emb_rows`` [n, C] are the final embeddings of those positions, ``dlogits_rows`` [n, V]
+    the rows of d(loss)/d(logits) that are not exact zeros (ops.masked_ce_rows on the DENSE logits).  forward() returns a
+    zero scalar that stands for the loss in the graph; backward() contracts over the n rows only:
+    d emb_rows = alpha dlogits_rows W, dW = alpha dlogits_rows^T emb_rows — exactly what the dense products give, the
+    rows left out being all zero."""
+
+    @staticmethod
+    def forward(ctx, emb_rows, w, alpha, dlogits_rows):
+        ctx.save_for_backward(emb_rows, w, dlogits_rows)
+        ctx.alpha = alpha
+        ctx.w_param = w
+        return torch.zeros((), dtype=torch.float32, device=emb_rows.device)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        emb_rows, w, dl = ctx.saved_tensors
+        slot = _grad_slot(ctx.w_param)
+        dx, dw = ops.linear_bwd(dl, emb_rows.contiguous(), w, alpha=ctx.alpha, accumulate_into=slot)
+        return dx, dw, None, None
+
+
 class _EmbeddingFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, idx, wte, dropout_p, dropout_seed):

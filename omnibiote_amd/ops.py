@@ -169,7 +169,7 @@ def linear_bwd_pair_is_grouped(M, N, K) -> bool:
     if e in ("0", "1"):
         return e == "1" and M >= 128 and N >= 128
     td, tw = _tiles256(M, K), _tiles256(N, K)
-    if not (M >= 1024 and N >= 8 * M and td <= 160 and td % 8 == 0 and tw % 8 == 0 and tw >= 256):
+    if not (M >= 4096 and N >= 8 * M and 64 <= td <= 160 and td % 8 == 0 and tw % 8 == 0 and tw >= 256):   # (a few tiles of dgrad beside 1024 of wgrad: two launches with split-K are 2.5x faster)
         return False
     work_d, work_w = td * N, tw * M
     return 0.5 <= work_d / work_w <= 2.0
@@ -355,6 +355,22 @@ def masked_ce(logits, targets, mlm_mask, n_accum: int, reuse: Optional[DLogitsBu
         reuse.prev_mask = m8
     loss = row_loss.sum() * inv_count[0]
     return loss, dlogits
+
+
+def masked_ce_rows(logits, targets, rows, n_accum: int):
+    """The same loss on a compact list of masked positions: ``rows`` int64 (n,) ascending row indices into the dense
+    logits (viewed [M, V]).  Returns (loss, dlogits_rows bf16 [n, V]) — the rows of d(logits) that are not exact zeros."""
+    _need(logits, "logits"); _need(targets, "targets", torch.int64); _need(rows, "rows", torch.int64)
+    V = logits.shape[-1]
+    M = logits.numel() // V
+    n = rows.numel()
+    assert targets.numel() == M and 0 < n <= M
+    inv_count = torch.full((1,), 1.0 / n, dtype=torch.float32, device=logits.device)
+    row_loss = torch.empty(n, dtype=torch.float32, device=logits.device)
+    dl = torch.empty((n, V), dtype=bf16, device=logits.device)
+    L.check(L.lib().obte_masked_ce_rows(_ptr(logits), _ptr(targets), _ptr(rows), _ptr(inv_count), 1.0 / n_accum, _ptr(row_loss), _ptr(dl),
+                                        n, M, V, _stream()), "obte_masked_ce_rows")
+    return row_loss.sum() * inv_count[0], dl
 
 
 def adamw_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, clip_coef=None):

@@ -177,11 +177,15 @@ class TrainStep:
         self.loss_impl, self.mask_impl = loss_impl, mask_impl
         self.sync_every = sync_every_micro_step
         self.max_grad_norm = max_grad_norm
-        # "dense": logits for every position, as the reference computes them (train_encoder.py:296).
-        # "masked" (SURVEY.md §8f rank 1): the loss only looks at the ~15 % MLM-masked positions (loss *= mask, :304), so
-        # the readout and the cross entropy run on those rows alone — the same loss and gradients (rows outside the mask
-        # contribute exact zeros) for 1/6.7 of the lm_head work and none of the 1 GiB logits tensors.
-        assert lm_head_impl in ("dense", "masked")
+        # "dense" (default): the forward computes the logits of EVERY position, as the reference does (train_encoder.py:296);
+        #     the loss multiplies the unmasked ~85 % of the rows by zero (:304), so d(logits) has exact-zero rows there and
+        #     the readout's backward contracts over the masked rows only (ops.masked_ce_rows + model._ReadoutRowsGradFn):
+        #     same gradients, the zero rows simply are not multiplied.
+        # "dense_full": the same forward, and the backward through the dense [M, V] d(logits) tensor — the literal
+        #     translation of the reference's graph (logits.backward(dlogits)); kept for A/B and for callers of model(x).
+        # "masked" (SURVEY.md §8f rank 1): readout and cross entropy on the masked rows alone in the forward too — the
+        #     same loss and gradients for 1/6.7 of the lm_head work and none of the 1 GiB logits tensor.
+        assert lm_head_impl in ("dense", "dense_full", "masked")
         self.lm_head_impl = lm_head_impl
         self._dlogits = {}
         self._all_ranges = None
@@ -237,6 +241,29 @@ class TrainStep:
         if self._prev_bwd_done is not None:
             torch.cuda.current_stream().wait_event(self._prev_bwd_done)
 
+    def _dense_logits_sparse_backward(self, x, y, mk, attn_mask, n_accum):
+        """lm_head_impl="dense": full logits in the forward, backward over the masked rows (see __init__)."""
+        from . import ops
+        from .model import _ReadoutRowsGradFn
+        emb = self.model(x, attn_mask=attn_mask, return_embeddings=True)
+        core = self.model.module if hasattr(self.model, "module") else self.model
+        rows = self._mask_rows_host[self._mb]
+        with torch.no_grad():
+            logits = core.lm_head(emb)                     # (B, T, V): every position, as model.py:253 computes them
+            if rows.numel() == 0:
+                loss, dl = None, None
+            else:
+                loss, dl = ops.masked_ce_rows(logits, y.reshape(-1), rows, n_accum)
+        del logits
+        self._order_backward()
+        if dl is None:    # nothing masked: zero gradients for every parameter (the reference would produce 0/0 = NaN here)
+            (emb.sum() * 0 + core.lm_head.weight.sum() * 0).backward()
+            return torch.zeros((), dtype=torch.float32, device=x.device)
+        emb_rows = emb.reshape(-1, emb.shape[-1]).index_select(0, rows)
+        wm = float(core.lm_head.output_mult) / float(core.lm_head.width_mult())
+        _ReadoutRowsGradFn.apply(emb_rows, core.lm_head.weight, wm, dl).backward()
+        return loss.detach()
+
     def _masked_rows_loss_backward(self, x, y, mk, attn_mask, n_accum):
         """Readout + CE on the masked rows only.  The row indices come from the host-side MLM draw (no device sync)."""
         from . import ops
@@ -269,7 +296,8 @@ class TrainStep:
         else:
             mask = mlm_mask[:rows].to(input_ids.device) & (input_ids != PAD_TOKEN) & (input_ids != EOS_TOKEN)
             masked_ids = input_ids.masked_fill(mask, MASK_TOKEN)
-        if self.lm_head_impl == "masked":
+        sparse_rows = self.lm_head_impl == "masked" or (self.lm_head_impl == "dense" and self.loss_impl == "fused" and self.fused_loss_fn is None)
+        if sparse_rows:
             # per-micro-batch row indices of the masked positions; mlm_corrupt drew the mask on the host, but PAD/EOS
             # exclusions were applied on the device, so fetch the final mask once per optimizer step (one small D2H copy)
             mh = mask.reshape(rows // self.mini, -1).cpu()
@@ -314,6 +342,8 @@ class TrainStep:
                     mk = mask[j * self.mini:(j + 1) * self.mini]
                     if self.lm_head_impl == "masked":
                         partial[self._slot] += self._masked_rows_loss_backward(x, y, mk, attn_mask, n_accum)
+                    elif sparse_rows:
+                        partial[self._slot] += self._dense_logits_sparse_backward(x, y, mk, attn_mask, n_accum)
                     else:
                         logits = self.model(x, attn_mask=attn_mask)
                         partial[self._slot] += self._loss_backward(logits, y, mk, n_accum)

@@ -273,17 +273,37 @@ def test_inplace_gradient_accumulation_is_bitwise_autograd_accumulation(golden_d
         assert torch.equal(results[0][k], results[1][k]), k
 
 
-def test_masked_rows_lm_head_gives_the_dense_loss_and_gradients():
-    """readout + CE on the MLM-masked rows only must reproduce the dense path's loss and gradients
-    (rows outside the mask contribute exact zeros there)."""
+def test_readout_paths_match_the_oracle_loss_and_gradients():
+    """SURVEY §8f rank 1 and the default readout: the three ways the harness can run lm_head + masked CE —
+    "dense_full" (dense logits, dense d(logits): the reference's graph), "dense" (dense logits, backward over the masked
+    rows only) and "masked" (masked rows only in the forward too) — against the ORACLE: R.model_forward -> R.readout ->
+    R.masked_lm_loss in fp32 on the same bf16-valued weights, accumulated over the same micro-batches
+    (train_encoder.py:296-305).  Rows outside the mask contribute exact zeros, so all three must give the oracle's loss
+    and its gradient for every parameter (lm_head.weight and, through d emb, everything below)."""
     from omnibiote_amd import train_encoder as TE
+    from omnibiote_amd.masks import RangeMask
     from omnibiote_amd.mup_compat import set_base_shapes
     from omnibiote_amd.model import OmniBioTA, OmniBioTAConfig
     C, H, Lyr, V, T, rows, mini = 128, 2, 2, 512, 64, 8, 4
-    w = R.hash_weights(R.RefConfig(block_size=T, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C))
-    ids = torch.from_numpy(TE.synthetic_rows(rows, T, V, np.random.default_rng(0), single_document=False)).to(DEV)
-    out = {}
-    for impl in ("dense", "masked"):
+    cfg = R.RefConfig(block_size=T, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C)
+    w = R.hash_weights(cfg)
+    ids_cpu = torch.from_numpy(TE.synthetic_rows(rows, T, V, np.random.default_rng(0), single_document=False))
+    ids = ids_cpu.to(DEV)
+    mlm = torch.from_numpy(np.random.default_rng(5).random((rows, T)) < 0.15)
+    # oracle: two micro-batches of four rows, loss / n_accum, gradients summed (autograd accumulation)
+    wb = {k: v.to(BF).float().requires_grad_(True) for k, v in w.items()}
+    rope = R.cast_rope_table(R.rope_table(C // H, T), BF)
+    mask_eff = mlm & (ids_cpu != 1) & (ids_cpu != R.EOS_TOKEN)
+    masked_ids = ids_cpu.masked_fill(mask_eff, 2)
+    ref_loss = 0.0
+    for j in range(rows // mini):
+        sl = slice(j * mini, (j + 1) * mini)
+        dense = RangeMask.from_tokens(ids_cpu[sl]).dense(torch.float32).unsqueeze(1)
+        logits = R.model_forward(wb, cfg, masked_ids[sl], dense, rope=rope)
+        lj = R.masked_lm_loss(logits, ids_cpu[sl], mask_eff[sl], rows // mini)
+        lj.backward()
+        ref_loss += lj.item()
+    for impl in ("dense_full", "dense", "masked"):
         c = OmniBioTAConfig(); c.block_size, c.vocab_size, c.n_layer, c.n_head, c.n_embd, c.dropout, c.flash = T, V, Lyr, H, C, 0.0, True
         m = OmniBioTA(c)
         cb = OmniBioTAConfig(); cb.block_size, cb.vocab_size, cb.n_layer, cb.dropout, cb.flash = T, V, Lyr, 0.0, True
@@ -299,17 +319,16 @@ def test_masked_rows_lm_head_gives_the_dense_loss_and_gradients():
         m.to(DEV)
         opt = torch.optim.SGD(m.parameters(), lr=0.0)
         step = TE.TrainStep(m, opt, None, mini_batch_size=mini, n_head=H, lm_head_impl=impl, max_grad_norm=1e9)
-        np.random.seed(5)
-        loss = step(ids)["loss"].item()
-        out[impl] = (loss, {k: p.grad.float().clone() for k, p in m.named_parameters()})
-    assert abs(out["dense"][0] - out["masked"][0]) <= 1e-3 * abs(out["dense"][0])
-    for k in out["dense"][1]:
-        a, b = out["dense"][1][k].flatten(), out["masked"][1][k].flatten()
-        rel = (a - b).norm().item() / (a.norm().item() + 1e-12)
-        assert rel <= 0.02, (k, rel)
+        loss = step(ids, mlm_mask=mlm.to(DEV))["loss"].item()
+        assert abs(loss - ref_loss) <= 0.02, (impl, loss, ref_loss)
+        for k, p in m.named_parameters():
+            got, want = p.grad.float().cpu().flatten(), wb[k].grad.flatten()
+            rel = (got - want).norm().item() / (want.norm().item() + 1e-12)
+            cos = torch.dot(got, want).item() / (got.norm().item() * want.norm().item() + 1e-30)
+            assert rel <= 0.05 and cos >= 0.998, (impl, k, rel, cos)
 
 
-@pytest.mark.parametrize("impl", ["dense", "masked"])
+@pytest.mark.parametrize("impl", ["dense", "dense_full", "masked"])
 def test_two_stream_micro_batch_pipeline_is_bitwise_the_single_stream_step(impl):
     """TrainStep(pipeline_streams=2) overlaps the forward of micro-batch j+1 with the backward of micro-batch j on a
     second stream but keeps the backward passes ordered: loss, gradients and updated weights must equal the
