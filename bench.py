@@ -271,9 +271,16 @@ def main():
     if a.gpus != world:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; drop WORLD_SIZE (bench.py then starts its own ranks) or "
                          f"launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    # OBTE_BENCH_REHEARSE=1: every rank on cuda:0 over gloo — rehearses the N > 1 control flow (collective order, DDP, the
+    # per-rank variants) on a one-GPU box, where RCCL refuses two ranks on one device.  The numbers it prints mean nothing.
+    rehearse = os.environ.get("OBTE_BENCH_REHEARSE") == "1" and world > 1
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 and rehearse:
+        dist.init_process_group("gloo")
+    elif world > 1:
         dist.init_process_group("nccl", device_id=dev)   # RCCL; device_id binds the communicator to this rank's GPU up front
     from omnibiote_amd import _lib
     from omnibiote_amd import train_encoder as TE
@@ -342,17 +349,20 @@ def main():
 
     log(f"timed region done: {value:,.0f} tokens/s")
     roofline = None
-    if not a.no_roofline and rank == 0:
+    if not a.no_roofline:
         # per-launch durations are only meaningful when launches do not share the chip: the profiled step runs on one
-        # stream (the timed steps above overlap two micro-batches, which stretches every kernel that has company)
+        # stream (the timed steps above overlap two micro-batches, which stretches every kernel that has company).
+        # EVERY rank runs this step (it contains the gradient all-reduce); only rank 0 records and reports.
         step.pipeline_streams = 1
-        _lib.lib().obte_profile_enable(1)
+        if rank == 0:
+            _lib.lib().obte_profile_enable(1)
         step(batches[0])
         torch.cuda.synchronize()
-        ms, dims, kind = collect_profile()
-        _lib.lib().obte_profile_enable(0)
+        ms, dims, kind = collect_profile() if rank == 0 else ([], [], [])
+        if rank == 0:
+            _lib.lib().obte_profile_enable(0)
         step.pipeline_streams = a.pipeline_streams
-        if len(ms):
+        if rank == 0 and len(ms):
             roofline = roofline_from_profile(ms, dims, kind, 1)
             # HBM bytes per launch of the GEMM family: PMC counters cannot be read from inside this process, so the
             # figure comes from the committed rocprofv3 --pmc passes over this same workload (tools/pmc_traffic.py)
@@ -433,7 +443,7 @@ def main():
         out = {
             "metric": METRIC if a.config == "small" else f"MLM train tokens/sec, {a.config} ctx={T}", "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU over gloo; not a measurement)",
             "config": {"workload": f"OmniBioTA {a.config} ({cfg['n_layer']}L/{cfg['n_embd']}d/{cfg['n_head']}h) ctx={T} MLM train step: "
                                    f"{a.rows_per_rank} rows/rank = {a.rows_per_rank // a.mini_batch_size} micro-batches of {a.mini_batch_size}, "
                                    f"{READOUT_TEXT[a.readout]}, dropout {a.dropout:g}, {'multi' if a.multi_document else 'single'}-document rows",

@@ -693,7 +693,8 @@ using namespace obte_gemm_v2;
 struct Plan { int bn; int splits; int variant; };   // variant: 1 = first structure (gemm_bf16_v1.hip), 2 / 3 = this file (K-tile ring / half-tile ring)
 static int splits_for(int64_t tiles, int64_t nk) {
     if (tiles >= 200 || nk < 16) return 1;
-    int s = (int)((256 + tiles - 1) / tiles);
+    int s = (int)(256 / tiles);   // the largest split whose tiles * s workgroups still fit ONE round of the 256 CUs (rounding up instead
+                                  // put e.g. 20 tiles x 13 = 260 workgroups into two rounds: the readout's row-compact input gradient)
     while (s > 1 && nk / s < 8) --s;
     return s < 1 ? 1 : (s > 16 ? 16 : s);
 }

@@ -3,10 +3,11 @@
 // so each element is read once and written once.  Algorithmic bytes per row: fwd 4*C (2 read + 2 written),
 // bwd 8*C (dy, x, [dresid] read; dx written) + the dw partials.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int LN_BWD_MAX_BLOCKS = 512;
+constexpr int LN_BWD_MAX_BLOCKS = 1024;   // 4 workgroups of 4 waves per CU: ~48 KB of row loads in flight per CU (512 left the HBM pipe half empty)
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
@@ -78,7 +79,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
         float xh[NCH][8], g[NCH][8];
+        bf16x8 res[NCH];   // the residual gradient is fetched together with x and dy: behind the two reductions its latency was exposed once per row
         float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 8;
+            res[i] = bf16x8{};
+            if (HAS_RESID && c < cols) res[i] = *reinterpret_cast<const bf16x8*>(dresid + row * cols + c);
+        }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = (lane + 64 * i) * 8;
@@ -106,12 +114,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
             const int c = (lane + 64 * i) * 8;
             if (c < cols) {
                 bf16x8 o;
-                bf16x8 r = {};
-                if (HAS_RESID) r = *reinterpret_cast<const bf16x8*>(dresid + row * cols + c);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float d = rs * (g[i][j] - s1 - xh[i][j] * s2);
-                    if (HAS_RESID) d += bf2f(r[j]);
+                    if (HAS_RESID) d += bf2f(res[i][j]);
                     o[j] = f2bf(d);
                 }
                 *reinterpret_cast<bf16x8*>(dx + row * cols + c) = o;
@@ -202,7 +208,13 @@ extern "C" int obte_layernorm_bwd_acc(const obte_bf16* dy, const obte_bf16* x, c
                                       int64_t rows, int cols, int accumulate_dw, obte_stream s) {
     OBTE_REQUIRE(dy && x && w && mean && rstd && dx && dw && ws, "obte_layernorm_bwd: null pointer");
     OBTE_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 4096, "obte_layernorm_bwd: bad shape rows=%lld cols=%d", (long long)rows, cols);
-    const int nblk = (int)(cdiv64(rows, 4) < LN_BWD_MAX_BLOCKS ? cdiv64(rows, 4) : LN_BWD_MAX_BLOCKS);
+    static int blocks_cap = 0;
+    if (!blocks_cap) {
+        const char* e = getenv("OBTE_LN_BLOCKS");   // timing experiments; the workspace admits up to LN_BWD_MAX_BLOCKS
+        blocks_cap = e ? atoi(e) : 512;
+        if (blocks_cap < 1 || blocks_cap > LN_BWD_MAX_BLOCKS) blocks_cap = 512;
+    }
+    const int nblk = (int)(cdiv64(rows, 4) < blocks_cap ? cdiv64(rows, 4) : blocks_cap);
     const dim3 grid(nblk), block(256);
     const size_t smem = (size_t)4 * cols * sizeof(float);
     hipStream_t st = (hipStream_t)s;
