@@ -60,6 +60,18 @@ int obte_layernorm_bwd_acc(const obte_bf16* dy, const obte_bf16* x, const obte_b
                        const float* rstd, const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dw, float* ws,
                        int64_t rows, int cols, int accumulate_dw, obte_stream s);
 
+/* Weight gradient accumulated over several calls in fp32 (gradient accumulation over micro-batches, train_encoder.py:284-311):
+ * `partials` is a caller-owned fp32 [obte_layernorm_bwd_ws_rows(), cols] buffer that persists between the calls.
+ *   OBTE_LN_PARTIAL_FIRST  partials  = this call's per-workgroup sums (unused rows zeroed); dw untouched (may be NULL)
+ *   OBTE_LN_PARTIAL_MORE   partials += this call's sums; dw untouched (may be NULL)
+ *   OBTE_LN_PARTIAL_LAST   partials += this call's sums, then dw = bf16(sum of all partial rows)  (overwrites dw)
+ * One reduction launch per optimizer step instead of one per micro-batch, and the sum over micro-batches is formed in fp32
+ * (autograd's `grad += new` rounds to bf16 after every micro-batch).  dx as in obte_layernorm_bwd. */
+enum { OBTE_LN_PARTIAL_FIRST = 1, OBTE_LN_PARTIAL_MORE = 2, OBTE_LN_PARTIAL_LAST = 3 };
+int obte_layernorm_bwd_partial(const obte_bf16* dy, const obte_bf16* x, const obte_bf16* w, const float* mean,
+                               const float* rstd, const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dw, float* partials,
+                               int64_t rows, int cols, int mode, obte_stream s);
+
 /* ---- bf16 GEMM on MFMA, fp32 accumulate (nn.Linear fwd/dgrad/wgrad: training/model.py:102,151,163,166,253)
  * D[M,N] = epilogue(alpha * sum_k A(m,k) * B(n,k)).
  *   a_kmajor=1: A(m,k) = a[m*lda + k]   (k contiguous)      a_kmajor=0: A(m,k) = a[k*lda + m]
@@ -262,6 +274,10 @@ typedef struct {
     const int32_t* key_ranges; const obte_bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
     float dropout_p; uint64_t dropout_seed;   /* one seed per block call; sites 1-3 derive from it.  p = 0: no dropout */
     const int32_t* query_bounds;              /* nullable: obte_mask_bounds output for a dense mask (backward only) */
+    /* backward only, optional: the two LayerNorm weight gradients accumulated over micro-batches in caller-owned fp32
+     * partial buffers (see obte_layernorm_bwd_partial); ln_partial_mode 0 = off, else OBTE_LN_PARTIAL_*.  With FIRST / MORE
+     * dln1_w / dln2_w are not written. */
+    float *ln1_partials, *ln2_partials; int32_t ln_partial_mode;
 } obte_block_desc;
 int64_t obte_block_act_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head);
 int64_t obte_block_bwd_ws_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head);

@@ -49,9 +49,11 @@ class BlockDesc(C.Structure):
                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
                 ("key_ranges", C.c_void_p), ("mask", C.c_void_p),
                 ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
-                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("query_bounds", C.c_void_p)]
+                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("query_bounds", C.c_void_p),
+                ("ln1_partials", C.c_void_p), ("ln2_partials", C.c_void_p), ("ln_partial_mode", C.c_int32)]
 
 
+LN_PARTIAL_FIRST, LN_PARTIAL_MORE, LN_PARTIAL_LAST = 1, 2, 3
 MT_MAX = 32
 
 
@@ -75,6 +77,7 @@ SYMBOLS = {
     "obte_layernorm_bwd_ws_rows": (C.c_int, []),
     "obte_layernorm_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, c_stream]),
     "obte_layernorm_bwd_acc": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, C.c_int, c_stream]),
+    "obte_layernorm_bwd_partial": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, C.c_int, c_stream]),
     "obte_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), c_stream]),
     "obte_gemm_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "obte_gemm_bf16_ws": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_int64, c_stream]),

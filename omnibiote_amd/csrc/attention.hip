@@ -494,16 +494,49 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bw
         const char* Kt = smem + cur * 2 * TB;
         const char* Vt = Kt + TB;
         const int key0 = t * 64;
-        // the 64-key tile is processed as two 32-key halves so that only one score/dP accumulator pair is live
+        // the 64-key tile is processed as two 32-key halves so that only one score/dP accumulator pair is live.
+        // Fragment reads are issued TWO k-steps (four fragments) ahead of the MFMAs that consume them and pinned there with
+        // sched_barrier: left alone hipcc sinks every ds_read to just before its first use, and the loop then runs
+        // read -> wait a full LDS latency -> MFMA, one fragment at a time (the waves were parked on lgkmcnt 37 % of the time).
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             f32x16 sc, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+            constexpr bool PIN = MODE != MASK_DENSE && !DROP;   // the dense-mask and dropout variants have no registers to spare for it
+            bf16x8 tk[2][ND];
+            if constexpr (PIN) {
+                bf16x8 ka[2][2], va[2][2];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 32 * mt, s, lane), qf[s], sc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vt, 32 * mt, s, lane), dof[s], dp, 0, 0, 0);
+                for (int u = 0; u < 2; ++u) { ka[0][u] = row_frag<D>(Kt, 32 * mt, u, lane); va[0][u] = row_frag<D>(Vt, 32 * mt, u, lane); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pp = 0; pp < NS / 2; ++pp) {
+                    if (pp + 1 < NS / 2) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            ka[(pp + 1) & 1][u] = row_frag<D>(Kt, 32 * mt, 2 * pp + 2 + u, lane);
+                            va[(pp + 1) & 1][u] = row_frag<D>(Vt, 32 * mt, 2 * pp + 2 + u, lane);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[pp & 1][u], qf[2 * pp + u], sc, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[pp & 1][u], dof[2 * pp + u], dp, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // the transposed K fragments of the first dQ k-step are fetched under the softmax arithmetic
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) tk[0][dt] = tr_frag<D>(Kt, 32 * mt, dt, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 32 * mt, s, lane), qf[s], sc, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vt, 32 * mt, s, lane), dof[s], dp, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -525,12 +558,27 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bw
                     sc[r] = pv * (dpd - dl);   // dS^T (without the scale factor)
                 }
             }
+            if constexpr (PIN) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8 dsf = pack8(sc, 8 * kk);
+                for (int dt = 0; dt < ND; ++dt) tk[1][dt] = tr_frag<D>(Kt, 32 * mt + 16, dt, lane);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int dt = 0; dt < ND; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Kt, 32 * mt + 16 * kk, dt, lane), dsf, dq[dt], 0, 0, 0);
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 dsf = pack8(sc, 8 * kk);
+#pragma unroll
+                    for (int dt = 0; dt < ND; ++dt)
+                        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tk[kk][dt], dsf, dq[dt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 dsf = pack8(sc, 8 * kk);
+#pragma unroll
+                    for (int dt = 0; dt < ND; ++dt)
+                        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Kt, 32 * mt + 16 * kk, dt, lane), dsf, dq[dt], 0, 0, 0);
+                }
             }
         }
         dma_wait_all();

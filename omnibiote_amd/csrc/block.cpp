@@ -192,7 +192,11 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     if (!grouped) TRY(gemm(dy_mlp, hact, dmlp_w, C, 4 * C, M, C, 4 * C, 0, 0, wepi, accumulate_matrices ? dmlp_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_mlp = dy^T hact
     TRY(gemm(dhpre, d->fc_w, dh, M, C, 4 * C, 4 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh2 = dhpre W_fc
     if (!grouped) TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, M, 4 * C, C, 0, 0, wepi, accumulate_matrices ? dfc_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_fc = dhpre^T h2
-    TRY(obte_layernorm_bwd_acc(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, lnws, M, C, acc_ln, s));                     // dx1 = dy + LN2'(dh2)
+    const int lnp = d->ln_partial_mode;
+    if (lnp) OBTE_REQUIRE(d->ln1_partials && d->ln2_partials && lnp >= OBTE_LN_PARTIAL_FIRST && lnp <= OBTE_LN_PARTIAL_LAST,
+                          "obte_block_bwd: ln_partial_mode needs both partial buffers and a valid mode");
+    if (lnp) TRY(obte_layernorm_bwd_partial(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, d->ln2_partials, M, C, lnp, s));
+    else TRY(obte_layernorm_bwd_acc(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, lnws, M, C, acc_ln, s));                     // dx1 = dy + LN2'(dh2)
     // attention: x1 = x + dropout(y W_proj^T)
     const obte_bf16* dx1_proj = dx1;
     if (drop) {
@@ -232,6 +236,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
         gs[4].epilogue = OBTE_EPI_NONE; gs[4].alpha = 1.0f;
         TRY(obte_gemm_grouped_bf16(gs, group_dgrad ? 5 : 4, s));
     }
-    TRY(obte_layernorm_bwd_acc(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, lnws, M, C, acc_ln, s));                      // dx = dx1 + LN1'(dh1)
+    if (lnp) TRY(obte_layernorm_bwd_partial(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, d->ln1_partials, M, C, lnp, s));
+    else TRY(obte_layernorm_bwd_acc(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, lnws, M, C, acc_ln, s));                      // dx = dx1 + LN1'(dh1)
     return OBTE_OK;
 }

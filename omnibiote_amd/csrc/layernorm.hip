@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int LN_BWD_MAX_BLOCKS = 1024;   // 4 workgroups of 4 waves per CU: ~48 KB of row loads in flight per CU (512 left the HBM pipe half empty)
+constexpr int LN_BWD_MAX_BLOCKS = 512;   // measured at 8192 x 1024: 256 / 384 / 512 / 768 / 1024 workgroups -> 24.5 / 23.4 / 22.9 / 25.3 / 28.1 us (backward + dw reduce)
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
@@ -62,7 +62,7 @@ template <int NCH, bool HAS_RESID>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                       const bf16* __restrict__ w, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const bf16* __restrict__ dresid,
-                                                      bf16* __restrict__ dx, float* __restrict__ ws, int64_t rows, int cols) {
+                                                      bf16* __restrict__ dx, float* __restrict__ ws, int64_t rows, int cols, int ws_accumulate) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = reinterpret_cast<float*>(smem_raw);  // [4][cols]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -133,8 +133,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < cols; c += 256)
-        ws[(int64_t)blockIdx.x * cols + c] = red[c] + red[cols + c] + red[2 * cols + c] + red[3 * cols + c];
+    // ws_accumulate: the partial row of this workgroup carries over from earlier calls (gradient accumulation over
+    // micro-batches in fp32: one thread owns one address, the order of the additions is the order of the calls)
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float t = red[c] + red[cols + c] + red[2 * cols + c] + red[3 * cols + c];
+        float* dst = ws + (int64_t)blockIdx.x * cols + c;
+        *dst = ws_accumulate ? *dst + t : t;
+    }
 }
 
 // dw[c] = sum over the per-workgroup partial rows; 32 columns x 8 row-groups per workgroup, 128-B row segments.
@@ -203,10 +208,10 @@ extern "C" int obte_layernorm_bwd(const obte_bf16* dy, const obte_bf16* x, const
     return obte_layernorm_bwd_acc(dy, x, w, mean, rstd, dresid, dx, dw, ws, rows, cols, 0, s);
 }
 
-extern "C" int obte_layernorm_bwd_acc(const obte_bf16* dy, const obte_bf16* x, const obte_bf16* w, const float* mean,
-                                      const float* rstd, const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dw, float* ws,
-                                      int64_t rows, int cols, int accumulate_dw, obte_stream s) {
-    OBTE_REQUIRE(dy && x && w && mean && rstd && dx && dw && ws, "obte_layernorm_bwd: null pointer");
+static int ln_bwd_impl(const obte_bf16* dy, const obte_bf16* x, const obte_bf16* w, const float* mean, const float* rstd,
+                       const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dw, float* ws, int64_t rows, int cols, int accumulate_dw,
+                       int ws_acc, bool reduce, bool clear_tail, obte_stream s) {
+    OBTE_REQUIRE(dy && x && w && mean && rstd && dx && ws && (dw || !reduce), "obte_layernorm_bwd: null pointer");
     OBTE_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 4096, "obte_layernorm_bwd: bad shape rows=%lld cols=%d", (long long)rows, cols);
     static int blocks_cap = 0;
     if (!blocks_cap) {
@@ -218,14 +223,19 @@ extern "C" int obte_layernorm_bwd_acc(const obte_bf16* dy, const obte_bf16* x, c
     const dim3 grid(nblk), block(256);
     const size_t smem = (size_t)4 * cols * sizeof(float);
     hipStream_t st = (hipStream_t)s;
+    if (clear_tail && nblk < LN_BWD_MAX_BLOCKS &&
+        hipMemsetAsync(ws + (size_t)nblk * cols, 0, (size_t)(LN_BWD_MAX_BLOCKS - nblk) * cols * sizeof(float), st) != hipSuccess) {
+        obte_set_error("obte_layernorm_bwd_partial: memset failed");
+        return OBTE_ELAUNCH;
+    }
 #define LN_BWD(N)                                                                                                           \
     do {                                                                                                                    \
         if (dresid)                                                                                                         \
             hipLaunchKernelGGL((ln_bwd_kernel<N, true>), grid, block, smem, st, (const bf16*)dy, (const bf16*)x, (const bf16*)w, \
-                               mean, rstd, (const bf16*)dresid, (bf16*)dx, ws, rows, cols);                                 \
+                               mean, rstd, (const bf16*)dresid, (bf16*)dx, ws, rows, cols, ws_acc);                         \
         else                                                                                                                \
             hipLaunchKernelGGL((ln_bwd_kernel<N, false>), grid, block, smem, st, (const bf16*)dy, (const bf16*)x, (const bf16*)w, \
-                               mean, rstd, (const bf16*)nullptr, (bf16*)dx, ws, rows, cols);                                \
+                               mean, rstd, (const bf16*)nullptr, (bf16*)dx, ws, rows, cols, ws_acc);                        \
     } while (0)
     switch (nch_for(cols)) {
         case 1: LN_BWD(1); break;
@@ -236,7 +246,25 @@ extern "C" int obte_layernorm_bwd_acc(const obte_bf16* dy, const obte_bf16* x, c
     }
 #undef LN_BWD
     OBTE_CHECK_LAUNCH("obte_layernorm_bwd");
-    hipLaunchKernelGGL(ln_dw_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, (const float*)ws, (bf16*)dw, nblk, cols, accumulate_dw);
-    OBTE_CHECK_LAUNCH("obte_layernorm_bwd(dw reduce)");
+    if (reduce) {
+        // a carried-over workspace is summed over ALL its rows (workgroups of earlier calls may have used more of them)
+        hipLaunchKernelGGL(ln_dw_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, (const float*)ws, (bf16*)dw,
+                           ws_acc || clear_tail ? LN_BWD_MAX_BLOCKS : nblk, cols, accumulate_dw);
+        OBTE_CHECK_LAUNCH("obte_layernorm_bwd(dw reduce)");
+    }
     return OBTE_OK;
+}
+
+extern "C" int obte_layernorm_bwd_acc(const obte_bf16* dy, const obte_bf16* x, const obte_bf16* w, const float* mean,
+                                      const float* rstd, const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dw, float* ws,
+                                      int64_t rows, int cols, int accumulate_dw, obte_stream s) {
+    return ln_bwd_impl(dy, x, w, mean, rstd, dresid, dx, dw, ws, rows, cols, accumulate_dw, 0, true, false, s);
+}
+
+extern "C" int obte_layernorm_bwd_partial(const obte_bf16* dy, const obte_bf16* x, const obte_bf16* w, const float* mean,
+                                          const float* rstd, const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dw, float* partials,
+                                          int64_t rows, int cols, int mode, obte_stream s) {
+    OBTE_REQUIRE(mode >= OBTE_LN_PARTIAL_FIRST && mode <= OBTE_LN_PARTIAL_LAST, "obte_layernorm_bwd_partial: bad mode %d", mode);
+    return ln_bwd_impl(dy, x, w, mean, rstd, dresid, dx, dw, partials, rows, cols, 0, mode != OBTE_LN_PARTIAL_FIRST,
+                       mode == OBTE_LN_PARTIAL_LAST, mode == OBTE_LN_PARTIAL_FIRST, s);
 }

@@ -97,22 +97,39 @@ def _require_hip(t: torch.Tensor, what: str) -> None:
 # (bf16(old + bf16(new))).  Only valid while nothing needs to observe per-micro-batch gradients: the harness sets it for
 # the micro-batches that run under DDP's no_sync(), never for the last one (whose AccumulateGrad hooks feed the reducer).
 _ACCUMULATE_INPLACE = False
+# LayerNorm weight gradients over micro-batches: instead of one reduction launch + one bf16 `grad += new` per LayerNorm
+# and micro-batch (17 LayerNorms x 16 micro-batches on the small config), the per-workgroup partial sums are carried in a
+# persistent fp32 buffer per weight (L.LN_PARTIAL_FIRST on the first such micro-batch, _MORE after it) and reduced ONCE,
+# by the micro-batch that runs with L.LN_PARTIAL_LAST and hands the total to autograd.  0 = off.  The total is
+# bf16(sum in fp32) — closer to the exact gradient than autograd's running bf16 sum, and not bitwise equal to it.
+_LN_PARTIAL_MODE = 0
 
 
 class accumulate_grads_inplace:
-    def __init__(self, enabled: bool = True):
+    def __init__(self, enabled: bool = True, ln_partial_mode: int = 0):
         self.enabled = enabled
+        self.ln_mode = ln_partial_mode
 
     def __enter__(self):
-        global _ACCUMULATE_INPLACE
-        self.prev = _ACCUMULATE_INPLACE
+        global _ACCUMULATE_INPLACE, _LN_PARTIAL_MODE
+        self.prev = (_ACCUMULATE_INPLACE, _LN_PARTIAL_MODE)
         _ACCUMULATE_INPLACE = self.enabled
+        _LN_PARTIAL_MODE = self.ln_mode
         return self
 
     def __exit__(self, *exc):
-        global _ACCUMULATE_INPLACE
-        _ACCUMULATE_INPLACE = self.prev
+        global _ACCUMULATE_INPLACE, _LN_PARTIAL_MODE
+        _ACCUMULATE_INPLACE, _LN_PARTIAL_MODE = self.prev
         return False
+
+
+def _ln_partials(param):
+    """The persistent fp32 partial-sum buffer of a LayerNorm weight (created on first use, lives with the parameter)."""
+    buf = getattr(param, "_obte_ln_partials", None)
+    if buf is None or buf.device != param.device or buf.numel() != L.lib().obte_layernorm_bwd_ws_rows() * param.numel():
+        buf = ops.ln_partials_buffer(param.numel(), param.device)
+        param._obte_ln_partials = buf
+    return buf
 
 
 def _grad_slot(param):
@@ -139,6 +156,10 @@ class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, mean, rstd = ctx.saved_tensors
+        if _LN_PARTIAL_MODE:
+            dx, dw = ops.layernorm_bwd(dy.contiguous(), x.contiguous(), w, mean, rstd, partials=_ln_partials(ctx.w_param),
+                                       partial_mode=_LN_PARTIAL_MODE)
+            return dx, dw
         dx, dw = ops.layernorm_bwd(dy.contiguous(), x.contiguous(), w, mean, rstd, accumulate_into=_grad_slot(ctx.w_param))
         return dx, dw
 
@@ -199,18 +220,19 @@ class _ReadoutRowsGradFn(torch.autograd.Function):
 
 class _EmbeddingFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, idx, wte, dropout_p, dropout_seed):
+    def forward(ctx, idx, wte, dropout_p, dropout_seed, order):
         ctx.save_for_backward(idx)
         ctx.vocab = wte.shape[0]
         ctx.w_param = wte
         ctx.drop = (dropout_p, dropout_seed)
+        ctx.order = order   # optional: a stable argsort of idx.reshape(-1) (int32) the caller already has
         return ops.embedding_fwd(idx.contiguous(), wte, dropout_p, dropout_seed)
 
     @staticmethod
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
         return None, ops.embedding_bwd(idx.contiguous(), dout.contiguous(), ctx.vocab, accumulate_into=_grad_slot(ctx.w_param),
-                                       dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1]), None, None
+                                       dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1], order=ctx.order), None, None, None
 
 
 class _BlockFn(torch.autograd.Function):
@@ -231,8 +253,10 @@ class _BlockFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, act, rope_cos, rope_sin, *params = ctx.saved_tensors
         slots = [_grad_slot(w) for w in ctx.w_params]
+        lnp = (_ln_partials(ctx.w_params[0]), _ln_partials(ctx.w_params[3])) if _LN_PARTIAL_MODE else None
         dx, grads = ops.block_bwd(x, dy.contiguous(), act, tuple(params), (rope_cos, rope_sin), ctx.n_head, ctx.mask,
-                                  accumulate_into=slots, dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1])
+                                  accumulate_into=slots, dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1], ln_partials=lnp,
+                                  ln_partial_mode=_LN_PARTIAL_MODE)
         return (dx, *grads, None, None, None, None, None, None)
 
 
@@ -453,7 +477,13 @@ class OmniBioTA(nn.Module):
         b = idx.shape[0]
         mask = ops.MaskSpec.from_user(attn_mask, b, t, self.config.n_head, idx.device)
         p = _active_p(self, self.transformer.drop.p)
-        x = _EmbeddingFn.apply(idx, wte, p, _new_seed() if p > 0 else 0)
+        # a training harness that sorts the token ids of a whole optimizer step in one call (the embedding backward sums
+        # gradient rows in sorted-id order) leaves this micro-batch's order here; consumed once
+        order = getattr(self, "_embedding_order", None)
+        self._embedding_order = None
+        if order is not None and (order.numel() != idx.numel() or order.dtype != torch.int32 or order.device != idx.device):
+            order = None
+        x = _EmbeddingFn.apply(idx, wte, p, _new_seed() if p > 0 else 0, order)
         for i, block in enumerate(self.transformer.h):
             if self.config.checkpoint_freq > 0 and i % self.config.checkpoint_freq == 0:
                 x = checkpoint(block, x, mask, use_reentrant=False)

@@ -50,8 +50,15 @@ def layernorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float = 1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dresid=None, accumulate_into=None):
-    """accumulate_into: an existing bf16 weight gradient to add into in place (then the returned dw is None)."""
+def ln_partials_buffer(cols: int, device) -> torch.Tensor:
+    """A persistent fp32 partial-sum buffer for obte_layernorm_bwd_partial (one per LayerNorm weight)."""
+    return torch.empty(L.lib().obte_layernorm_bwd_ws_rows() * cols, dtype=torch.float32, device=device)
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dresid=None, accumulate_into=None, partials=None, partial_mode=0):
+    """accumulate_into: an existing bf16 weight gradient to add into in place (then the returned dw is None).
+    partials + partial_mode (L.LN_PARTIAL_*): accumulate the weight gradient over calls in the caller's fp32 buffer; dw is
+    returned only by LN_PARTIAL_LAST (None otherwise)."""
     _need(dy, "dy"); _need(x, "x"); _need(w, "weight")
     _need(mean, "mean", torch.float32); _need(rstd, "rstd", torch.float32)
     cols = x.shape[-1]
@@ -60,6 +67,13 @@ def layernorm_bwd(dy, x, w, mean, rstd, dresid=None, accumulate_into=None):
     if dresid is not None:
         _need(dresid, "dresid"); assert dresid.shape == x.shape
     dx = torch.empty_like(x)
+    if partial_mode:
+        _need(partials, "partials", torch.float32)
+        assert accumulate_into is None and partials.numel() == L.lib().obte_layernorm_bwd_ws_rows() * cols
+        dw = torch.empty_like(w) if partial_mode == L.LN_PARTIAL_LAST else None
+        L.check(L.lib().obte_layernorm_bwd_partial(_ptr(dy), _ptr(x), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dresid), _ptr(dx), _ptr(dw),
+                                                    _ptr(partials), rows, cols, int(partial_mode), _stream()), "obte_layernorm_bwd_partial")
+        return dx, dw
     if accumulate_into is not None:
         _need(accumulate_into, "grad"); assert accumulate_into.shape == w.shape
     dw = accumulate_into if accumulate_into is not None else torch.empty_like(w)
@@ -298,13 +312,17 @@ def embedding_fwd(idx, wte, dropout_p=0.0, dropout_seed=0):
     return out
 
 
-def embedding_bwd(idx, dout, vocab, accumulate_into=None, dropout_p=0.0, dropout_seed=0):
+def embedding_bwd(idx, dout, vocab, accumulate_into=None, dropout_p=0.0, dropout_seed=0, order=None):
     """accumulate_into: an existing dense (vocab, C) gradient; the touched rows are updated in place
-    (bf16(old + bf16(sum))), nothing else is read or written."""
+    (bf16(old + bf16(sum))), nothing else is read or written.  order: a stable argsort of idx.reshape(-1) as int32, if
+    the caller has one already (the harness sorts a whole optimizer step's ids in one call)."""
     _need(idx, "idx", torch.int64); _need(dout, "dout")
     rows, Cc = idx.numel(), dout.shape[-1]
-    # the order is plumbing (a stable sort of <= a few 10k token ids); the summation itself is ours
-    order = torch.sort(idx.reshape(-1), stable=True).indices.to(torch.int32)
+    if order is None:
+        # the order is plumbing (a stable sort of <= a few 10k token ids); the summation itself is ours
+        order = torch.sort(idx.reshape(-1), stable=True).indices.to(torch.int32)
+    else:
+        _need(order, "order", torch.int32); assert order.numel() == rows
     ws = torch.empty(max(int(L.lib().obte_embedding_bwd_ws_bytes(rows, Cc)), 16), dtype=torch.uint8, device=dout.device)
     if accumulate_into is not None:
         _need(accumulate_into, "grad"); assert tuple(accumulate_into.shape) == (vocab, Cc)
@@ -387,11 +405,12 @@ def sumsq_(g, out):
 
 
 # -------------------------------------------------------------------------------------------------------- block
-def _block_desc(B, T, Cc, H, params, rope, mask: MaskSpec, dropout_p=0.0, dropout_seed=0):
+def _block_desc(B, T, Cc, H, params, rope, mask: MaskSpec, dropout_p=0.0, dropout_seed=0, ln_partials=None, ln_partial_mode=0):
     ln1, attn_w, proj_w, ln2, fc_w, mlp_w = params
+    p1, p2 = ln_partials if ln_partials is not None else (None, None)
     return L.BlockDesc(B, T, Cc, H, _ptr(ln1), _ptr(attn_w), _ptr(proj_w), _ptr(ln2), _ptr(fc_w), _ptr(mlp_w),
                        _ptr(rope[0]), _ptr(rope[1]), _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq,
-                       float(dropout_p), int(dropout_seed), _ptr(mask.qbounds))
+                       float(dropout_p), int(dropout_seed), _ptr(mask.qbounds), _ptr(p1), _ptr(p2), int(ln_partial_mode))
 
 
 def block_fwd(x, params, rope, H, mask: MaskSpec, dropout_p=0.0, dropout_seed=0):
@@ -409,16 +428,23 @@ def block_fwd(x, params, rope, H, mask: MaskSpec, dropout_p=0.0, dropout_seed=0)
     return y, act
 
 
-def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec, accumulate_into=None, dropout_p=0.0, dropout_seed=0):
+def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec, accumulate_into=None, dropout_p=0.0, dropout_seed=0, ln_partials=None,
+              ln_partial_mode=0):
     """accumulate_into: optional list of 6 tensors-or-None (same order as params).  When the four matrix entries are all
     given, their gradients are added into those tensors in place and the corresponding returned grads are None; the
-    same, independently, for the two LayerNorm weights (entries 0 and 3)."""
+    same, independently, for the two LayerNorm weights (entries 0 and 3).
+    ln_partials=(buf1, buf2) + ln_partial_mode (L.LN_PARTIAL_*): the two LayerNorm weight gradients are accumulated over
+    calls in those fp32 buffers instead (see layernorm_bwd); their returned grads are None except with LN_PARTIAL_LAST."""
     _need(x, "x"); _need(dy, "dy")
     B, T, Cc = x.shape
     ws = torch.empty(int(L.lib().obte_block_bwd_ws_bytes(B, T, Cc, H)), dtype=torch.uint8, device=x.device)
     dx = torch.empty_like(x)
     acc = accumulate_into is not None and all(accumulate_into[i] is not None for i in (1, 2, 4, 5))
-    acc_ln = accumulate_into is not None and all(accumulate_into[i] is not None for i in (0, 3))
+    acc_ln = (not ln_partial_mode) and accumulate_into is not None and all(accumulate_into[i] is not None for i in (0, 3))
+    if ln_partial_mode:
+        for t in ln_partials:
+            _need(t, "ln_partials", torch.float32)
+            assert t.numel() == L.lib().obte_layernorm_bwd_ws_rows() * Cc
     grads = []
     for i, w in enumerate(params):
         if (acc and i in (1, 2, 4, 5)) or (acc_ln and i in (0, 3)):
@@ -427,8 +453,9 @@ def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec, accumulate_into=None,
             grads.append(g)
         else:
             grads.append(torch.empty_like(w))
-    d = _block_desc(B, T, Cc, H, params, rope, mask, dropout_p, dropout_seed)
+    d = _block_desc(B, T, Cc, H, params, rope, mask, dropout_p, dropout_seed, ln_partials, ln_partial_mode)
     L.check(L.lib().obte_block_bwd_acc(C.byref(d), _ptr(x), _ptr(dy), _ptr(act), _ptr(ws), _ptr(dx), *[_ptr(g) for g in grads],
                                         int(acc) + 2 * int(acc_ln), _stream()), "obte_block_bwd")
-    grads = [None if ((acc and i in (1, 2, 4, 5)) or (acc_ln and i in (0, 3))) else g for i, g in enumerate(grads)]
+    ln_none = ln_partial_mode in (L.LN_PARTIAL_FIRST, L.LN_PARTIAL_MORE)
+    grads = [None if ((acc and i in (1, 2, 4, 5)) or ((acc_ln or ln_none) and i in (0, 3))) else g for i, g in enumerate(grads)]
     return dx, grads

@@ -199,11 +199,13 @@ class TrainStep:
         self._slot = 0
         self._prev_bwd_done = None
 
-    def _inplace(self, enabled: bool):
+    def _inplace(self, enabled: bool, ln_partial_mode: int = 0):
         if self.loss_impl != "fused" or os.environ.get("OBTE_NO_INPLACE_ACCUM") == "1":   # CPU-oracle tests / A-B switch
             return contextlib.nullcontext()
         from .model import accumulate_grads_inplace
-        return accumulate_grads_inplace(enabled)
+        if self.fused_loss_fn is not None or os.environ.get("OBTE_NO_LN_PARTIALS") == "1":   # stub models / A-B switch
+            ln_partial_mode = 0
+        return accumulate_grads_inplace(enabled, ln_partial_mode)
 
     def _mask(self, tokens: torch.Tensor, dtype, j: int = -1):
         from . import masks
@@ -303,6 +305,12 @@ class TrainStep:
             mh = mask.reshape(rows // self.mini, -1).cpu()
             self._mask_rows_host = [torch.nonzero(mh[j], as_tuple=False).reshape(-1).to(input_ids.device) for j in range(mh.shape[0])]
         dtype = next(self.model.parameters()).dtype
+        core_model = self.model.module if hasattr(self.model, "module") else self.model
+        emb_orders = None
+        if input_ids.is_cuda and self.loss_impl == "fused" and self.fused_loss_fn is None and hasattr(core_model, "transformer"):
+            # the embedding backward sums gradient rows in sorted-token order: ONE segmented sort for all micro-batches of
+            # the step instead of a radix sort (four launches) per micro-batch
+            emb_orders = torch.sort(masked_ids.reshape(n_accum, -1), dim=1, stable=True).indices.to(torch.int32)
         cum_loss = torch.zeros((), dtype=torch.float32, device=input_ids.device)
         from . import masks
         self._all_ranges = masks.RangeMask.from_tokens(input_ids, padding=self.use_padding, group=self.mini).key_ranges
@@ -332,13 +340,20 @@ class TrainStep:
                 self._prev_bwd_done = None
             self._slot = (j % 2) if side else 0
             with (torch.cuda.stream(self._streams[j % 2]) if side else contextlib.nullcontext()):
+                if emb_orders is not None:
+                    core_model._embedding_order = emb_orders[j]
                 attn_mask = self._mask(y, dtype, j)
                 ctx = contextlib.nullcontext()
                 if hasattr(self.model, "no_sync") and not last and not self.sync_every:
                     ctx = self.model.no_sync()
                 # all but the last micro-batch: nobody observes the per-micro-batch gradients, so the big matrices are
                 # accumulated by the wgrad epilogues themselves (model.accumulate_grads_inplace)
-                with ctx, self._inplace(not last and not self.sync_every):
+                # LayerNorm weight gradients: micro-batch 0 delivers through autograd (there is no .grad yet), 1 .. n-2 carry
+                # fp32 partial sums (first / more), the last one folds them in and delivers the total through autograd
+                ln_mode = 0
+                if n_accum > 2 and not self.sync_every and j >= 1:
+                    ln_mode = 1 if j == 1 else (3 if last else 2)
+                with ctx, self._inplace(not last and not self.sync_every, ln_mode):
                     mk = mask[j * self.mini:(j + 1) * self.mini]
                     if self.lm_head_impl == "masked":
                         partial[self._slot] += self._masked_rows_loss_backward(x, y, mk, attn_mask, n_accum)

@@ -517,3 +517,54 @@ def test_hip_training_trajectory_tracks_the_reference_run(golden_dir):
         d = np.abs(p.detach().float().flatten()[::stride].cpu().numpy() - g["final_flash/" + k])
         dd = np.abs(g["final_manual/" + k] - g["final_flash/" + k])
         assert d.mean() <= 3.0 * dd.mean() + 2e-3 and d.max() <= 0.06, (k, d.mean(), d.max(), dd.mean(), dd.max())
+
+
+def test_layernorm_weight_gradients_carried_as_fp32_partials_over_micro_batches(monkeypatch):
+    """Over the micro-batches of one optimizer step the LayerNorm weight gradients are carried as fp32 per-workgroup partial
+    sums and reduced once (obte_layernorm_bwd_partial) instead of being reduced and added in bf16 after every micro-batch.
+    Every other gradient must be bit-identical to the per-micro-batch path (OBTE_NO_LN_PARTIALS=1); the LayerNorm weight
+    gradients must agree with it to bf16 accumulation noise and be at least as close to the oracle's fp32 gradient."""
+    from omnibiote_amd import train_encoder as TE
+    from omnibiote_amd.masks import RangeMask
+    from omnibiote_amd.mup_compat import set_base_shapes
+    from omnibiote_amd.model import OmniBioTA, OmniBioTAConfig
+    C, H, Lyr, V, T, rows, mini = 128, 2, 2, 512, 64, 24, 4          # 6 micro-batches
+    cfg = R.RefConfig(block_size=T, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C)
+    w = R.hash_weights(cfg)
+    ids_cpu = torch.from_numpy(TE.synthetic_rows(rows, T, V, np.random.default_rng(3), single_document=False))
+    mlm = torch.from_numpy(np.random.default_rng(4).random((rows, T)) < 0.15)
+    grads = {}
+    for tag, env in (("partials", "0"), ("per_micro_batch", "1")):
+        monkeypatch.setenv("OBTE_NO_LN_PARTIALS", env)
+        c = OmniBioTAConfig(); c.block_size, c.vocab_size, c.n_layer, c.n_head, c.n_embd, c.dropout, c.flash = T, V, Lyr, H, C, 0.0, True
+        m = OmniBioTA(c)
+        cb = OmniBioTAConfig(); cb.block_size, cb.vocab_size, cb.n_layer, cb.dropout, cb.flash = T, V, Lyr, 0.0, True
+        cb.n_embd, cb.n_head = 24, 3
+        base = OmniBioTA(cb)
+        cb.n_embd, cb.n_head = 48, 12
+        delta = OmniBioTA(cb)
+        set_base_shapes(m, base, delta=delta, rescale_params=False)
+        m.load_state_dict(w, strict=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.to(BF)
+        m.to(DEV)
+        step = TE.TrainStep(m, torch.optim.SGD(m.parameters(), lr=0.0), None, mini_batch_size=mini, n_head=H, max_grad_norm=1e9)
+        step(ids_cpu.to(DEV), mlm_mask=mlm.to(DEV))
+        grads[tag] = {k: p.grad.float().cpu().clone() for k, p in m.named_parameters()}
+    wb = {k: v.to(BF).float().requires_grad_(True) for k, v in w.items()}
+    rope = R.cast_rope_table(R.rope_table(C // H, T), BF)
+    mask_eff = mlm & (ids_cpu != 1) & (ids_cpu != R.EOS_TOKEN)
+    masked_ids = ids_cpu.masked_fill(mask_eff, 2)
+    for j in range(rows // mini):
+        sl = slice(j * mini, (j + 1) * mini)
+        dense = RangeMask.from_tokens(ids_cpu[sl]).dense(torch.float32).unsqueeze(1)
+        R.masked_lm_loss(R.model_forward(wb, cfg, masked_ids[sl], dense, rope=rope), ids_cpu[sl], mask_eff[sl], rows // mini).backward()
+    for k in grads["partials"]:
+        a, b, ref = grads["partials"][k], grads["per_micro_batch"][k], wb[k].grad
+        if "ln_" in k:
+            rel = ((a - b).norm() / b.norm()).item()
+            ea, eb = ((a - ref).norm() / ref.norm()).item(), ((b - ref).norm() / ref.norm()).item()
+            assert rel <= 1e-2 and ea <= eb + 2e-3, (k, rel, ea, eb)
+        else:
+            assert torch.equal(a, b), k
