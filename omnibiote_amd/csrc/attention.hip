@@ -495,48 +495,18 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bw
         const char* Vt = Kt + TB;
         const int key0 = t * 64;
         // the 64-key tile is processed as two 32-key halves so that only one score/dP accumulator pair is live.
-        // Fragment reads are issued TWO k-steps (four fragments) ahead of the MFMAs that consume them and pinned there with
-        // sched_barrier: left alone hipcc sinks every ds_read to just before its first use, and the loop then runs
-        // read -> wait a full LDS latency -> MFMA, one fragment at a time (the waves were parked on lgkmcnt 37 % of the time).
+        // (Tried, measured no change — 173-176 us for the whole backward either way: issuing the K / V fragment reads two
+        // k-steps ahead of their MFMAs and the transposed K fragments under the softmax arithmetic, pinned with
+        // sched_barrier.  hipcc's own order is read -> wait -> MFMA per fragment, but the SIMD's second wave covers it.)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             f32x16 sc, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
-            constexpr bool PIN = MODE != MASK_DENSE && !DROP;   // the dense-mask and dropout variants have no registers to spare for it
-            bf16x8 tk[2][ND];
-            if constexpr (PIN) {
-                bf16x8 ka[2][2], va[2][2];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) { ka[0][u] = row_frag<D>(Kt, 32 * mt, u, lane); va[0][u] = row_frag<D>(Vt, 32 * mt, u, lane); }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int pp = 0; pp < NS / 2; ++pp) {
-                    if (pp + 1 < NS / 2) {
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            ka[(pp + 1) & 1][u] = row_frag<D>(Kt, 32 * mt, 2 * pp + 2 + u, lane);
-                            va[(pp + 1) & 1][u] = row_frag<D>(Vt, 32 * mt, 2 * pp + 2 + u, lane);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[pp & 1][u], qf[2 * pp + u], sc, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[pp & 1][u], dof[2 * pp + u], dp, 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // the transposed K fragments of the first dQ k-step are fetched under the softmax arithmetic
-#pragma unroll
-                for (int dt = 0; dt < ND; ++dt) tk[0][dt] = tr_frag<D>(Kt, 32 * mt, dt, lane);
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 32 * mt, s, lane), qf[s], sc, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vt, 32 * mt, s, lane), dof[s], dp, 0, 0, 0);
-                }
+            for (int s = 0; s < NS; ++s) {
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 32 * mt, s, lane), qf[s], sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vt, 32 * mt, s, lane), dof[s], dp, 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -558,27 +528,12 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bw
                     sc[r] = pv * (dpd - dl);   // dS^T (without the scale factor)
                 }
             }
-            if constexpr (PIN) {
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int dt = 0; dt < ND; ++dt) tk[1][dt] = tr_frag<D>(Kt, 32 * mt + 16, dt, lane);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 dsf = pack8(sc, 8 * kk);
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bf16x8 dsf = pack8(sc, 8 * kk);
-#pragma unroll
-                    for (int dt = 0; dt < ND; ++dt)
-                        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tk[kk][dt], dsf, dq[dt], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bf16x8 dsf = pack8(sc, 8 * kk);
-#pragma unroll
-                    for (int dt = 0; dt < ND; ++dt)
-                        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Kt, 32 * mt + 16 * kk, dt, lane), dsf, dq[dt], 0, 0, 0);
-                }
+                for (int dt = 0; dt < ND; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Kt, 32 * mt + 16 * kk, dt, lane), dsf, dq[dt], 0, 0, 0);
             }
         }
         dma_wait_all();
@@ -792,375 +747,6 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kern
     }
 }
 
-// ==========================================================================================================
-// backward, one wave per SIMD ("x4" kernels): 4 waves per workgroup, each wave owns 64 rows (two 32-row halves) and the
-// whole 512-register file, so every fragment read from LDS feeds TWO MFMAs (0.5-0.75 KiB of LDS reads per MFMA instead of
-// 1-1.25 with 32 rows per wave: at 128 B/clk/CU the 8-wave kernels above were bounded by the LDS pipe, not by MFMA).
-// The row constants ride in the accumulators: S' starts from -lse/scale and dP' from -delta, so p = exp2(S' * scale2) and
-// dS = p * dP' need no subtractions (cdna_hip_programming.md, Attention backward).  No dropout, no dense masks here: those
-// variants keep the kernels above.  Same arithmetic otherwise; same LDS images, swizzles and DMA helpers.
-// ==========================================================================================================
-// dK, dV: 256 keys per workgroup, 64 per wave, key on the lane.  V (the B operand of dP) stays in LDS for the whole
-// kernel, K fragments in registers, dK^T / dV^T of the wave's 64 keys in 256 accumulator registers.
-template <int D, int MODE>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_x4_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NW = 4;
-    constexpr int QB = 32 * 2 * D;
-    constexpr int NS = D / 16, ND = D / 32;
-    constexpr int STAGE = 2 * QB + 256;
-    constexpr int VB = 256 * 2 * D;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5;
-    const BlockId bid_ = block_id((int)((p.T + 255) / 256), p.H);
-    const int hd = bid_.hd;
-    const int64_t b = bid_.b;
-    const int T = (int)p.T;
-    const int C = p.H * D;
-    const int64_t ld = 3 * (int64_t)C;
-    int key[2], key_c[2];
-    bool k_ok[2];
-    bf16x8 kf[2][NS];
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-        key[kh] = bid_.blk * 256 + wave * 64 + kh * 32 + (lane & 31);
-        k_ok[kh] = key[kh] < T;
-        key_c[kh] = k_ok[kh] ? key[kh] : T - 1;
-        const bf16* kptr = p.qkv + (b * T + key_c[kh]) * ld + C + hd * D;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) kf[kh][s] = *reinterpret_cast<const bf16x8*>(kptr + 16 * s + 8 * h);
-    }
-    char* Vblk = smem + 2 * STAGE;
-    {
-        TileDma<D, 256, NW> dmv;
-        dmv.init(wave, lane, ld);
-        const int64_t row0 = (int64_t)bid_.blk * 256;
-        dmv.issue(p.qkv + (b * T + row0) * ld + 2 * C + hd * D, (((int64_t)T - row0) * ld - (2 * C + hd * D)) * 2, Vblk, wave);
-    }
-    int qs[2], qe[2];
-    int lo = T, hi = 0;
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-        qs[kh] = 0; qe[kh] = T;
-        if (MODE == MASK_RANGES) {
-            qs[kh] = max(p.key_ranges[(b * T + key_c[kh]) * 2], 0);
-            qe[kh] = min(p.key_ranges[(b * T + key_c[kh]) * 2 + 1], T);
-        }
-        if (!k_ok[kh]) { qs[kh] = 0; qe[kh] = 0; }
-        if (k_ok[kh]) { lo = min(lo, qs[kh]); hi = max(hi, qe[kh]); }
-    }
-    if (MODE == MASK_RANGES) block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 2 * STAGE + VB), wave, lane);
-    else { lo = 0; hi = T; }
-    const int t_begin = lo / 32;
-    int t_end = hi > lo ? (hi + 31) / 32 : t_begin;
-    if (p.max_tiles) t_end = min(t_end, t_begin + p.max_tiles - 1);
-
-    const bf16* qbase = p.qkv + b * T * ld + hd * D;
-    const bf16* dobase = p.d_o + b * T * C + hd * D;
-    const float* lse_b = p.lse_in + (b * p.H + hd) * T;
-    const float* del_b = p.delta + (b * p.H + hd) * T;
-
-    f32x16 dk[2][ND], dv[2][ND];
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-        for (int i = 0; i < ND; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { dk[kh][i][r] = 0.f; dv[kh][i][r] = 0.f; }
-    const float scale2 = p.scale * LOG2E;
-    const float inv_scale = 1.0f / p.scale;
-
-    TileDma<D, 32, NW> dmq, dmd;
-    dmq.init(wave, lane, ld);
-    dmd.init(wave, lane, C);
-    auto issue_qd = [&](int t, char* stage) {
-        const int64_t row0 = (int64_t)t * 32;
-        dmq.issue(qbase + row0 * ld, (((int64_t)T - row0) * ld - hd * D) * 2, stage, wave);
-        dmd.issue(dobase + row0 * C, (((int64_t)T - row0) * C - hd * D) * 2, stage + QB, wave);
-    };
-    float st_l = 0.f;  // threads 0..31: -lse/scale of row tid (the initial S accumulator); 32..63: -delta of row tid-32
-    auto load_stats = [&](int q0) {
-        if (tid < 64) {
-            const int q = q0 + (tid & 31);
-            float v = 0.f;
-            if (q < T) v = tid < 32 ? -lse_b[q] * inv_scale : -del_b[q];
-            else if (tid < 32) v = -INFINITY;   // rows past T (and rows whose lse is +inf): p = exp2(-inf) = 0
-            st_l = v;
-        }
-    };
-    auto store_stats = [&](char* stage) {
-        if (tid < 64) reinterpret_cast<float*>(stage + 2 * QB)[tid] = st_l;
-    };
-    if (t_begin < t_end) {
-        issue_qd(t_begin, smem);
-        load_stats(t_begin * 32);
-        store_stats(smem);
-    }
-    dma_wait_all();
-    prologue_wait_all();
-    __syncthreads();
-
-    for (int t = t_begin; t < t_end; ++t) {
-        const int cur = (t - t_begin) & 1;
-        const bool more = t + 1 < t_end;
-        if (more) {
-            issue_qd(t + 1, smem + (cur ^ 1) * STAGE);
-            load_stats((t + 1) * 32);
-        }
-        const char* Qt = smem + cur * STAGE;
-        const char* Dt = Qt + QB;
-        const float* stats = reinterpret_cast<const float*>(Qt + 2 * QB);
-        const int q0 = t * 32;
-
-        f32x16 sc[2], dp[2];
-        // the row constants are the initial accumulators: S' = Q K^T - lse/scale, dP' = dO V^T - delta
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(stats + 8 * i + 4 * h);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(stats + 32 + 8 * i + 4 * h);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { sc[kh][4 * i + j] = l4[j]; dp[kh][4 * i + j] = d4[j]; }
-            }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const bf16x8 qa = row_frag<D>(Qt, 0, s, lane), da = row_frag<D>(Dt, 0, s, lane);
-            sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[0][s], sc[0], 0, 0, 0);
-            sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[1][s], sc[1], 0, 0, 0);
-            dp[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, row_frag<D>(Vblk, 64 * wave, s, lane), dp[0], 0, 0, 0);
-            dp[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, row_frag<D>(Vblk, 64 * wave + 32, s, lane), dp[1], 0, 0, 0);
-        }
-        bf16x8 pf[2][2], dsf[2][2];
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            const bool inside = q0 >= qs[kh] && q0 + 32 <= qe[kh];
-            if (__all(inside)) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = fast_exp2(sc[kh][r] * scale2);
-                    sc[kh][r] = pv;
-                    dp[kh][r] = pv * dp[kh][r];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int q = q0 + acc_row(r, h);
-                    float pv = fast_exp2(sc[kh][r] * scale2);
-                    if (q < qs[kh] || q >= qe[kh]) pv = 0.f;
-                    sc[kh][r] = pv;
-                    dp[kh][r] = pv * dp[kh][r];
-                }
-            }
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) { pf[kh][kk] = pack8(sc[kh], 8 * kk); dsf[kh][kk] = pack8(dp[kh], 8 * kk); }
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int dt = 0; dt < ND; ++dt) {
-                const bf16x8 td = tr_frag<D>(Dt, 16 * kk, dt, lane), tq = tr_frag<D>(Qt, 16 * kk, dt, lane);
-                dv[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td, pf[0][kk], dv[0][dt], 0, 0, 0);
-                dv[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td, pf[1][kk], dv[1][dt], 0, 0, 0);
-                dk[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq, dsf[0][kk], dk[0][dt], 0, 0, 0);
-                dk[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq, dsf[1][kk], dk[1][dt], 0, 0, 0);
-            }
-        if (more) store_stats(smem + (cur ^ 1) * STAGE);
-        dma_wait_all();
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
-        if (k_ok[kh]) {
-            bf16* dkrow = p.dqkv + (b * T + key[kh]) * ld + C + hd * D;
-            bf16* dvrow = dkrow + C;
-#pragma unroll
-            for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int d0 = 32 * dt + 8 * i + 4 * h;
-                    float g[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) g[j] = dk[kh][dt][4 * i + j] * p.scale;
-                    rope_inv4(g, p.rope_cos, p.rope_sin, key[kh], D, d0);
-                    bf16x4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = f2bf(g[j]);
-                    *reinterpret_cast<bf16x4*>(dkrow + d0) = v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = f2bf(dv[kh][dt][4 * i + j]);
-                    *reinterpret_cast<bf16x4*>(dvrow + d0) = v;
-                }
-        }
-}
-
-// dQ (and delta): 256 queries per workgroup, 64 per wave, query on the lane; K/V stream through LDS in 64-key tiles.
-// Q and dO fragments of the wave's 64 queries stay in registers, every K / V fragment read from LDS feeds both halves.
-template <int D, int MODE>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_x4_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NW = 4;
-    constexpr int TB = 64 * 2 * D;
-    constexpr int NS = D / 16, ND = D / 32;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5;
-    const BlockId bid_ = block_id((int)((p.T + 255) / 256), p.H);
-    const int hd = bid_.hd;
-    const int64_t b = bid_.b;
-    const int T = (int)p.T;
-    const int C = p.H * D;
-    const int64_t ld = 3 * (int64_t)C;
-    int q_row[2], q_c[2], ks[2], ke[2];
-    bool q_ok[2];
-    bf16x8 qf[2][NS], dof[2][NS];
-    float sinit[2], dinit[2];
-    int lo = T, hi = 0;
-#pragma unroll
-    for (int qh = 0; qh < 2; ++qh) {
-        q_row[qh] = bid_.blk * 256 + wave * 64 + qh * 32 + (lane & 31);
-        q_ok[qh] = q_row[qh] < T;
-        q_c[qh] = q_ok[qh] ? q_row[qh] : T - 1;
-        const bf16* qptr = p.qkv + (b * T + q_c[qh]) * ld + hd * D;
-        const bf16* doptr = p.d_o + (b * T + q_c[qh]) * C + hd * D;
-        const bf16* optr = p.o_in + (b * T + q_c[qh]) * C + hd * D;
-        float dl = 0.f;
-        {   // delta from its own copy of the dO row (a separately loaded temporary: the fragments kept for the MFMAs are then
-            // never read by a vector ALU instruction, which lets the register allocator keep them in accumulation registers)
-            const bf16* doptr2 = doptr;
-            asm volatile("" : "+v"(doptr2));
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const bf16x8 of = *reinterpret_cast<const bf16x8*>(optr + 16 * s + 8 * h);
-                const bf16x8 df = *reinterpret_cast<const bf16x8*>(doptr2 + 16 * s + 8 * h);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dl += bf2f(of[j]) * bf2f(df[j]);
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            qf[qh][s] = *reinterpret_cast<const bf16x8*>(qptr + 16 * s + 8 * h);
-            dof[qh][s] = *reinterpret_cast<const bf16x8*>(doptr + 16 * s + 8 * h);
-        }
-        dl += __shfl_xor(dl, 32, 64);
-        if (h == 0 && q_ok[qh]) p.delta[(b * p.H + hd) * T + q_row[qh]] = dl;
-        dinit[qh] = -dl;
-        sinit[qh] = -p.lse_in[(b * p.H + hd) * T + q_c[qh]] / p.scale;   // +inf lse (degenerate row) -> -inf -> p = 0
-        ks[qh] = 0; ke[qh] = T;
-        if (MODE == MASK_RANGES) {
-            ks[qh] = max(p.key_ranges[(b * T + q_c[qh]) * 2], 0);
-            ke[qh] = min(p.key_ranges[(b * T + q_c[qh]) * 2 + 1], T);
-        }
-        lo = min(lo, ks[qh]); hi = max(hi, ke[qh]);
-    }
-    if (MODE == MASK_RANGES) block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 4 * TB), wave, lane);
-    else { lo = 0; hi = T; }
-    const int t_begin = lo / 64;
-    int t_end = hi > lo ? (hi + 63) / 64 : t_begin;
-    if (p.max_tiles) t_end = min(t_end, t_begin + p.max_tiles - 1);
-
-    const bf16* kbase = p.qkv + b * T * ld + C + hd * D;
-    const bf16* vbase = kbase + C;
-    f32x16 dq[2][ND];
-#pragma unroll
-    for (int qh = 0; qh < 2; ++qh)
-#pragma unroll
-        for (int i = 0; i < ND; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dq[qh][i][r] = 0.f;
-    const float scale2 = p.scale * LOG2E;
-
-    TileDma<D, 64, NW> dma;
-    dma.init(wave, lane, ld);
-    auto issue_kv = [&](int t, int stage) {
-        const int64_t row0 = (int64_t)t * 64;
-        const int64_t rows_left = ((int64_t)T - row0) * ld;
-        char* st = smem + stage * 2 * TB;
-        dma.issue(kbase + row0 * ld, (rows_left - (C + hd * D)) * 2, st, wave);
-        dma.issue(vbase + row0 * ld, (rows_left - (2 * C + hd * D)) * 2, st + TB, wave);
-    };
-    if (t_begin < t_end) issue_kv(t_begin, 0);
-    dma_wait_all();
-    prologue_wait_all();
-    __syncthreads();
-
-    for (int t = t_begin; t < t_end; ++t) {
-        const int cur = (t - t_begin) & 1;
-        if (t + 1 < t_end) issue_kv(t + 1, cur ^ 1);
-        const char* Kt = smem + cur * 2 * TB;
-        const char* Vt = Kt + TB;
-        const int key0 = t * 64;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            f32x16 sc[2], dp[2];
-#pragma unroll
-            for (int qh = 0; qh < 2; ++qh)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { sc[qh][r] = sinit[qh]; dp[qh][r] = dinit[qh]; }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const bf16x8 ka = row_frag<D>(Kt, 32 * mt, s, lane), va = row_frag<D>(Vt, 32 * mt, s, lane);
-                sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[0][s], sc[0], 0, 0, 0);
-                sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[1][s], sc[1], 0, 0, 0);
-                dp[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[0][s], dp[0], 0, 0, 0);
-                dp[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[1][s], dp[1], 0, 0, 0);
-            }
-            bf16x8 dsf[2][2];
-            const int kb0 = key0 + 32 * mt;
-#pragma unroll
-            for (int qh = 0; qh < 2; ++qh) {
-                const bool inside = kb0 >= ks[qh] && kb0 + 32 <= ke[qh];
-                if (__all(inside)) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sc[qh][r] = fast_exp2(sc[qh][r] * scale2) * dp[qh][r];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kb0 + acc_row(r, h);
-                        float pv = fast_exp2(sc[qh][r] * scale2);
-                        if (key < ks[qh] || key >= ke[qh]) pv = 0.f;
-                        sc[qh][r] = pv * dp[qh][r];
-                    }
-                }
-                dsf[qh][0] = pack8(sc[qh], 0);
-                dsf[qh][1] = pack8(sc[qh], 8);
-            }
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int dt = 0; dt < ND; ++dt) {
-                    const bf16x8 tk = tr_frag<D>(Kt, 32 * mt + 16 * kk, dt, lane);
-                    dq[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tk, dsf[0][kk], dq[0][dt], 0, 0, 0);
-                    dq[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tk, dsf[1][kk], dq[1][dt], 0, 0, 0);
-                }
-        }
-        dma_wait_all();
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int qh = 0; qh < 2; ++qh)
-        if (q_ok[qh]) {
-            bf16* drow = p.dqkv + (b * T + q_row[qh]) * ld + hd * D;
-#pragma unroll
-            for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float g[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) g[j] = dq[qh][dt][4 * i + j] * p.scale;
-                    const int d0 = 32 * dt + 8 * i + 4 * h;
-                    rope_inv4(g, p.rope_cos, p.rope_sin, q_row[qh], D, d0);
-                    bf16x4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = f2bf(g[j]);
-                    *reinterpret_cast<bf16x4*>(drow + d0) = v;
-                }
-        }
-}
-
 // Explicit instantiations (implicit instantiation alone left some host stubs undefined with hipcc / ROCm 7.2).
 #define OBTE_INST_ATTN(D, M)                                                       \
     template __global__ void attn_fwd_kernel<D, M, false>(AttnParams);             \
@@ -1169,11 +755,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_x4_kernel(AttnParams p) {
     template __global__ void attn_fwd_kernel<D, M, true>(AttnParams);              \
     template __global__ void attn_bwd_dq_kernel<D, M, true>(AttnParams);           \
     template __global__ void attn_bwd_dkdv_kernel<D, M, true>(AttnParams);
-#define OBTE_INST_X4(D, M)                                                       \
-    template __global__ void attn_bwd_dq_x4_kernel<D, M>(AttnParams);            \
-    template __global__ void attn_bwd_dkdv_x4_kernel<D, M>(AttnParams);
-OBTE_INST_X4(64, 0) OBTE_INST_X4(64, 1) OBTE_INST_X4(128, 0) OBTE_INST_X4(128, 1)
-#undef OBTE_INST_X4
 OBTE_INST_ATTN(64, 0) OBTE_INST_ATTN(64, 1) OBTE_INST_ATTN(64, 2)
 OBTE_INST_ATTN(128, 0) OBTE_INST_ATTN(128, 1) OBTE_INST_ATTN(128, 2)
 #undef OBTE_INST_ATTN
@@ -1207,47 +788,8 @@ int launch_fwd(const AttnParams& p, int mode, hipStream_t st) {
     return OBTE_OK;
 }
 
-// OBTE_ATTN_BWD=x4 | w8: force the one-wave-per-SIMD kernels (where they exist) or the eight-wave ones (A/B timing, tests)
-static int bwd_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("OBTE_ATTN_BWD");
-        v = (e && !strcmp(e, "x4")) ? 4 : 8;   // measured (B=8,H=8,T=1024,D=128): x4 221 us vs w8 178 us — hipcc puts every MFMA accumulator of a >256-register kernel into AGPRs and shuttles S/dP through v_accvgpr moves
-    }
-    return v;
-}
-
-template <int D>
-int launch_bwd_x4(const AttnParams& p, int mode, hipStream_t st) {
-    const dim3 grid((unsigned)(cdiv64(p.T, 256) * p.H * p.B)), block(256);
-    {
-        const int smem = 4 * 64 * 2 * D + 64;
-        if (mode == MASK_NONE) {
-            set_smem(attn_bwd_dq_x4_kernel<D, MASK_NONE>, smem);
-            hipLaunchKernelGGL((attn_bwd_dq_x4_kernel<D, MASK_NONE>), grid, block, smem, st, p);
-        } else {
-            set_smem(attn_bwd_dq_x4_kernel<D, MASK_RANGES>, smem);
-            hipLaunchKernelGGL((attn_bwd_dq_x4_kernel<D, MASK_RANGES>), grid, block, smem, st, p);
-        }
-        OBTE_CHECK_LAUNCH("obte_attn_bwd(dq x4)");
-    }
-    {
-        const int smem = 2 * (2 * 32 * 2 * D + 256) + 256 * 2 * D + 64;
-        if (mode == MASK_NONE) {
-            set_smem(attn_bwd_dkdv_x4_kernel<D, MASK_NONE>, smem);
-            hipLaunchKernelGGL((attn_bwd_dkdv_x4_kernel<D, MASK_NONE>), grid, block, smem, st, p);
-        } else {
-            set_smem(attn_bwd_dkdv_x4_kernel<D, MASK_RANGES>, smem);
-            hipLaunchKernelGGL((attn_bwd_dkdv_x4_kernel<D, MASK_RANGES>), grid, block, smem, st, p);
-        }
-        OBTE_CHECK_LAUNCH("obte_attn_bwd(dkdv x4)");
-    }
-    return OBTE_OK;
-}
-
 template <int D>
 int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
-    if (mode != MASK_DENSE && !p.drop.thresh24 && bwd_variant() == 4) return launch_bwd_x4<D>(p, mode, st);
     {
         const int smem = 4 * 64 * 2 * D + 64;
         const dim3 grid_d((unsigned)(cdiv64(p.T, 32 * FwdShape<true>::NW) * p.H * p.B)), block_d(64 * FwdShape<true>::NW);
