@@ -93,7 +93,7 @@ enum {
                                pairs (2j,2j+1) of each head rotated by (rope_cos, rope_sin)[row % rope_T][j], fp32 [T, hs/2];
                                all-zero sin = the reference's cos-only bf16 mode */
     OBTE_EPI_ADD_DROPOUT = 4 /* d = bf16(aux + dropout(bf16(acc)))   resid_dropout / mlp dropout (model.py:151,167);
-                                element (m,n) uses dropout index m*ldd+n of (dropout_seed, dropout_site) */
+                                element (m,n) is dropout element (row m, col n) of (dropout_seed, dropout_site) */
 };
 typedef struct {
     const obte_bf16* a; const obte_bf16* b; obte_bf16* d;
@@ -131,13 +131,15 @@ int64_t obte_gemm_workspace_bytes_max(int64_t M, int64_t N, int64_t K);
 int obte_gemm_grouped_bf16(const obte_gemm_args* gs, int count, obte_stream s);
 
 /* ---- dropout (training/model.py:83-84,160,204) -------------------------------------------------------------------
- * Every dropout site of the path draws its mask from one counter-based generator: element `idx` of site `site` is
- * kept iff hash(seed, site, idx) >= p (see csrc/common.h drop_keep); kept values are scaled by 1/(1-p) and rounded to
- * bf16.  Forward and backward regenerate the mask from (seed, site) — nothing is stored.  Sites: 0 embedding output
- * (idx = row*C + col), 1 attention probabilities (idx = ((b*H+h)*T + q)*T + key), 2 attention c_proj output,
- * 3 MLP c_proj output (idx = row*C + col), 7 free for callers.  The RNG stream necessarily differs from PyTorch's.
- * obte_dropout_bf16: out = dropout(in) elementwise with idx = linear index (in may alias out). */
-int obte_dropout_bf16(const obte_bf16* in, obte_bf16* out, int64_t n, float p, uint64_t seed, int32_t site, obte_stream s);
+ * Every dropout site of the path is a matrix and draws its mask from one counter-based generator: element (row, col) of
+ * site `site` is kept iff the 16 bits it owns of hash32(rowkey(seed, site, row) ^ (col >> 1)) are >= p * 2^16 (two columns
+ * share one 32-bit hash, a row's key is formed once; csrc/common.h drop_rowkey / drop_keep); kept values are scaled by
+ * 1/(1-p) and rounded to bf16.  Forward and backward regenerate the mask from (seed, site) — nothing is stored.  Sites:
+ * 0 embedding output (row = token position, col = feature), 1 attention probabilities (row = (b*H + h)*T + query,
+ * col = key), 2 attention c_proj output, 3 MLP c_proj output (row = token position, col = feature), 7 free for callers.
+ * The RNG stream necessarily differs from PyTorch's.
+ * obte_dropout_bf16: out = dropout(in) on a flat [n / cols, cols] matrix (in may alias out); cols % 8 == 0. */
+int obte_dropout_bf16(const obte_bf16* in, obte_bf16* out, int64_t n, int64_t cols, float p, uint64_t seed, int32_t site, obte_stream s);
 
 /* ---- RoPE on the q and k thirds of a packed qkv activation, in place (training/model.py:39-50,108) ------
  * qkv: [rows = B*T, 3*C]; pairs (2j,2j+1) of each head; position = row % T.  cos/sin: fp32 [T, hs/2].

@@ -93,7 +93,7 @@ SYMBOLS = {
     "obte_embedding_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int64, c_stream]),
     "obte_embedding_fwd_dropout": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_uint64, c_stream]),
     "obte_embedding_bwd_dropout": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_uint64, c_stream]),
-    "obte_dropout_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_int32, c_stream]),
+    "obte_dropout_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_uint64, C.c_int32, c_stream]),
     "obte_embedding_bwd_ws_bytes": (C.c_int64, [C.c_int64, C.c_int]),
     "obte_embedding_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int64, c_stream]),
     "obte_embedding_bwd_acc": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int64, C.c_int, c_stream]),

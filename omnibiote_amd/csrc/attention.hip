@@ -35,7 +35,7 @@ struct AttnParams {
     const int32_t* key_ranges; const bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
     const int32_t* query_bounds;   // dense mode only: per-key [first, last+1) query bounds (obte_mask_bounds), nullable
     int64_t B, T; int H; float scale;
-    DropCfg drop;   // attention-probability dropout (site 1); thresh24 == 0: off
+    DropCfg drop;   // attention-probability dropout (site 1); thresh16 == 0: off
     int max_tiles;  // timing-only diagnostic (OBTE_ATTN_DEBUG=tiles:N): every workgroup stops after N tiles (results are wrong; 0 = off)
 };
 
@@ -195,12 +195,14 @@ __device__ __forceinline__ void block_minmax(int& lo, int& hi, int* scratch, int
 // ==========================================================================================================
 // forward
 // ==========================================================================================================
-// Queries per workgroup: 256 (eight waves, one workgroup per CU) without dropout.  Every workgroup streams the whole
-// K and V of its (batch, head) through LDS, so the L2 -> LDS traffic is inversely proportional to the query block: at
+// Queries per workgroup: 256 (eight waves, one workgroup per CU), with and without dropout.  Every workgroup streams the
+// whole K and V of its (batch, head) through LDS, so the L2 -> LDS traffic is inversely proportional to the query block: at
 // 128 queries the forward moved 268 MB per launch in 50 us = 5.4 TB/s, the chip-wide LDS-DMA ceiling — that, not MFMA,
-// VALU, LDS or DMA latency, was what bounded it.  The dropout variants keep 128 queries / four waves with one workgroup
-// per CU: they need the 512-register budget.
-template <bool DROP> struct FwdShape { static constexpr int NW = DROP ? 4 : 8; static constexpr int STAGES = 2; };   // a deeper ring (4 stages, 3 tiles ahead) measured slower: 48.9 vs 45.9 us
+// VALU, LDS or DMA latency, was what bounded it.  (The dropout variants ran 128 queries / four waves while every probability
+// cost two hash rounds and 64-bit index arithmetic and the kernels needed the 512-register budget; with the row key
+// hoisted and one hash per two keys — csrc/common.h — they fit 256 registers: forward 99 -> 58 us, backward 310 -> 189 us
+// at p = 0.1, against 47 / 160 us without dropout.)
+template <bool DROP> struct FwdShape { static constexpr int NW = 8; static constexpr int STAGES = 2; };   // a deeper ring (4 stages, 3 tiles ahead) measured slower: 48.9 vs 45.9 us
 template <int D, int MODE, bool DROP>
 __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_fwd_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -225,6 +227,8 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_fwd_kernel(At
     bf16x8 qf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qptr + 16 * s + 8 * h);
+    // dropout row = (batch, head, query): its key is formed once per lane, not once per probability
+    const uint32_t drop_rk = DROP ? drop_rowkey(((uint64_t)b * p.H + hd) * (uint64_t)T + (uint64_t)q_c, p.drop) : 0u;
 
     int ks = 0, ke = T;
     if (MODE == MASK_RANGES) {
@@ -342,14 +346,22 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_fwd_kernel(At
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv = fast_exp2(__builtin_fmaf(sc[mt][r], sx, -m_safe));
-                rs += pv;   // the normaliser uses the un-dropped probabilities
+            for (int i = 0; i < 4; ++i) {
+                // registers 4i .. 4i+3 hold four consecutive keys (a multiple of 4 onwards): two pairs, one hash each
+                uint32_t bits[2] = {0u, 0u};
                 if (DROP) {
-                    const uint64_t di = (((uint64_t)b * p.H + hd) * T + q_c) * (uint64_t)T + (uint64_t)(key0 + 32 * mt + acc_row(r, h));
-                    pv = drop_keep(di, p.drop) ? pv * p.drop.scale : 0.f;
+                    const uint32_t g = (uint32_t)(key0 + 32 * mt + 8 * i + 4 * h) >> 1;
+                    bits[0] = drop_pair_bits(drop_rk, g);
+                    bits[1] = drop_pair_bits(drop_rk, g + 1);
                 }
-                sc[mt][r] = pv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * i + j;
+                    float pv = fast_exp2(__builtin_fmaf(sc[mt][r], sx, -m_safe));
+                    rs += pv;   // the normaliser uses the un-dropped probabilities
+                    if (DROP) pv = drop_keep_bits(bits[j >> 1], (uint32_t)(j & 1), p.drop) ? pv * p.drop.scale : 0.f;
+                    sc[mt][r] = pv;
+                }
             }
         l += rs;
         // O^T += V^T P^T : P^T accumulators are the B operand as they stand
@@ -398,12 +410,12 @@ __device__ __forceinline__ void rope_inv4(float (&g)[4], const float* cos_t, con
 }
 
 // ==========================================================================================================
-// backward, part 1: dQ (and delta).  Same shape as forward: 256 queries per workgroup (128 with dropout), query on the lane.
+// backward, part 1: dQ (and delta).  Same shape as forward: 256 queries per workgroup, query on the lane.
 //   S^T = K Q^T ; P^T = exp(S^T*scale + mask - lse) ; dP^T = V dO^T ; dS^T = P^T (dP^T - delta) ; dQ^T += K^T dS^T
 // ==========================================================================================================
-// 256 queries (eight waves) per workgroup without dropout, for the same reason as the forward: K/V traffic per query.
+// 256 queries (eight waves) per workgroup, for the same reason as the forward: K/V traffic per query.
 template <int D, int MODE, bool DROP>
-__global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dq_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = FwdShape<DROP>::NW;
     constexpr int TB = 64 * 2 * D;
@@ -430,6 +442,7 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bw
         dof[s] = *reinterpret_cast<const bf16x8*>(doptr + 16 * s + 8 * h);
     }
     const float lse2 = p.lse_in[(b * p.H + hd) * T + q_c] * LOG2E;
+    const uint32_t drop_rk = DROP ? drop_rowkey(((uint64_t)b * p.H + hd) * (uint64_t)T + (uint64_t)q_c, p.drop) : 0u;
     // delta = rowsum(O * dO), computed here from the dO fragments already in registers (it used to be a kernel of its
     // own: one 9-us launch per layer) and published for the dK/dV kernel, which runs after this one on the same stream
     float dl = 0.f;
@@ -512,6 +525,12 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bw
             for (int i = 0; i < 4; ++i) {
                 float mk[4] = {0.f, 0.f, 0.f, 0.f};
                 if (MODE == MASK_DENSE) mask4(mrow, key0 + 32 * mt + 8 * i + 4 * h, T, mvec, mk);
+                uint32_t bits[2] = {0u, 0u};
+                if (DROP) {
+                    const uint32_t g = (uint32_t)(key0 + 32 * mt + 8 * i + 4 * h) >> 1;
+                    bits[0] = drop_pair_bits(drop_rk, g);
+                    bits[1] = drop_pair_bits(drop_rk, g + 1);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int r = 4 * i + j;
@@ -521,10 +540,7 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bw
                     float pv = fast_exp2(x);
                     if (key < ks || key >= ke) pv = 0.f;
                     float dpd = dp[r];
-                    if (DROP) {
-                        const uint64_t di = (((uint64_t)b * p.H + hd) * T + q_c) * (uint64_t)T + (uint64_t)key;
-                        dpd = drop_keep(di, p.drop) ? dpd * p.drop.scale : 0.f;
-                    }
+                    if (DROP) dpd = drop_keep_bits(bits[j >> 1], (uint32_t)(j & 1), p.drop) ? dpd * p.drop.scale : 0.f;
                     sc[r] = pv * (dpd - dl);   // dS^T (without the scale factor)
                 }
             }
@@ -560,12 +576,12 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, DROP ? 2 : 1) void attn_bw
 }
 
 // ==========================================================================================================
-// backward, part 2: dK and dV.  256 keys per workgroup (128 with dropout; 32 per wave), key on the lane; queries stream through
+// backward, part 2: dK and dV.  256 keys per workgroup (32 per wave), key on the lane; queries stream through
 // LDS in 32-row tiles (Q and dO, plus their lse/delta).
 //   S = Q K^T ; P = exp(S*scale + mask - lse) ; dP = dO V^T ; dS = P (dP - delta)
 //   dV^T += dO^T P ; dK^T += Q^T dS
 // ==========================================================================================================
-// 256 keys (eight waves) per workgroup without dropout: the Q / dO tiles every workgroup streams are then shared by
+// 256 keys (eight waves) per workgroup: the Q / dO tiles every workgroup streams are then shared by
 // twice as many keys (half the L2 -> LDS traffic per key).
 template <int D, int MODE, bool DROP>
 __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kernel(AttnParams p) {
@@ -573,7 +589,7 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kern
     constexpr int NW = FwdShape<DROP>::NW;
     constexpr int QB = 32 * 2 * D;  // bytes of one 32-row tile
     constexpr int NS = D / 16, ND = D / 32;
-    constexpr int STAGE = 2 * QB + 256;  // Q tile, dO tile, 32 lse2 + 32 delta floats
+    constexpr int STAGE = 2 * QB + 384;  // Q tile, dO tile, 32 lse2 + 32 delta floats + 32 dropout row keys
     constexpr int VB = 32 * NW * 2 * D;  // the workgroup's own V rows, kept in LDS for the whole kernel (B operand of dP)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -644,7 +660,7 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kern
         dmq.issue(qbase + row0 * ld, (((int64_t)T - row0) * ld - hd * D) * 2, stage, wave);
         dmd.issue(dobase + row0 * C, (((int64_t)T - row0) * C - hd * D) * 2, stage + QB, wave);
     };
-    float st_l = 0.f;  // threads 0..31: lse2 of row tid ; 32..63: delta of row tid-32
+    float st_l = 0.f;  // threads 0..31: lse2 of row tid ; 32..63: delta of row tid-32 ; 64..95 (dropout): row key of row tid-64
     auto load_stats = [&](int q0) {
         if (tid < 64) {
             const int q = q0 + (tid & 31);
@@ -652,10 +668,13 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kern
             if (q < T) v = tid < 32 ? lse_b[q] * LOG2E : del_b[q];
             else if (tid < 32) v = INFINITY;   // rows past T: p = exp2(x - inf) = 0
             st_l = v;
+        } else if (DROP && tid < 96) {
+            const int q = min(q0 + (tid & 31), T - 1);
+            st_l = __uint_as_float(drop_rowkey(((uint64_t)b * p.H + hd) * (uint64_t)T + (uint64_t)q, p.drop));
         }
     };
     auto store_stats = [&](char* stage) {
-        if (tid < 64) reinterpret_cast<float*>(stage + 2 * QB)[tid] = st_l;
+        if (tid < (DROP ? 96 : 64)) reinterpret_cast<float*>(stage + 2 * QB)[tid] = st_l;
     };
     if (t_begin < t_end) {
         issue_qd(t_begin, smem);
@@ -699,9 +718,8 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kern
                 float pv = fast_exp2(x);
                 if (q < qs || q >= qe) pv = 0.f;
                 float pd = pv, dpd = dp[r];
-                if (DROP) {
-                    const uint64_t di = (((uint64_t)b * p.H + hd) * T + (uint64_t)(q < T ? q : T - 1)) * (uint64_t)T + (uint64_t)key_c;
-                    const bool kp = drop_keep(di, p.drop);
+                if (DROP) {   // row key of query q from the stage's table, this lane's key as the column
+                    const bool kp = drop_keep(__float_as_uint(stats[64 + 8 * i + 4 * h + j]), (uint32_t)key_c, p.drop);
                     pd = kp ? pv * p.drop.scale : 0.f;
                     dpd = kp ? dpd * p.drop.scale : 0.f;
                 }
@@ -774,7 +792,7 @@ int launch_fwd(const AttnParams& p, int mode, hipStream_t st) {
     const dim3 grid((unsigned)(cdiv64(p.T, 32 * FwdShape<false>::NW) * p.H * p.B)), block(64 * FwdShape<false>::NW);
 #define GO(M)                                                                                 \
     do {                                                                                      \
-        if (p.drop.thresh24) {                                                                \
+        if (p.drop.thresh16) {                                                                \
             set_smem(attn_fwd_kernel<D, M, true>, smem);                                      \
             hipLaunchKernelGGL((attn_fwd_kernel<D, M, true>), grid_d, block_d, smem, st, p);  \
         } else {                                                                              \
@@ -796,7 +814,7 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
         const dim3 grid((unsigned)(cdiv64(p.T, 32 * FwdShape<false>::NW) * p.H * p.B)), block(64 * FwdShape<false>::NW);
 #define GO(M)                                                                                    \
     do {                                                                                         \
-        if (p.drop.thresh24) {                                                                   \
+        if (p.drop.thresh16) {                                                                   \
             set_smem(attn_bwd_dq_kernel<D, M, true>, smem);                                      \
             hipLaunchKernelGGL((attn_bwd_dq_kernel<D, M, true>), grid_d, block_d, smem, st, p);  \
         } else {                                                                                 \
@@ -809,12 +827,12 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
         OBTE_CHECK_LAUNCH("obte_attn_bwd(dq)");
     }
     {
-        const int smem = 2 * (2 * 32 * 2 * D + 256) + 32 * FwdShape<false>::NW * 2 * D + 64;   // >= the dropout variant's
+        const int smem = 2 * (2 * 32 * 2 * D + 384) + 32 * FwdShape<false>::NW * 2 * D + 64;   // >= the dropout variant's
         const dim3 grid_d((unsigned)(cdiv64(p.T, 32 * FwdShape<true>::NW) * p.H * p.B)), block_d(64 * FwdShape<true>::NW);
         const dim3 grid((unsigned)(cdiv64(p.T, 32 * FwdShape<false>::NW) * p.H * p.B)), block(64 * FwdShape<false>::NW);
 #define GO(M)                                                                                      \
     do {                                                                                           \
-        if (p.drop.thresh24) {                                                                     \
+        if (p.drop.thresh16) {                                                                     \
             set_smem(attn_bwd_dkdv_kernel<D, M, true>, smem);                                      \
             hipLaunchKernelGGL((attn_bwd_dkdv_kernel<D, M, true>), grid_d, block_d, smem, st, p);  \
         } else {                                                                                   \

@@ -185,7 +185,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     // MLP: out = x1 + dropout(hact W_mlp^T): the projection sees dy masked by the same (seed, site 3) mask
     const obte_bf16* dy_mlp = dy;
     if (drop) {
-        TRY(obte_dropout_bf16(dy, dym, M * C, d->dropout_p, d->dropout_seed, SITE_MLP, s));
+        TRY(obte_dropout_bf16(dy, dym, M * C, C, d->dropout_p, d->dropout_seed, SITE_MLP, s));
         dy_mlp = dym;
     }
     TRY(gemm(dy_mlp, d->mlp_w, dhpre, M, 4 * C, C, C, 4 * C, 1, 0, OBTE_EPI_GELU_BWD, hpre, nullptr, s));      // dhpre = (dy W_mlp) * gelu'(h): hpre holds the derivative
@@ -200,7 +200,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     // attention: x1 = x + dropout(y W_proj^T)
     const obte_bf16* dx1_proj = dx1;
     if (drop) {
-        TRY(obte_dropout_bf16(dx1, dym2, M * C, d->dropout_p, d->dropout_seed, SITE_RESID, s));
+        TRY(obte_dropout_bf16(dx1, dym2, M * C, C, d->dropout_p, d->dropout_seed, SITE_RESID, s));
         dx1_proj = dym2;
     }
     TRY(gemm(dx1_proj, d->proj_w, dyattn, M, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dy_attn = dx1 W_proj

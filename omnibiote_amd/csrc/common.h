@@ -147,27 +147,41 @@ __device__ __forceinline__ float gelu_ref_grad(float x) {
 }
 
 // ---- dropout: counter-based keep decision -------------------------------------------------------------------
-// keep(idx) is a pure function of (seed, site, element index), so forward and backward regenerate the same mask with
-// no mask tensor in memory, and a host-side restatement (tests) can reproduce it bit for bit.  Two rounds of the
-// "lowbias32" integer finaliser; an element is dropped when the top 24 bits fall below p * 2^24.
+// keep(row, col) is a pure function of (seed, site, row, col), so forward and backward regenerate the same mask with no
+// mask tensor in memory, and a host-side restatement (oracle/omnibiote_ref.py dropout_keep) reproduces it bit for bit.
+// Every dropout site is a matrix: row = token (embedding, projection outputs) or (batch, head, query) (attention
+// probabilities), col = feature or key.  Two levels, so that the expensive part is paid once per ROW and once per PAIR
+// of columns instead of once per element (the first form — two lowbias32 rounds and 64-bit index arithmetic per element —
+// made the attention kernels 2.4x slower with dropout on):
+//     rowkey = hash32(hash32(lo32(row) ^ s0) + hi32(row) * 0x9E3779B1 + s1)       once per row (per lane in attention)
+//     bits   = hash32(rowkey ^ (col >> 1))                                        once per two columns
+//     keep   = (col odd ? bits >> 16 : bits & 0xFFFF) >= thresh16                 thresh16 = round(p * 2^16)
+// hash32 is the "lowbias32" integer finaliser.  p is resolved to 2^-16; the kept values are scaled by 1 / (1 - p).
 struct DropCfg {
-    uint32_t s0, s1, thresh24;   // thresh24 == 0  <=>  dropout off
+    uint32_t s0, s1, thresh16;   // thresh16 == 0  <=>  dropout off
     float scale;                 // 1 / (1 - p)
 };
 __host__ __device__ __forceinline__ uint32_t obte_hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-__host__ __device__ __forceinline__ bool drop_keep(uint64_t idx, const DropCfg& c) {
-    uint32_t x = obte_hash32((uint32_t)idx ^ c.s0);
-    x = obte_hash32(x + (uint32_t)(idx >> 32) * 0x9E3779B1U + c.s1);
-    return (x >> 8) >= c.thresh24;
+__host__ __device__ __forceinline__ uint32_t drop_rowkey(uint64_t row, const DropCfg& c) {
+    return obte_hash32(obte_hash32((uint32_t)row ^ c.s0) + (uint32_t)(row >> 32) * 0x9E3779B1U + c.s1);
+}
+// the 32 bits that decide columns 2g and 2g+1 of a row
+__host__ __device__ __forceinline__ uint32_t drop_pair_bits(uint32_t rowkey, uint32_t g) { return obte_hash32(rowkey ^ g); }
+__host__ __device__ __forceinline__ bool drop_keep_bits(uint32_t bits, uint32_t col, const DropCfg& c) {
+    return ((col & 1u) ? (bits >> 16) : (bits & 0xFFFFu)) >= c.thresh16;
+}
+__host__ __device__ __forceinline__ bool drop_keep(uint32_t rowkey, uint32_t col, const DropCfg& c) {
+    return drop_keep_bits(drop_pair_bits(rowkey, col >> 1), col, c);
 }
 static inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) {
     DropCfg c;
     c.s0 = (uint32_t)seed ^ (site * 0x632BE5ABU);
     c.s1 = (uint32_t)(seed >> 32) + site * 0x9E3779B9U;
-    c.thresh24 = p > 0.f ? (uint32_t)((double)p * 16777216.0) : 0u;
+    c.thresh16 = p > 0.f ? (uint32_t)((double)p * 65536.0 + 0.5) : 0u;
+    if (p > 0.f && c.thresh16 == 0u) c.thresh16 = 1u;
     c.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     return c;
 }

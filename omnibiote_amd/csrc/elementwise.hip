@@ -54,19 +54,31 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
         const int c = (int)(i % cpr) * 8;
         const int64_t tok = clamp_tok(idx[r], vocab);
         bf16x8 v = *reinterpret_cast<const bf16x8*>(wte + tok * cols + c);
-        if (dc.thresh24) {
+        if (dc.thresh16) {
+            const uint32_t rk = drop_rowkey((uint64_t)r, dc);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = drop_keep((uint64_t)(r * cols + c + j), dc) ? f2bf(bf2f(v[j]) * dc.scale) : f2bf(0.f);
+            for (int jj = 0; jj < 4; ++jj) {
+                const uint32_t bits = drop_pair_bits(rk, (uint32_t)(c >> 1) + jj);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) v[2 * jj + e] = drop_keep_bits(bits, (uint32_t)e, dc) ? f2bf(bf2f(v[2 * jj + e]) * dc.scale) : f2bf(0.f);
+            }
         }
         *reinterpret_cast<bf16x8*>(out + r * cols + c) = v;
     }
 }
 
-__global__ __launch_bounds__(256) void dropout_kernel(const bf16* in, bf16* out, int64_t n8, DropCfg dc) {
+// element i*8 + j of the flat tensor is (row, column) = divmod(i*8 + j, cols); cols % 8 == 0, so a thread's 8 elements share a row
+__global__ __launch_bounds__(256) void dropout_kernel(const bf16* in, bf16* out, int64_t n8, int64_t cols, DropCfg dc) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         bf16x8 v = reinterpret_cast<const bf16x8*>(in)[i];
+        const int64_t row = (i * 8) / cols;
+        const uint32_t c = (uint32_t)((i * 8) - row * cols);
+        const uint32_t rk = drop_rowkey((uint64_t)row, dc);
+        for (int jj = 0; jj < 4; ++jj) {
+            const uint32_t bits = drop_pair_bits(rk, (c >> 1) + jj);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = drop_keep((uint64_t)(i * 8 + j), dc) ? f2bf(bf2f(v[j]) * dc.scale) : f2bf(0.f);
+            for (int e = 0; e < 2; ++e) v[2 * jj + e] = drop_keep_bits(bits, (uint32_t)e, dc) ? f2bf(bf2f(v[2 * jj + e]) * dc.scale) : f2bf(0.f);
+        }
         reinterpret_cast<bf16x8*>(out)[i] = v;
     }
 }
@@ -121,10 +133,14 @@ __global__ __launch_bounds__(128) void embed_bwd_chunk_kernel(const int64_t* __r
         int seg_start = 0;
         for (int i = 0; i < n; ++i) {
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(dout + (int64_t)s_row[i] * cols + col);
-            if (dc.thresh24) {   // gradient of the dropped output: bf16(dout * scale) where kept, as autograd would form it
+            if (dc.thresh16) {   // gradient of the dropped output: bf16(dout * scale) where kept, as autograd would form it
+                const uint32_t rk = drop_rowkey((uint64_t)s_row[i], dc);
+                for (int jj = 0; jj < 4; ++jj) {
+                    const uint32_t bits = drop_pair_bits(rk, (uint32_t)(col >> 1) + jj);
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (drop_keep((uint64_t)((int64_t)s_row[i] * cols + col + j), dc)) acc[j] += bf2f(f2bf(bf2f(v[j]) * dc.scale));
+                    for (int e = 0; e < 2; ++e)
+                        if (drop_keep_bits(bits, (uint32_t)e, dc)) acc[2 * jj + e] += bf2f(f2bf(bf2f(v[2 * jj + e]) * dc.scale));
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
@@ -454,11 +470,13 @@ extern "C" int obte_embedding_fwd(const int64_t* idx, const obte_bf16* wte, obte
     return obte_embedding_fwd_dropout(idx, wte, out, rows, cols, vocab, 0.f, 0, s);
 }
 
-extern "C" int obte_dropout_bf16(const obte_bf16* in, obte_bf16* out, int64_t n, float p, uint64_t seed, int32_t site, obte_stream s) {
+extern "C" int obte_dropout_bf16(const obte_bf16* in, obte_bf16* out, int64_t n, int64_t cols, float p, uint64_t seed, int32_t site,
+                                 obte_stream s) {
     OBTE_REQUIRE(in && out && n > 0 && n % 8 == 0, "obte_dropout_bf16: null pointer or n not a positive multiple of 8");
+    OBTE_REQUIRE(cols > 0 && cols % 8 == 0 && n % cols == 0 && cols < (1ll << 32), "obte_dropout_bf16: cols must be a multiple of 8 that divides n");
     if (check_p("obte_dropout_bf16", p)) return OBTE_EINVAL;
     hipLaunchKernelGGL(dropout_kernel, dim3(stream_grid(n / 8, 256)), dim3(256), 0, (hipStream_t)s, (const bf16*)in, (bf16*)out, n / 8,
-                       make_drop(p, seed, (uint32_t)site));
+                       cols, make_drop(p, seed, (uint32_t)site));
     OBTE_CHECK_LAUNCH("obte_dropout_bf16");
     return OBTE_OK;
 }

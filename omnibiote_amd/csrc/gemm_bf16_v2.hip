@@ -209,10 +209,16 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
                 }
             } else if (EPI == OBTE_EPI_ADD_DROPOUT) {
                 const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.aux + o);
+                const uint32_t rk = drop_rowkey((uint64_t)m, p.drop);   // dropout element = (row m, column n + j)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float t = drop_keep((uint64_t)(o + j), p.drop) ? bf2f(f2bf(bf2f(v[j]) * p.drop.scale)) : 0.f;
-                    v[j] = f2bf(bf2f(r[j]) + t);
+                for (int jj = 0; jj < 4; ++jj) {
+                    const uint32_t bits = drop_pair_bits(rk, (uint32_t)(n >> 1) + jj);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * jj + e;
+                        const float t = drop_keep_bits(bits, (uint32_t)e, p.drop) ? bf2f(f2bf(bf2f(v[j]) * p.drop.scale)) : 0.f;
+                        v[j] = f2bf(bf2f(r[j]) + t);
+                    }
                 }
             } else if (EPI == OBTE_EPI_GELU_BWD) {
                 const bf16x8 h = *reinterpret_cast<const bf16x8*>(p.aux + o);

@@ -145,10 +145,12 @@ def linear_fwd(x2d, w, epilogue=L.EPI_NONE, aux=None, alpha=1.0, dropout=None):
 
 
 def dropout(x, p, seed, site=L.SITE_USER, out=None):
-    """out = dropout(x) with the library's counter-based mask (element index = flat index); x may alias out."""
+    """out = dropout(x) with the library's counter-based mask: x is read as a matrix [numel / last dim, last dim] and
+    element (row, col) decides (include/omnibiote_hip.h, dropout); x may alias out."""
     _need(x, "x")
     out = torch.empty_like(x) if out is None else out
-    L.check(L.lib().obte_dropout_bf16(_ptr(x), _ptr(out), x.numel(), float(p), int(seed), int(site), _stream()), "obte_dropout_bf16")
+    L.check(L.lib().obte_dropout_bf16(_ptr(x), _ptr(out), x.numel(), int(x.shape[-1]), float(p), int(seed), int(site), _stream()),
+            "obte_dropout_bf16")
     return out
 
 

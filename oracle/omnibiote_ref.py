@@ -116,7 +116,7 @@ def readout(emb: torch.Tensor, weight: torch.Tensor, width_mult: float, output_m
 # --------------------------------------------------------------------------------------------------
 # dropout masks of the HIP path, restated (include/omnibiote_hip.h "dropout"; csrc/common.h drop_keep).
 # The reference uses PyTorch's generator (model.py:83-84,160,204), whose stream no other implementation can
-# reproduce; the product instead derives every mask from a counter-based hash of (seed, site, element index),
+# reproduce; the product instead derives every mask from a counter-based hash of (seed, site, row, column),
 # which this restatement mirrors bit for bit so that dropout-on parity tests can hand the oracle the same mask.
 # --------------------------------------------------------------------------------------------------
 _M32 = np.uint64(0xFFFFFFFF)
@@ -130,21 +130,30 @@ def _hash32(x: np.ndarray) -> np.ndarray:
     return x
 
 
-def dropout_keep(idx: np.ndarray, p: float, seed: int, site: int) -> np.ndarray:
-    """Boolean keep decision for element indices ``idx`` (uint64) of dropout site ``site``."""
-    idx = np.asarray(idx, dtype=np.uint64)
+def dropout_keep(rows: np.ndarray, cols: np.ndarray, p: float, seed: int, site: int) -> np.ndarray:
+    """Boolean keep decision for the elements (row, col) of dropout site ``site`` (csrc/common.h drop_rowkey / drop_keep):
+    rowkey = hash32(hash32(lo32(row) ^ s0) + hi32(row) * 0x9E3779B1 + s1); bits = hash32(rowkey ^ (col >> 1)); the element
+    owns the low (even col) or high (odd col) 16 bits, kept iff they are >= round(p * 2^16).  ``rows`` / ``cols`` broadcast."""
+    rows = np.asarray(rows, dtype=np.uint64)
+    cols = np.asarray(cols, dtype=np.uint64)
     s0 = np.uint64(((seed & 0xFFFFFFFF) ^ ((site * 0x632BE5AB) & 0xFFFFFFFF)) & 0xFFFFFFFF)
     s1 = np.uint64(((seed >> 32) + site * 0x9E3779B9) & 0xFFFFFFFF)
-    thresh = np.uint64(int(float(np.float32(p)) * 16777216.0)) if p > 0 else np.uint64(0)
-    x = _hash32((idx & _M32) ^ s0)
-    x = _hash32((x + ((idx >> np.uint64(32)) * np.uint64(0x9E3779B1) & _M32) + s1) & _M32)
-    return (x >> np.uint64(8)) >= thresh
+    thresh = np.uint64(max(int(float(np.float32(p)) * 65536.0 + 0.5), 1)) if p > 0 else np.uint64(0)
+    rk = _hash32((rows & _M32) ^ s0)
+    rk = _hash32((rk + (((rows >> np.uint64(32)) * np.uint64(0x9E3779B1)) & _M32) + s1) & _M32)
+    bits = _hash32(rk ^ (cols >> np.uint64(1)))
+    own = np.where((cols & np.uint64(1)) == 1, bits >> np.uint64(16), bits & np.uint64(0xFFFF))
+    return own >= thresh
 
 
 def dropout_scale_mask(shape, p: float, seed: int, site: int) -> torch.Tensor:
-    """fp32 tensor of ``shape`` holding 1/(1-p) where kept and 0 where dropped; element index = flat index."""
-    n = int(np.prod(shape))
-    keep = dropout_keep(np.arange(n, dtype=np.uint64), p, seed, site)
+    """fp32 tensor of ``shape`` holding 1/(1-p) where kept and 0 where dropped.  The tensor is read as a matrix: col = the
+    last dimension, row = the flat index of the leading dimensions — (token, feature) for activations, ((b*H + h)*T + q,
+    key) for attention probabilities of shape (B, H, T, T)."""
+    shape = tuple(int(v) for v in shape)
+    ncol = shape[-1]
+    nrow = int(np.prod(shape[:-1])) if len(shape) > 1 else 1
+    keep = dropout_keep(np.arange(nrow, dtype=np.uint64)[:, None], np.arange(ncol, dtype=np.uint64)[None, :], p, seed, site)
     scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
     return torch.from_numpy(np.where(keep, scale, np.float32(0.0)).astype(np.float32).reshape(shape))
 

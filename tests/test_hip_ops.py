@@ -682,8 +682,11 @@ def test_dropout_mask_matches_restatement_and_rate():
     n, p = 1 << 20, 0.1
     x = torch.ones(n, dtype=BF, device=DEV)
     y = ops().dropout(x, p, SEED, site=7).float().cpu()
-    mask = R.dropout_scale_mask((n,), p, SEED, 7)
+    mask = R.dropout_scale_mask((n,), p, SEED, 7)           # a 1-D tensor is one row of n columns
     assert torch.equal(y, mask.to(BF).float())
+    y2 = ops().dropout(x.view(1 << 10, 1 << 10), p, SEED, site=7).float().cpu()      # the same buffer as a 1024 x 1024 matrix
+    assert torch.equal(y2, R.dropout_scale_mask((1 << 10, 1 << 10), p, SEED, 7).to(BF).float())
+    assert not torch.equal(y2.flatten(), y)
     assert abs((y != 0).float().mean().item() - 0.9) < 2e-3
     z = ops().dropout(x, p, SEED + 1, site=7).float().cpu()
     assert not torch.equal(y, z)

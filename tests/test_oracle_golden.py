@@ -185,3 +185,34 @@ def test_oracle_training_trajectory_tracks_the_reference_run(golden_dir):
         dd = np.abs(g["final_manual/" + k] - g["final_flash/" + k])
         # bar: the spread between the reference's own two runs (dd), plus two bf16 ulps at 1.0 spread over the tensor
         assert d.mean() <= 3.0 * dd.mean() + 2e-3 and d.max() <= 0.06, (k, d.mean(), d.max(), dd.mean(), dd.max())
+
+
+def test_dropout_generator_statistics():
+    """The counter-based dropout generator (restated in the oracle bit for bit from csrc/common.h: one hash per row, one per
+    pair of columns, 16 bits per element) must behave like independent Bernoulli draws at the sizes the path uses it:
+    overall rate, per-row and per-column rates, no correlation between the two elements of a pair, between neighbouring
+    pairs, neighbouring rows, sites or seeds."""
+    p, rows, cols = 0.1, 2048, 1024
+    keep = R.dropout_keep(np.arange(rows, dtype=np.uint64)[:, None], np.arange(cols, dtype=np.uint64)[None, :], p, 0x1234_5678_9ABC, 1)
+    k = keep.astype(np.float64)
+    n = rows * cols
+    sd = np.sqrt(p * (1 - p))
+    assert abs(k.mean() - (1 - p)) < 4 * sd / np.sqrt(n)
+    assert np.abs(k.mean(axis=1) - (1 - p)).max() < 5.5 * sd / np.sqrt(cols)       # every row
+    assert np.abs(k.mean(axis=0) - (1 - p)).max() < 5.5 * sd / np.sqrt(rows)       # every column
+    z = (k - k.mean()) / k.std()
+
+    def corr(a, b):
+        return float((a * b).mean())
+    bound = 5.0 / np.sqrt(n / 2)
+    assert abs(corr(z[:, 0::2], z[:, 1::2])) < bound          # the two halves of one 32-bit hash
+    assert abs(corr(z[:, 1:-1:2], z[:, 2::2])) < bound        # neighbouring pairs
+    assert abs(corr(z[:-1], z[1:])) < bound                   # neighbouring rows
+    other_site = R.dropout_keep(np.arange(rows, dtype=np.uint64)[:, None], np.arange(cols, dtype=np.uint64)[None, :], p, 0x1234_5678_9ABC, 2)
+    other_seed = R.dropout_keep(np.arange(rows, dtype=np.uint64)[:, None], np.arange(cols, dtype=np.uint64)[None, :], p, 0x1234_5678_9ABD, 1)
+    for o in (other_site, other_seed):
+        zo = (o - o.mean()) / o.std()
+        assert abs(corr(z, zo)) < bound
+    # rows beyond 2^32 use the high word
+    hi = R.dropout_keep(np.array([[5], [5 + (1 << 32)]], dtype=np.uint64), np.arange(4096, dtype=np.uint64)[None, :], p, 7, 0)
+    assert (hi[0] != hi[1]).mean() > 0.1
