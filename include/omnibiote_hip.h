@@ -160,6 +160,7 @@ typedef struct {
     const int32_t* key_ranges; const obte_bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
     int64_t B, T; int32_t n_head, head_dim; float scale;
     float dropout_p; uint64_t dropout_seed;     /* attention-probability dropout (site 1); p = 0 disables */
+    const int32_t* ranges_exact;                /* nullable; with mask + key_ranges: the device flag obte_mask_bounds wrote */
 } obte_attn_fwd_args;
 int obte_attn_fwd(const obte_attn_fwd_args* a, obte_stream s);
 
@@ -174,6 +175,7 @@ typedef struct {
     int64_t B, T; int32_t n_head, head_dim; float scale;
     float dropout_p; uint64_t dropout_seed;     /* must equal the forward call's */
     const int32_t* query_bounds;                /* nullable; with a dense mask: int32 [B,T,2] per KEY, see obte_mask_bounds */
+    const int32_t* ranges_exact;                /* nullable; with mask + key_ranges + query_bounds: obte_mask_bounds' flag */
 } obte_attn_bwd_args;
 int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s);
 
@@ -186,10 +188,16 @@ int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s);
  *                       kind count for every key).
  * Pass key_bounds as `key_ranges` TOGETHER with `mask` to obte_attn_fwd / obte_attn_bwd / the block descriptor (a mask
  * with key_ranges means "dense arithmetic, ranges only bound the loops"), and query_bounds in the field of that name.
+ * ranges_exact (nullable, int32 [1] on the device; needs col_scratch int32 [B*T]): set to 1 iff the mask IS a range mask —
+ * every row's allowed keys are one contiguous run of exact zeros, the same for all heads, everything else <= -3e4, and
+ * every key's queries are one contiguous run too (block-diagonal document masks, key-padding masks).  Passed on in the
+ * `ranges_exact` fields, it lets the attention entry points run the range kernels for such a mask: both representations are
+ * launched and the kernels of the one that does not apply return at once, so the host never reads the flag.
  * row_scratch: uint8 [B*T].  Replaces nothing in the reference (training/train_encoder.py:31-57 builds the mask, and
  * model.py:115-146 hands it to SDPA whole). */
 int obte_mask_bounds(const obte_bf16* mask, int64_t mask_sb, int64_t mask_sh, int64_t mask_sq, int64_t B, int32_t n_head,
-                     int64_t T, int32_t* key_bounds, int32_t* query_bounds, uint8_t* row_scratch, obte_stream s);
+                     int64_t T, int32_t* key_bounds, int32_t* query_bounds, uint8_t* row_scratch, int32_t* ranges_exact,
+                     int32_t* col_scratch, obte_stream s);
 
 /* ---- token embedding (training/model.py:203,241) ------------------------------------------------------------
  * fwd: out[r,:] = wte[idx[r],:].  bwd: dwte (dense [V,C], fully written) = scatter-add of dout rows, summed in
@@ -280,6 +288,7 @@ typedef struct {
      * partial buffers (see obte_layernorm_bwd_partial); ln_partial_mode 0 = off, else OBTE_LN_PARTIAL_*.  With FIRST / MORE
      * dln1_w / dln2_w are not written. */
     float *ln1_partials, *ln2_partials; int32_t ln_partial_mode;
+    const int32_t* ranges_exact;              /* nullable: obte_mask_bounds' flag for a dense mask (see obte_mask_bounds) */
 } obte_block_desc;
 int64_t obte_block_act_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head);
 int64_t obte_block_bwd_ws_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head);

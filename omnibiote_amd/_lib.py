@@ -30,7 +30,7 @@ class AttnFwdArgs(C.Structure):
                 ("key_ranges", C.c_void_p), ("mask", C.c_void_p),
                 ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
                 ("B", C.c_int64), ("T", C.c_int64), ("n_head", C.c_int32), ("head_dim", C.c_int32), ("scale", C.c_float),
-                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64)]
+                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("ranges_exact", C.c_void_p)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -39,7 +39,7 @@ class AttnBwdArgs(C.Structure):
                 ("key_ranges", C.c_void_p), ("mask", C.c_void_p),
                 ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
                 ("B", C.c_int64), ("T", C.c_int64), ("n_head", C.c_int32), ("head_dim", C.c_int32), ("scale", C.c_float),
-                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("query_bounds", C.c_void_p)]
+                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("query_bounds", C.c_void_p), ("ranges_exact", C.c_void_p)]
 
 
 class BlockDesc(C.Structure):
@@ -50,7 +50,8 @@ class BlockDesc(C.Structure):
                 ("key_ranges", C.c_void_p), ("mask", C.c_void_p),
                 ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
                 ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("query_bounds", C.c_void_p),
-                ("ln1_partials", C.c_void_p), ("ln2_partials", C.c_void_p), ("ln_partial_mode", C.c_int32)]
+                ("ln1_partials", C.c_void_p), ("ln2_partials", C.c_void_p), ("ln_partial_mode", C.c_int32),
+                ("ranges_exact", C.c_void_p)]
 
 
 LN_PARTIAL_FIRST, LN_PARTIAL_MORE, LN_PARTIAL_LAST = 1, 2, 3
@@ -88,7 +89,7 @@ SYMBOLS = {
     "obte_rope_qk_inplace": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, c_stream]),
     "obte_attn_fwd": (C.c_int, [C.POINTER(AttnFwdArgs), c_stream]),
     "obte_mask_bounds": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, c_stream]),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
     "obte_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), c_stream]),
     "obte_embedding_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int64, c_stream]),
     "obte_embedding_fwd_dropout": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_uint64, c_stream]),

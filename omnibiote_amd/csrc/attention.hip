@@ -33,7 +33,9 @@ struct AttnParams {
     const bf16* o_in; const bf16* d_o; const float* lse_in; float* delta; bf16* dqkv;   // backward
     const float* rope_cos; const float* rope_sin;               // backward: inverse RoPE on dq, dk (nullable)
     const int32_t* key_ranges; const bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
-    const int32_t* query_bounds;   // dense mode only: per-key [first, last+1) query bounds (obte_mask_bounds), nullable
+    const int32_t* query_bounds;   // per-key [first, last+1) query bounds (obte_mask_bounds), nullable: loop bounds in dense mode,
+                                   // the exact query range of every key in range mode (else the mask is taken to be symmetric)
+    const int32_t* gate; int gate_expect;   // nullable device flag: the kernel runs only if *gate == gate_expect (see launch_fwd)
     int64_t B, T; int H; float scale;
     DropCfg drop;   // attention-probability dropout (site 1); thresh16 == 0: off
     int max_tiles;  // timing-only diagnostic (OBTE_ATTN_DEBUG=tiles:N): every workgroup stops after N tiles (results are wrong; 0 = off)
@@ -206,6 +208,7 @@ template <bool DROP> struct FwdShape { static constexpr int NW = 8; static const
 template <int D, int MODE, bool DROP>
 __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_fwd_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.gate && __builtin_amdgcn_readfirstlane(*p.gate) != p.gate_expect) return;   // the other mask representation's launch does the work
     constexpr int NW = FwdShape<DROP>::NW;
     constexpr int TB = 64 * 2 * D;  // bytes of one 64-row tile
     constexpr int NS = D / 16;      // k-steps over the head dim
@@ -417,6 +420,7 @@ __device__ __forceinline__ void rope_inv4(float (&g)[4], const float* cos_t, con
 template <int D, int MODE, bool DROP>
 __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dq_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.gate && __builtin_amdgcn_readfirstlane(*p.gate) != p.gate_expect) return;   // the other mask representation's launch does the work
     constexpr int NW = FwdShape<DROP>::NW;
     constexpr int TB = 64 * 2 * D;
     constexpr int NS = D / 16, ND = D / 32;
@@ -586,6 +590,7 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dq_kernel
 template <int D, int MODE, bool DROP>
 __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.gate && __builtin_amdgcn_readfirstlane(*p.gate) != p.gate_expect) return;   // the other mask representation's launch does the work
     constexpr int NW = FwdShape<DROP>::NW;
     constexpr int QB = 32 * 2 * D;  // bytes of one 32-row tile
     constexpr int NS = D / 16, ND = D / 32;
@@ -618,8 +623,9 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kern
     // by symmetry of the mask, the queries that see this key are the keys this position sees as a query
     int qs = 0, qe = T;
     if (MODE == MASK_RANGES) {
-        qs = max(p.key_ranges[(b * T + key_c) * 2], 0);
-        qe = min(p.key_ranges[(b * T + key_c) * 2 + 1], T);
+        const int32_t* src = p.query_bounds ? p.query_bounds : p.key_ranges;   // no per-key table: symmetric mask
+        qs = max(src[(b * T + key_c) * 2], 0);
+        qe = min(src[(b * T + key_c) * 2 + 1], T);
     }
     if (!k_ok) { qs = 0; qe = 0; }
     int lo = k_ok ? qs : T, hi = k_ok ? qe : 0;
@@ -869,6 +875,31 @@ static int check_common(const char* who, const void* qkv, int64_t B, int64_t T, 
     return OBTE_OK;
 }
 
+// A dense additive mask that obte_mask_bounds found to be EXACTLY a range mask (ranges_exact[0] == 1 on the device: every
+// row's allowed keys are one contiguous run of zeros shared by all heads, every key's queries one contiguous run) is served
+// by the range kernels, which skip the element-by-element mask reads (forward 85 -> 55 us, backward 353 -> 174 us at the
+// hot-path shape).  The host cannot know the flag without a sync, so BOTH representations are launched and the kernels of
+// the one that does not apply return at once (AttnParams::gate).  Every mask the reference's trainer builds qualifies
+// (train_encoder.py:25-57), and so do key-padding masks; any other additive mask takes the dense kernels as before.
+template <int D>
+int launch_fwd_gated(AttnParams p, const int32_t* flag, hipStream_t st) {
+    AttnParams pr = p;
+    pr.mask = nullptr; pr.gate = flag; pr.gate_expect = 1;
+    int rc = launch_fwd<D>(pr, MASK_RANGES, st);
+    if (rc != OBTE_OK) return rc;
+    p.gate = flag; p.gate_expect = 0;
+    return launch_fwd<D>(p, MASK_DENSE, st);
+}
+template <int D>
+int launch_bwd_gated(AttnParams p, const int32_t* flag, hipStream_t st) {
+    AttnParams pr = p;
+    pr.mask = nullptr; pr.gate = flag; pr.gate_expect = 1;   // pr.query_bounds: the exact per-key query ranges
+    int rc = launch_bwd<D>(pr, MASK_RANGES, st);
+    if (rc != OBTE_OK) return rc;
+    p.gate = flag; p.gate_expect = 0;
+    return launch_bwd<D>(p, MASK_DENSE, st);
+}
+
 extern "C" int obte_attn_fwd(const obte_attn_fwd_args* a, obte_stream s) {
     OBTE_REQUIRE(a, "obte_attn_fwd: null args");
     int rc = check_common("obte_attn_fwd", a->qkv, a->B, a->T, a->n_head, a->head_dim, a->key_ranges, a->mask);
@@ -883,7 +914,10 @@ extern "C" int obte_attn_fwd(const obte_attn_fwd_args* a, obte_stream s) {
     p.max_tiles = debug_max_tiles();
     const int mode = mask_mode(a->key_ranges, a->mask);
     const int prof = obte_prof_begin((hipStream_t)s, 100, a->B * a->n_head, a->T, a->head_dim);
-    rc = a->head_dim == 128 ? launch_fwd<128>(p, mode, (hipStream_t)s) : launch_fwd<64>(p, mode, (hipStream_t)s);
+    if (mode == MASK_DENSE && a->key_ranges && a->ranges_exact)
+        rc = a->head_dim == 128 ? launch_fwd_gated<128>(p, a->ranges_exact, (hipStream_t)s) : launch_fwd_gated<64>(p, a->ranges_exact, (hipStream_t)s);
+    else
+        rc = a->head_dim == 128 ? launch_fwd<128>(p, mode, (hipStream_t)s) : launch_fwd<64>(p, mode, (hipStream_t)s);
     obte_prof_end(prof, (hipStream_t)s);
     return rc;
 }
@@ -904,7 +938,10 @@ extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
     p.max_tiles = debug_max_tiles();
     const int mode = mask_mode(a->key_ranges, a->mask);
     const int prof = obte_prof_begin((hipStream_t)s, 101, a->B * a->n_head, a->T, a->head_dim);
-    rc = a->head_dim == 128 ? launch_bwd<128>(p, mode, (hipStream_t)s) : launch_bwd<64>(p, mode, (hipStream_t)s);
+    if (mode == MASK_DENSE && a->key_ranges && a->query_bounds && a->ranges_exact)
+        rc = a->head_dim == 128 ? launch_bwd_gated<128>(p, a->ranges_exact, (hipStream_t)s) : launch_bwd_gated<64>(p, a->ranges_exact, (hipStream_t)s);
+    else
+        rc = a->head_dim == 128 ? launch_bwd<128>(p, mode, (hipStream_t)s) : launch_bwd<64>(p, mode, (hipStream_t)s);
     obte_prof_end(prof, (hipStream_t)s);
     return rc;
 }
@@ -914,68 +951,98 @@ extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
 namespace {
 constexpr float MASKING = -3.0e4f;   // an additive entry at or below this is "masked": exp() of it underflows to 0
 
-// one wave per (b, q) row: [first, last+1) over the keys any head allows; (0,T) and row_full = 1 if some head allows none
+// one wave per (b, q) row: [first, last+1) over the keys any head allows; (0,T) and row_full = 1 if some head allows none.
+// exact (nullable): cleared unless the row's allowed keys are, for every head alike, one contiguous run of exact zeros.
 __global__ __launch_bounds__(256) void mask_row_bounds_kernel(const bf16* mask, int64_t sb, int64_t sh, int64_t sq, int64_t B, int H,
-                                                               int64_t T, int32_t* kb, uint8_t* row_full) {
+                                                               int64_t T, int32_t* kb, uint8_t* row_full, int32_t* exact) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     if (row >= B * T) return;
     const int64_t b = row / T, q = row % T;
     const int heads = sh == 0 ? 1 : H;
     int lo = (int)T, hi = 0;
-    bool full = false;
+    bool full = false, is_range = true;
+    int l0 = 0, u0 = 0;
     for (int h = 0; h < heads; ++h) {
         const bf16* r = mask + b * sb + h * sh + q * sq;
-        int l = (int)T, u = 0;
+        int l = (int)T, u = 0, cnt = 0, nonzero = 0;
         for (int64_t k = lane; k < T; k += 64) {
-            if (bf2f(r[k]) > MASKING) { l = min(l, (int)k); u = max(u, (int)k + 1); }
+            const float v = bf2f(r[k]);
+            if (v > MASKING) { l = min(l, (int)k); u = max(u, (int)k + 1); ++cnt; nonzero += v != 0.f; }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { l = min(l, __shfl_xor(l, o, 64)); u = max(u, __shfl_xor(u, o, 64)); }
+        for (int o = 32; o > 0; o >>= 1) {
+            l = min(l, __shfl_xor(l, o, 64)); u = max(u, __shfl_xor(u, o, 64));
+            cnt += __shfl_xor(cnt, o, 64); nonzero += __shfl_xor(nonzero, o, 64);
+        }
         if (u == 0) full = true;
+        if (u == 0 || cnt != u - l || nonzero != 0) is_range = false;
+        if (h == 0) { l0 = l; u0 = u; } else if (l != l0 || u != u0) is_range = false;
         lo = min(lo, l); hi = max(hi, u);
     }
     if (full) { lo = 0; hi = (int)T; }
-    if (lane == 0) { kb[row * 2] = lo; kb[row * 2 + 1] = hi; row_full[row] = full ? 1 : 0; }
+    if (lane == 0) {
+        kb[row * 2] = lo; kb[row * 2 + 1] = hi; row_full[row] = full ? 1 : 0;
+        if (exact && !is_range) *exact = 0;   // plain store of the same value from every violating row
+    }
 }
 
-// thread per (b, key), grid.y chunks of 64 queries: [first, last+1) over the queries that allow the key (or are "full" rows)
+// thread per (b, key), grid.y chunks of 64 queries: [first, last+1) over the queries that allow the key (or are "full" rows);
+// cnt (nullable): the number of such queries, for the contiguity check of mask_col_check_kernel
 __global__ __launch_bounds__(256) void mask_col_bounds_kernel(const bf16* mask, int64_t sb, int64_t sh, int64_t sq, int64_t B, int H,
-                                                               int64_t T, const uint8_t* row_full, int32_t* qb) {
+                                                               int64_t T, const uint8_t* row_full, int32_t* qb, int32_t* cnt) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t b = blockIdx.z;
     if (k >= T) return;
     const int heads = sh == 0 ? 1 : H;
     const int64_t q0 = (int64_t)blockIdx.y * 64, q1 = min(q0 + 64, T);
-    int lo = (int)T, hi = 0;
+    int lo = (int)T, hi = 0, n = 0;
     for (int64_t q = q0; q < q1; ++q) {
         bool ok = row_full[b * T + q] != 0;
         for (int h = 0; h < heads && !ok; ++h) ok = bf2f(mask[b * sb + h * sh + q * sq + k]) > MASKING;
-        if (ok) { lo = min(lo, (int)q); hi = max(hi, (int)q + 1); }
+        if (ok) { lo = min(lo, (int)q); hi = max(hi, (int)q + 1); ++n; }
     }
     if (hi > 0) {
         atomicMin(&qb[(b * T + k) * 2], lo);
         atomicMax(&qb[(b * T + k) * 2 + 1], hi);
+        if (cnt) atomicAdd(&cnt[b * T + k], n);
     }
 }
-__global__ void mask_col_init_kernel(int32_t* qb, int64_t n, int T) {
+__global__ void mask_col_init_kernel(int32_t* qb, int32_t* cnt, int32_t* exact, int64_t n, int T) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) { qb[i * 2] = T; qb[i * 2 + 1] = 0; }   // a key no query can see: empty [T, 0)
+    if (i < n) { qb[i * 2] = T; qb[i * 2 + 1] = 0; if (cnt) cnt[i] = 0; }   // a key no query can see: empty [T, 0)
+    if (i == 0 && exact) *exact = 1;
+}
+// every key's queries must be one contiguous run as well (the dK/dV kernel walks [first, last+1) of its key)
+__global__ void mask_col_check_kernel(const int32_t* qb, const int32_t* cnt, int32_t* exact, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const int lo = qb[i * 2], hi = qb[i * 2 + 1];
+        if (cnt[i] != (hi > lo ? hi - lo : 0)) *exact = 0;
+    }
 }
 }  // namespace
 
 extern "C" int obte_mask_bounds(const obte_bf16* mask, int64_t mask_sb, int64_t mask_sh, int64_t mask_sq, int64_t B, int32_t n_head,
-                                int64_t T, int32_t* key_bounds, int32_t* query_bounds, uint8_t* row_scratch, obte_stream s) {
+                                int64_t T, int32_t* key_bounds, int32_t* query_bounds, uint8_t* row_scratch, int32_t* ranges_exact,
+                                int32_t* col_scratch, obte_stream s) {
     OBTE_REQUIRE(mask && key_bounds && query_bounds && row_scratch, "obte_mask_bounds: null pointer");
+    OBTE_REQUIRE(!ranges_exact || col_scratch, "obte_mask_bounds: ranges_exact needs col_scratch (int32 [B*T])");
     OBTE_REQUIRE(B > 0 && T > 0 && n_head > 0 && B < 65536 && T < (1 << 24), "obte_mask_bounds: bad B/T/H");
     hipStream_t st = (hipStream_t)s;
-    hipLaunchKernelGGL(mask_row_bounds_kernel, dim3((unsigned)cdiv64(B * T, 4)), dim3(256), 0, st, (const bf16*)mask, mask_sb, mask_sh, mask_sq, B,
-                       (int)n_head, T, key_bounds, row_scratch);
-    OBTE_CHECK_LAUNCH("obte_mask_bounds(rows)");
-    hipLaunchKernelGGL(mask_col_init_kernel, dim3((unsigned)cdiv64(B * T, 256)), dim3(256), 0, st, query_bounds, B * T, (int)T);
+    int32_t* cnt = ranges_exact ? col_scratch : nullptr;
+    hipLaunchKernelGGL(mask_col_init_kernel, dim3((unsigned)cdiv64(B * T, 256)), dim3(256), 0, st, query_bounds, cnt, ranges_exact, B * T, (int)T);
     OBTE_CHECK_LAUNCH("obte_mask_bounds(init)");
+    hipLaunchKernelGGL(mask_row_bounds_kernel, dim3((unsigned)cdiv64(B * T, 4)), dim3(256), 0, st, (const bf16*)mask, mask_sb, mask_sh, mask_sq, B,
+                       (int)n_head, T, key_bounds, row_scratch, ranges_exact);
+    OBTE_CHECK_LAUNCH("obte_mask_bounds(rows)");
     hipLaunchKernelGGL(mask_col_bounds_kernel, dim3((unsigned)cdiv64(T, 256), (unsigned)cdiv64(T, 64), (unsigned)B), dim3(256), 0, st,
-                       (const bf16*)mask, mask_sb, mask_sh, mask_sq, B, (int)n_head, T, (const uint8_t*)row_scratch, query_bounds);
+                       (const bf16*)mask, mask_sb, mask_sh, mask_sq, B, (int)n_head, T, (const uint8_t*)row_scratch, query_bounds, cnt);
     OBTE_CHECK_LAUNCH("obte_mask_bounds(columns)");
+    if (ranges_exact) {
+        hipLaunchKernelGGL(mask_col_check_kernel, dim3((unsigned)cdiv64(B * T, 256)), dim3(256), 0, st, (const int32_t*)query_bounds,
+                           (const int32_t*)cnt, ranges_exact, B * T);
+        OBTE_CHECK_LAUNCH("obte_mask_bounds(column check)");
+    }
     return OBTE_OK;
 }

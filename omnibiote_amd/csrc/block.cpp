@@ -135,6 +135,7 @@ extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte
     af.mask_sb = d->mask_sb; af.mask_sh = d->mask_sh; af.mask_sq = d->mask_sq;
     af.B = d->B; af.T = d->T; af.n_head = H; af.head_dim = hs; af.scale = 8.0f / (float)C;  // model.py:119
     af.dropout_p = d->dropout_p; af.dropout_seed = d->dropout_seed;
+    af.ranges_exact = d->ranges_exact;
     TRY(obte_attn_fwd(&af, s));
     TRY(gemm(yat, d->proj_w, x1, M, C, C, C, C, 1, 1, OBTE_EPI_ADD, x, nullptr, s, nullptr, 0, d->dropout_p, d->dropout_seed, SITE_RESID));
     TRY(obte_layernorm_fwd(x1, d->ln2_w, h2, mean2, rstd2, M, C, 1e-5f, s));
@@ -210,6 +211,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     ab.rope_cos = d->rope_cos; ab.rope_sin = d->rope_sin;
     ab.key_ranges = d->key_ranges; ab.mask = d->mask; ab.mask_sb = d->mask_sb; ab.mask_sh = d->mask_sh; ab.mask_sq = d->mask_sq;
     ab.query_bounds = d->query_bounds;
+    ab.ranges_exact = d->ranges_exact;
     ab.B = d->B; ab.T = d->T; ab.n_head = H; ab.head_dim = hs; ab.scale = 8.0f / (float)C;
     ab.dropout_p = d->dropout_p; ab.dropout_seed = d->dropout_seed;
     TRY(obte_attn_bwd(&ab, s));

@@ -222,12 +222,13 @@ class MaskSpec:
     """How a mask reaches the kernels: per-query key ranges (int32 [B,T,2]) or a dense additive bf16 tensor
     (B, H|1, T, T), possibly an expand() view with stride-0 heads, last dim contiguous."""
 
-    __slots__ = ("ranges", "dense", "sb", "sh", "sq", "qbounds")
+    __slots__ = ("ranges", "dense", "sb", "sh", "sq", "qbounds", "exact")
 
-    def __init__(self, ranges=None, dense=None, qbounds=None):
+    def __init__(self, ranges=None, dense=None, qbounds=None, exact=None):
         """With ``dense``: ``ranges`` / ``qbounds`` are the optional loop bounds of obte_mask_bounds (per query / per key);
-        the dense values still decide every weight."""
-        self.ranges, self.dense, self.qbounds = ranges, dense, qbounds
+        the dense values still decide every weight — unless ``exact`` (obte_mask_bounds' device flag) says the mask IS a
+        range mask, in which case the range kernels serve it (include/omnibiote_hip.h, obte_mask_bounds)."""
+        self.ranges, self.dense, self.qbounds, self.exact = ranges, dense, qbounds, exact
         self.sb = self.sh = self.sq = 0
         if dense is not None:
             self.sb, self.sh, self.sq = dense.stride(0), dense.stride(1), dense.stride(2)
@@ -240,9 +241,11 @@ class MaskSpec:
         kb = torch.empty((B, T, 2), dtype=torch.int32, device=m.device)
         qb = torch.empty((B, T, 2), dtype=torch.int32, device=m.device)
         scratch = torch.empty((B * T,), dtype=torch.uint8, device=m.device)
+        exact = torch.empty((1,), dtype=torch.int32, device=m.device)
+        counts = torch.empty((B * T,), dtype=torch.int32, device=m.device)
         L.check(L.lib().obte_mask_bounds(_ptr(m), m.stride(0), m.stride(1), m.stride(2), B, H, T, _ptr(kb), _ptr(qb), _ptr(scratch),
-                                         _stream()), "obte_mask_bounds")
-        return MaskSpec(ranges=kb, dense=m, qbounds=qb)
+                                         _ptr(exact), _ptr(counts), _stream()), "obte_mask_bounds")
+        return MaskSpec(ranges=kb, dense=m, qbounds=qb, exact=exact)
 
     @staticmethod
     def from_user(attn_mask, B, T, H, device):
@@ -286,7 +289,7 @@ def attn_fwd(qkv, B, T, H, hs, scale, mask: Optional[MaskSpec] = None, dropout_p
     o = torch.empty((B, T, H * hs), dtype=bf16, device=qkv.device)
     lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
     a = L.AttnFwdArgs(_ptr(qkv), _ptr(o), _ptr(lse), _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq,
-                      B, T, H, hs, float(scale), float(dropout_p), int(dropout_seed))
+                      B, T, H, hs, float(scale), float(dropout_p), int(dropout_seed), _ptr(mask.exact))
     L.check(L.lib().obte_attn_fwd(C.byref(a), _stream()), "obte_attn_fwd")
     return o, lse
 
@@ -299,7 +302,7 @@ def attn_bwd(qkv, o, d_o, lse, B, T, H, hs, scale, mask: Optional[MaskSpec] = No
     cos, sin = rope if rope is not None else (None, None)
     a = L.AttnBwdArgs(_ptr(qkv), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(delta), _ptr(dqkv), _ptr(cos), _ptr(sin),
                       _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq, B, T, H, hs, float(scale),
-                      float(dropout_p), int(dropout_seed), _ptr(mask.qbounds))
+                      float(dropout_p), int(dropout_seed), _ptr(mask.qbounds), _ptr(mask.exact))
     L.check(L.lib().obte_attn_bwd(C.byref(a), _stream()), "obte_attn_bwd")
     return dqkv
 
@@ -412,7 +415,7 @@ def _block_desc(B, T, Cc, H, params, rope, mask: MaskSpec, dropout_p=0.0, dropou
     p1, p2 = ln_partials if ln_partials is not None else (None, None)
     return L.BlockDesc(B, T, Cc, H, _ptr(ln1), _ptr(attn_w), _ptr(proj_w), _ptr(ln2), _ptr(fc_w), _ptr(mlp_w),
                        _ptr(rope[0]), _ptr(rope[1]), _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq,
-                       float(dropout_p), int(dropout_seed), _ptr(mask.qbounds), _ptr(p1), _ptr(p2), int(ln_partial_mode))
+                       float(dropout_p), int(dropout_seed), _ptr(mask.qbounds), _ptr(p1), _ptr(p2), int(ln_partial_mode), _ptr(mask.exact))
 
 
 def block_fwd(x, params, rope, H, mask: MaskSpec, dropout_p=0.0, dropout_seed=0):

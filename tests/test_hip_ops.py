@@ -878,3 +878,58 @@ def test_fused_adamw_reference_rounding_is_torch_adamw_on_bf16_tensors():
     print("fused AdamW (reference rounding) vs torch.optim.AdamW on bf16 CPU tensors:", same, "of", total, "elements identical; worst / bar:", worst)
     assert max(worst.values()) <= 1.0, worst
     assert same >= 0.999 * total, (same, total)
+
+
+@pytest.mark.parametrize("kind,expect", [("block_diagonal", 1), ("key_padding", 1), ("additive_values", 0), ("per_head", 0),
+                                         ("hole", 0), ("fully_masked_row", 0)])
+def test_dense_mask_that_is_a_range_mask_takes_the_range_kernels(kind, expect):
+    """obte_mask_bounds decides on the device whether a dense additive mask IS a range mask (contiguous runs of exact zeros,
+    all heads alike, every key's queries contiguous too); if so the range kernels serve it, else the dense ones — both are
+    launched and one set returns at once.  Whatever the route, forward and backward must match the oracle, and the flag must
+    say what the mask is.  key_padding is NOT symmetric: it exercises the per-key query ranges of the dK/dV kernel."""
+    B, H, T, hs = 2, 2, 192, 64
+    C = H * hs
+    scale = 8.0 / C
+    qkv, q, k, v = _attn_case(B, T, H, hs, seed=31)
+    NEG = -1e9
+    m = torch.full((B, H, T, T), NEG)
+    if kind == "block_diagonal":
+        tokens = np.random.default_rng(1).integers(20, 100, size=(B, T))
+        tokens[0, [50, 120]] = R.EOS_TOKEN
+        tokens[1, [7, 100, 150]] = R.EOS_TOKEN
+        m = _blocks_to_masks(tokens, T)[0].unsqueeze(1).expand(B, H, T, T).clone()
+    elif kind == "key_padding":
+        for b, n in enumerate((150, 77)):
+            m[b, :, :, :n] = 0.0
+    elif kind == "additive_values":
+        m[:] = 0.0
+        m[:, :, :, 100:] = NEG
+        m[:, :, 5, 10] = -0.5
+    elif kind == "per_head":
+        m[:, 0, :, :100] = 0.0
+        m[:, 1, :, :120] = 0.0
+    elif kind == "hole":
+        m[:, :, :, :150] = 0.0
+        m[:, :, 30, 60:70] = NEG
+    elif kind == "fully_masked_row":
+        m[:, :, :, :150] = 0.0
+        m[0, :, 3, :] = NEG
+    o = ops()
+    md = m.to(BF).to(DEV)
+    if kind in ("block_diagonal", "key_padding", "hole"):
+        md = md[:, :1].expand(B, H, T, T)            # the reference's stride-0 head view (train_encoder.py:292)
+    spec = o.MaskSpec.from_user(md, B, T, H, DEV)
+    assert int(spec.exact.item()) == expect, kind
+    qf, kf, vf = q.requires_grad_(True), k.requires_grad_(True), v.requires_grad_(True)
+    ref = R.attention(qf, kf, vf, scale, m.to(BF).float())
+    d_o = rnd(B, T, C, seed=98)
+    ref.backward(d_o.reshape(B, T, H, hs).transpose(1, 2).float())
+    got, lse = o.attn_fwd(qkv.to(DEV), B, T, H, hs, scale, spec)
+    rows_ok = torch.ones(B, T, dtype=torch.bool)
+    if kind == "fully_masked_row":
+        rows_ok[0, 3] = False                         # uniform softmax over raw scores there: forward checked, backward row excluded
+    close(got, ref.transpose(1, 2).reshape(B, T, C), atol=6e-3, what=f"{kind} fwd")
+    dqkv = o.attn_bwd(qkv.to(DEV), got, d_o.to(DEV), lse, B, T, H, hs, scale, spec)
+    dref = torch.cat([g.transpose(1, 2).reshape(B, T, C) for g in (qf.grad, kf.grad, vf.grad)], dim=2)
+    if kind != "fully_masked_row":
+        close(dqkv, dref, atol=1.5e-2, rtol=2.0 ** -6, what=f"{kind} bwd")
