@@ -31,7 +31,7 @@ def main(fetch_csv, write_csv, out):
            "read_bytes_per_launch": 2.0 * fetch_kib * 1024 / calls, "write_bytes_per_launch": write_kib * 1024 / calls,
            "traffic_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024 / calls,
            "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; separate --pmc passes",
-           "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_roofline --pipeline_streams 1 --plan_cache profiles/r01_final_gemm_plans_small.json"}
+           "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_roofline --pipeline_streams 1 --plan_cache plans.json (tools/profile_pmc_bench.sh)"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
