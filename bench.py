@@ -87,7 +87,10 @@ KIND_NAMES = {12: "gemm_fwd(NT)", 13: "gemm_fwd(NT)+gelu", 14: "gemm_fwd(NT)+res
               17: "gemm_fwd(NT)+rope", 8: "gemm_dgrad(NN)", 11: "gemm_dgrad(NN)+gelu_bwd", 0: "gemm_wgrad(TN)",
               2: "gemm_wgrad(TN)+accumulate", 32: "gemm_grouped(wgrads)", 34: "gemm_grouped(wgrads)+accumulate",
               33: "gemm_grouped(wgrads+dgrad)", 35: "gemm_grouped(wgrads+dgrad)+accumulate", 100: "attn_fwd", 101: "attn_bwd",
-              102: "lm_head+CE fused fwd", 103: "lm_head+CE fused bwd"}
+              110: "ln_fwd", 111: "ln_bwd", 112: "masked_ce_rows", 113: "adamw"}
+HBM_KINDS = {110: lambda d0, d1, d2: 4.0 * d0 * d1, 111: lambda d0, d1, d2: (6.0 + 2.0 * d2) * d0 * d1,
+             112: lambda d0, d1, d2: 4.0 * d0 * d1, 113: lambda d0, d1, d2: 14.0 * d0}   # algorithmic bytes per launch
+PEAK_HBM_TBS = 8.0   # MI355X HBM3E (MI355X_MICROARCH.md)
 # profiler kind = code above + 1000 * kernel structure: the name rocprofv3 --kernel-trace shows for that launch
 STRUCT_NAMES = {1: "gemm_bf16_kernel", 2: "gemm_v2_kernel", 3: "gemm_v3_kernel"}
 GEMM_FAMILY = "bf16 MFMA GEMM family: gemm_bf16_kernel, gemm_v2_kernel, gemm_v3_kernel, gemm_v3_group_kernel"
@@ -105,8 +108,8 @@ def rocprof_name(k: int) -> str:
 def launch_flops(code: int, d0, d1, d2) -> float:
     if code in (100, 101):   # attention: fwd 4*T*T*D per (b,h); bwd 2.5x (five products) — algorithmic, recompute not counted
         return 4.0 * d0 * d1 * d1 * d2 * (1.0 if code == 100 else 2.5)
-    if code in (102, 103):   # fused readout + CE: forward 2*M*V*C, backward twice that (recompute not counted)
-        return 2.0 * d0 * d1 * d2 * (1.0 if code == 102 else 2.0)
+    if code in HBM_KINDS:
+        return 0.0
     return 2.0 * d0 * d1 * d2
 
 
@@ -124,8 +127,13 @@ def roofline_from_profile(ms, dims, kind, n_steps):
     """Group launches by kernel family; the dominant family (largest total time) becomes ``roofline``; inside it every
     kernel is also listed under the name rocprofv3 shows for it, with the dominant single kernel named."""
     fam, by_kind, by_kernel = {}, {}, {}
+    hbm = {}
     for t, (d0, d1, d2), k in zip(ms, dims, kind):
         code = int(k) % 1000
+        if code in HBM_KINDS:   # HBM-bound kernels: algorithmic bytes / time against the 8 TB/s roof, reported beside the MFMA family
+            e = hbm.setdefault(KIND_NAMES[code], dict(time_ms=0.0, bytes=0.0, launches=0))
+            e["time_ms"] += float(t); e["bytes"] += HBM_KINDS[code](float(d0), float(d1), float(d2)); e["launches"] += 1
+            continue
         flops = launch_flops(code, d0, d1, d2)
         name = GEMM_FAMILY if code < 100 else KIND_NAMES.get(code, str(code))
         for table, key in ((fam, name), (by_kind, KIND_NAMES.get(code, str(code))), (by_kernel, rocprof_name(k))):
@@ -150,7 +158,11 @@ def roofline_from_profile(ms, dims, kind, n_steps):
             "share_of_profiled_time": round(f["time_ms"] / sum(x["time_ms"] for x in fam.values()), 3),
             "dominant_kernel_by_rocprof_name": gemm_kernels[0] if (dom == GEMM_FAMILY and gemm_kernels) else dom,
             "by_rocprof_kernel": kernels,
-            "breakdown": {n: row(e) for n, e in sorted(by_kind.items())}}
+            "breakdown": {n: row(e) for n, e in sorted(by_kind.items())},
+            "hbm_bound_kernels": {n: {"ms_per_step": round(e["time_ms"] / n_steps, 3), "launches_per_step": e["launches"] // n_steps,
+                                      "achieved_TBps": round(e["bytes"] / (e["time_ms"] * 1e-3) / 1e12, 2),
+                                      "frac_of_hbm_peak": round(e["bytes"] / (e["time_ms"] * 1e-3) / 1e12 / PEAK_HBM_TBS, 3)}
+                                  for n, e in sorted(hbm.items())}}
     return roof
 
 
@@ -379,6 +391,8 @@ def main():
             if a.shapes_out:
                 tab = {}
                 for t, d, k in zip(ms, dims, kind):
+                    if int(k) % 1000 in HBM_KINDS:
+                        continue
                     key = (KIND_NAMES.get(int(k) % 1000, str(int(k))) + " [" + rocprof_name(k) + "]", int(d[0]), int(d[1]), int(d[2]), int(k) % 1000)
                     e = tab.setdefault(key, [0, 0.0])
                     e[0] += 1; e[1] += float(t)

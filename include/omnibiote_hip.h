@@ -40,7 +40,9 @@ int obte_struct_sizes(int64_t* out, int cap);
  * caller's stream.  obte_profile_collect synchronises those events and returns up to cap records:
  * ms[i] = elapsed milliseconds, dims[3*i..] = (M,N,K) for a GEMM or (B*H, T, head_dim) for attention,
  * kind[i] = a_kmajor*8 + b_kmajor*4 + epilogue (+ 32.. for a grouped launch) + 1000 * kernel structure (1 gemm_bf16_kernel,
- * 2 gemm_v2_kernel, 3 gemm_v3_kernel) for a GEMM, 100 = attention forward, 101 = attention backward.
+ * 2 gemm_v2_kernel, 3 gemm_v3_kernel) for a GEMM, 100 = attention forward, 101 = attention backward; the HBM-bound
+ * kernels record (rows, cols, flag): 110 LayerNorm forward, 111 LayerNorm backward (flag = residual gradient added),
+ * 112 masked CE over (n_rows, vocab), 113 AdamW over (elements, 1, 1).
  * Returns the number of records written (records are cleared). */
 int obte_profile_enable(int on);
 int obte_profile_collect(double* ms, int64_t* dims, int32_t* kind, int cap);

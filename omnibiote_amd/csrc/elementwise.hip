@@ -543,8 +543,10 @@ extern "C" int obte_masked_ce_rows(const obte_bf16* logits, const int64_t* targe
     OBTE_REQUIRE(logits && target && row_index && grad_scale && dlogits_rows && row_loss, "obte_masked_ce_rows: null pointer");
     OBTE_REQUIRE(n_rows > 0 && n_rows <= total_rows && total_rows < (1ll << 31) && vocab > 0 && vocab % 8 == 0,
                  "obte_masked_ce_rows: need 0 < n_rows <= total_rows and vocab %% 8 == 0");
+    const int prof = obte_prof_begin((hipStream_t)s, 112, n_rows, vocab, 1);   // algorithmic bytes = 4 * n_rows * vocab (read + write)
     hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)s, (const bf16*)logits, target,
                        (const uint8_t*)nullptr, (const uint8_t*)nullptr, grad_scale, row_scale, row_loss, (bf16*)dlogits_rows, vocab, row_index);
+    obte_prof_end(prof, (hipStream_t)s);
     OBTE_CHECK_LAUNCH("obte_masked_ce_rows");
     return OBTE_OK;
 }
@@ -596,7 +598,11 @@ extern "C" int obte_adamw_multi_bf16_ref(const obte_mt_args* a, double beta1, do
         t.step_size[i] = (float)((double)a->lr[i] / (1.0 - pow(beta1, st)));
     }
     const float w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2);
+    int64_t n_all = 0;
+    for (int i = 0; i < a->count; ++i) n_all += a->n[i];
+    const int prof = obte_prof_begin((hipStream_t)s, 113, n_all, 1, 1);        // algorithmic bytes = 14 * elements (p, g, m, v read; p, m, v written)
     hipLaunchKernelGGL(adamw_multi_ref_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, t, (float)beta2, w1, w2, (float)eps, clip_coef);
+    obte_prof_end(prof, (hipStream_t)s);
     OBTE_CHECK_LAUNCH("obte_adamw_multi_bf16_ref");
     return OBTE_OK;
 }

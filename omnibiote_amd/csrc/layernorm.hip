@@ -189,6 +189,7 @@ extern "C" int obte_layernorm_fwd(const obte_bf16* x, const obte_bf16* w, obte_b
     if (rows == 0) return OBTE_OK;
     const dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
     hipStream_t st = (hipStream_t)s;
+    const int prof = obte_prof_begin(st, 110, rows, cols, 1);   // HBM-bound: algorithmic bytes = 4 * rows * cols
 #define LN_FWD(N) hipLaunchKernelGGL((ln_fwd_kernel<N>), grid, block, 0, st, (const bf16*)x, (const bf16*)w, (bf16*)y, mean, rstd, rows, cols, eps)
     switch (nch_for(cols)) {
         case 1: LN_FWD(1); break;
@@ -198,6 +199,7 @@ extern "C" int obte_layernorm_fwd(const obte_bf16* x, const obte_bf16* w, obte_b
         default: LN_FWD(16); break;
     }
 #undef LN_FWD
+    obte_prof_end(prof, st);
     OBTE_CHECK_LAUNCH("obte_layernorm_fwd");
     return OBTE_OK;
 }
@@ -228,6 +230,7 @@ static int ln_bwd_impl(const obte_bf16* dy, const obte_bf16* x, const obte_bf16*
         obte_set_error("obte_layernorm_bwd_partial: memset failed");
         return OBTE_ELAUNCH;
     }
+    const int prof = obte_prof_begin(st, 111, rows, cols, dresid ? 1 : 0);   // algorithmic bytes = (6 + 2 * has_resid) * rows * cols
 #define LN_BWD(N)                                                                                                           \
     do {                                                                                                                    \
         if (dresid)                                                                                                         \
@@ -245,11 +248,13 @@ static int ln_bwd_impl(const obte_bf16* dy, const obte_bf16* x, const obte_bf16*
         default: LN_BWD(16); break;
     }
 #undef LN_BWD
+    if (!reduce) obte_prof_end(prof, st);
     OBTE_CHECK_LAUNCH("obte_layernorm_bwd");
     if (reduce) {
         // a carried-over workspace is summed over ALL its rows (workgroups of earlier calls may have used more of them)
         hipLaunchKernelGGL(ln_dw_reduce_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, (const float*)ws, (bf16*)dw,
                            ws_acc || clear_tail ? LN_BWD_MAX_BLOCKS : nblk, cols, accumulate_dw);
+        obte_prof_end(prof, st);
         OBTE_CHECK_LAUNCH("obte_layernorm_bwd(dw reduce)");
     }
     return OBTE_OK;

@@ -45,7 +45,7 @@ def candidates(M: int, N: int, K: int, epi: int) -> List[Tuple[int, int, int]]:
             if bn == 256 and N < 256:
                 continue
             tiles = ((M + 255) // 256) * ((N + bn - 1) // bn)
-            for s in (2, 3, 4, 5, 6, 8):
+            for s in (2, 3, 4, 5, 6, 8, 10, 12, 16):
                 if nk // s >= 8 and tiles * s <= 1024:
                     c.append((2, bn, s))
                     if bn == 256:
@@ -87,6 +87,7 @@ def tune_gemm(M: int, N: int, K: int, a_kmajor: bool, b_kmajor: bool, epi: int =
 def model_gemm_shapes(rows: int, n_embd: int, vocab: int):
     """Every GEMM of one training micro-step: (M, N, K, a_kmajor, b_kmajor, epilogue)."""
     M, C, V = rows, n_embd, vocab
+    Mm = max(64, int(round(0.15 * rows / 8)) * 8)
     E = L
     return [
         (M, 3 * C, C, True, True, E.EPI_NONE), (M, C, C, True, True, E.EPI_ADD), (M, 4 * C, C, True, True, E.EPI_GELU),
@@ -95,6 +96,8 @@ def model_gemm_shapes(rows: int, n_embd: int, vocab: int):
         (M, C, 3 * C, True, False, E.EPI_NONE), (M, C, V, True, False, E.EPI_NONE),
         (C, 4 * C, M, False, False, E.EPI_NONE), (4 * C, C, M, False, False, E.EPI_NONE), (C, C, M, False, False, E.EPI_NONE),
         (3 * C, C, M, False, False, E.EPI_NONE), (V, C, M, False, False, E.EPI_NONE),
+        # the readout's backward over the MLM-masked rows (about 15 % of M; the library applies these two plans to counts within 20 %)
+        (Mm, C, V, True, False, E.EPI_NONE), (V, C, Mm, False, False, E.EPI_NONE),
     ]
 
 
