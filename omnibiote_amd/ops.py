@@ -270,8 +270,6 @@ class MaskSpec:
             raise RuntimeError("attn_mask must be on the GPU")
         if m.dtype == torch.bool:
             raise RuntimeError("boolean masks are not part of the reference's contract; pass an additive float mask")
-        if m.shape[1] == H and m.stride(1) != 0 and H > 1:
-            pass
         if m.dtype != bf16 or m.stride(3) != 1:
             # convert without materialising H copies of an expand()ed mask
             if m.shape[1] == 1 or m.stride(1) == 0:
