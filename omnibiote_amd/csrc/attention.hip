@@ -38,6 +38,7 @@ struct AttnParams {
     const int32_t* gate; int gate_expect;   // nullable device flag: the kernel runs only if *gate == gate_expect (see launch_fwd)
     int64_t B, T; int H; float scale;
     DropCfg drop;   // attention-probability dropout (site 1); thresh16 == 0: off
+    int no_wait;    // timing-only diagnostic (OBTE_ATTN_DEBUG=nowait): the tile loops do not wait for their LDS-DMA (results are wrong)
     int max_tiles;  // timing-only diagnostic (OBTE_ATTN_DEBUG=tiles:N): every workgroup stops after N tiles (results are wrong; 0 = off)
 };
 
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_fwd_kernel(At
             for (int dt = 0; dt < ND; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Vt, 16 * kk, dt, lane), pf, o[dt], 0, 0, 0);
         }
-        dma_wait_leave(OPS * min(max(t_end - t - 2, 0), R - 2));   // tile t+1 landed; later ones may stay in flight
+        if (!p.no_wait) dma_wait_leave(OPS * min(max(t_end - t - 2, 0), R - 2));   // tile t+1 landed; later ones may stay in flight
         __syncthreads();
     }
 
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dq_kernel
                     dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Kt, 32 * mt + 16 * kk, dt, lane), dsf, dq[dt], 0, 0, 0);
             }
         }
-        dma_wait_all();
+        if (!p.no_wait) dma_wait_all();
         __syncthreads();
     }
 
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kern
             }
         }
         if (more) store_stats(smem + (cur ^ 1) * STAGE);
-        dma_wait_all();
+        if (!p.no_wait) dma_wait_all();
         __syncthreads();
     }
 
@@ -856,6 +857,11 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
 }  // namespace
 
 // OBTE_ATTN_DEBUG=tiles:N -> max_tiles = N + 1 (N tiles per workgroup, N >= 0); unset -> 0 (off).  Timing only.
+static int debug_no_wait() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OBTE_ATTN_DEBUG"); v = (e && !strcmp(e, "nowait")) ? 1 : 0; }
+    return v;
+}
 static int debug_max_tiles() {
     static int v = -1;
     if (v < 0) {
@@ -911,7 +917,7 @@ extern "C" int obte_attn_fwd(const obte_attn_fwd_args* a, obte_stream s) {
     p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
     OBTE_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "obte_attn_fwd: dropout p must be in [0,1)");
     p.drop = make_drop(a->dropout_p, a->dropout_seed, OBTE_SITE_ATTN);
-    p.max_tiles = debug_max_tiles();
+    p.max_tiles = debug_max_tiles(); p.no_wait = debug_no_wait();
     const int mode = mask_mode(a->key_ranges, a->mask);
     const int prof = obte_prof_begin((hipStream_t)s, 100, a->B * a->n_head, a->T, a->head_dim);
     if (mode == MASK_DENSE && a->key_ranges && a->ranges_exact)
@@ -935,7 +941,7 @@ extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
     p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
     OBTE_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "obte_attn_bwd: dropout p must be in [0,1)");
     p.drop = make_drop(a->dropout_p, a->dropout_seed, OBTE_SITE_ATTN);
-    p.max_tiles = debug_max_tiles();
+    p.max_tiles = debug_max_tiles(); p.no_wait = debug_no_wait();
     const int mode = mask_mode(a->key_ranges, a->mask);
     const int prof = obte_prof_begin((hipStream_t)s, 101, a->B * a->n_head, a->T, a->head_dim);
     if (mode == MASK_DENSE && a->key_ranges && a->query_bounds && a->ranges_exact)

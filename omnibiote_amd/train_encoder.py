@@ -198,6 +198,7 @@ class TrainStep:
         self._streams = None
         self._slot = 0
         self._prev_bwd_done = None
+        self._host_bufs = {}
 
     def _inplace(self, enabled: bool, ln_partial_mode: int = 0):
         if self.loss_impl != "fused" or os.environ.get("OBTE_NO_INPLACE_ACCUM") == "1":   # CPU-oracle tests / A-B switch
@@ -286,24 +287,67 @@ class TrainStep:
         logits.backward(dlogits)
         return loss.detach()
 
-    def __call__(self, input_ids: torch.Tensor, mlm_mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    def _host_prelude(self, input_ids, ids_host, rows, n_accum, want_rows):
+        """The MLM corruption with every host-side input at hand (train_encoder.py:273-279): the Bernoulli draw AND the
+        PAD/EOS exclusions are evaluated on the host copy of the batch, so the final mask — and from it the per-micro-batch
+        lists of masked positions — is known without a device round trip.  Mask and lists go to the GPU through reused
+        pinned buffers as asynchronous copies; the host never waits for the device here (the `.cpu()` of the device-side
+        form stalls the host until the previous optimizer step has drained: 1.5-2 ms of idle GPU per step)."""
+        dev = input_ids.device
+        T = input_ids.shape[1]
+        ids_h = np.asarray(ids_host)[:rows]
+        draw = np.random.binomial(1, 0.15, (rows, T))                                  # same call, same stream as mlm_corrupt
+        mask_h = (draw != 0) & (ids_h != PAD_TOKEN) & (ids_h != EOS_TOKEN)
+        st = self._host_bufs.get((rows, T, dev))
+        if st is None:
+            st = dict(mask_pin=torch.empty((rows, T), dtype=torch.bool).pin_memory(), rows_pin=torch.empty(rows * T, dtype=torch.int64).pin_memory(),
+                      mask_dev=torch.empty((rows, T), dtype=torch.bool, device=dev), rows_dev=torch.empty(rows * T, dtype=torch.int64, device=dev),
+                      done=None)
+            self._host_bufs[(rows, T, dev)] = st
+        if st["done"] is not None:
+            st["done"].synchronize()        # the previous step's copies out of these pinned buffers (long finished)
+        st["mask_pin"].numpy()[...] = mask_h
+        st["mask_dev"].copy_(st["mask_pin"], non_blocking=True)
+        lists = None
+        if want_rows:
+            per = mask_h.reshape(n_accum, -1)
+            idx = [np.flatnonzero(per[j]) for j in range(n_accum)]
+            sizes = [len(v) for v in idx]
+            total = int(sum(sizes))
+            if total:
+                st["rows_pin"].numpy()[:total] = np.concatenate(idx)
+                st["rows_dev"][:total].copy_(st["rows_pin"][:total], non_blocking=True)
+            off = np.concatenate([[0], np.cumsum(sizes)])
+            lists = [st["rows_dev"][int(off[j]):int(off[j + 1])] for j in range(n_accum)]
+        st["done"] = torch.cuda.current_stream().record_event()
+        mask = st["mask_dev"]
+        return input_ids.masked_fill(mask, MASK_TOKEN), mask, lists
+
+    def __call__(self, input_ids: torch.Tensor, mlm_mask: Optional[torch.Tensor] = None, input_ids_host=None) -> Dict[str, torch.Tensor]:
         """mlm_mask (optional, bool (rows, T)): the positions to corrupt instead of the host Bernoulli draw of
-        train_encoder.py:273-274 (PAD/EOS are still excluded) — lets tests hand two runs the same corruption."""
+        train_encoder.py:273-274 (PAD/EOS are still excluded) — lets tests hand two runs the same corruption.
+        input_ids_host (optional, the same batch as a host array/tensor, e.g. what the loader produced before its H2D copy):
+        lets the step form the MLM mask without waiting for the device (see _host_prelude); results are identical."""
         rows = input_ids.shape[0] // self.mini * self.mini
         input_ids = input_ids[:rows]
         n_accum = rows // self.mini
         self.optimizer.zero_grad(set_to_none=True)
-        if mlm_mask is None:
-            masked_ids, mask = mlm_corrupt(input_ids)
-        else:
-            mask = mlm_mask[:rows].to(input_ids.device) & (input_ids != PAD_TOKEN) & (input_ids != EOS_TOKEN)
-            masked_ids = input_ids.masked_fill(mask, MASK_TOKEN)
         sparse_rows = self.lm_head_impl == "masked" or (self.lm_head_impl == "dense" and self.loss_impl == "fused" and self.fused_loss_fn is None)
-        if sparse_rows:
-            # per-micro-batch row indices of the masked positions; mlm_corrupt drew the mask on the host, but PAD/EOS
-            # exclusions were applied on the device, so fetch the final mask once per optimizer step (one small D2H copy)
-            mh = mask.reshape(rows // self.mini, -1).cpu()
-            self._mask_rows_host = [torch.nonzero(mh[j], as_tuple=False).reshape(-1).to(input_ids.device) for j in range(mh.shape[0])]
+        if mlm_mask is None and input_ids_host is not None and input_ids.is_cuda:
+            masked_ids, mask, lists = self._host_prelude(input_ids, input_ids_host, rows, n_accum, sparse_rows)
+            if sparse_rows:
+                self._mask_rows_host = lists
+        else:
+            if mlm_mask is None:
+                masked_ids, mask = mlm_corrupt(input_ids)
+            else:
+                mask = mlm_mask[:rows].to(input_ids.device) & (input_ids != PAD_TOKEN) & (input_ids != EOS_TOKEN)
+                masked_ids = input_ids.masked_fill(mask, MASK_TOKEN)
+            if sparse_rows:
+                # per-micro-batch row indices of the masked positions; mlm_corrupt drew the mask on the host, but PAD/EOS
+                # exclusions were applied on the device, so fetch the final mask once per optimizer step (one small D2H copy)
+                mh = mask.reshape(rows // self.mini, -1).cpu()
+                self._mask_rows_host = [torch.nonzero(mh[j], as_tuple=False).reshape(-1).to(input_ids.device) for j in range(mh.shape[0])]
         dtype = next(self.model.parameters()).dtype
         core_model = self.model.module if hasattr(self.model, "module") else self.model
         emb_orders = None
@@ -566,7 +610,10 @@ def make_batch_source(args, batch_size: int, device, rng):
         print(f"note: no token shards under {args.base_dir}; training on synthetic rows")
 
     def synth(rows):
-        return torch.from_numpy(synthetic_rows(rows, args.ctx_len, 2 ** 16, rng, single_document=not args.multi_document)).to(device)
+        host = synthetic_rows(rows, args.ctx_len, 2 ** 16, rng, single_document=not args.multi_document)
+        dev_t = torch.from_numpy(host).to(device)
+        dev_t._obte_host_copy = host      # lets TrainStep form the MLM mask without a device round trip
+        return dev_t
     return synth, "synthetic rows", (lambda: None)
 
 
@@ -689,7 +736,7 @@ def run(args):
             t0 = time.time()
             rows = effective_batch(i, total_iters, args, batch_size)
             ids = next_batch(rows)
-            out = step(ids)
+            out = step(ids, input_ids_host=getattr(ids, "_obte_host_copy", None))
             stats = torch.stack([out["loss"], out["tokens"].float()])
             if world > 1:
                 dist.all_reduce(stats)

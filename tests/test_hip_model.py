@@ -568,3 +568,39 @@ def test_layernorm_weight_gradients_carried_as_fp32_partials_over_micro_batches(
             assert rel <= 1e-2 and ea <= eb + 2e-3, (k, rel, ea, eb)
         else:
             assert torch.equal(a, b), k
+
+
+def test_host_side_mlm_prelude_gives_the_same_step():
+    """TrainStep(input_ids_host=...) forms the MLM mask and the masked-row lists on the host copy of the batch (no device
+    round trip); with the same NumPy seed it must be the step the device-side form runs: same loss, same gradients, bitwise."""
+    from omnibiote_amd import train_encoder as TE
+    from omnibiote_amd.mup_compat import set_base_shapes
+    from omnibiote_amd.model import OmniBioTA, OmniBioTAConfig
+    C, H, Lyr, V, T, rows, mini = 128, 2, 2, 512, 64, 16, 4
+    w = R.hash_weights(R.RefConfig(block_size=T, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C))
+    host = TE.synthetic_rows(rows, T, V, np.random.default_rng(8), single_document=False)
+    host[:, -3:] = 1                                   # some PAD at the row ends: the exclusions matter
+    out = {}
+    for tag in ("device", "host"):
+        c = OmniBioTAConfig(); c.block_size, c.vocab_size, c.n_layer, c.n_head, c.n_embd, c.dropout, c.flash = T, V, Lyr, H, C, 0.0, True
+        m = OmniBioTA(c)
+        cb = OmniBioTAConfig(); cb.block_size, cb.vocab_size, cb.n_layer, cb.dropout, cb.flash = T, V, Lyr, 0.0, True
+        cb.n_embd, cb.n_head = 24, 3
+        base = OmniBioTA(cb)
+        cb.n_embd, cb.n_head = 48, 12
+        delta = OmniBioTA(cb)
+        set_base_shapes(m, base, delta=delta, rescale_params=False)
+        m.load_state_dict(w, strict=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.to(BF)
+        m.to(DEV)
+        step = TE.TrainStep(m, torch.optim.SGD(m.parameters(), lr=0.0), None, mini_batch_size=mini, n_head=H, max_grad_norm=1e9)
+        losses = []
+        for s in range(2):                              # twice: the pinned buffers are reused
+            np.random.seed(31 + s)
+            losses.append(step(torch.from_numpy(host).to(DEV), input_ids_host=host if tag == "host" else None)["loss"].item())
+        out[tag] = (losses, {k: p.grad.clone() for k, p in m.named_parameters()})
+    assert out["device"][0] == out["host"][0]
+    for k in out["device"][1]:
+        assert torch.equal(out["device"][1][k], out["host"][1][k]), k
