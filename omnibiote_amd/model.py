@@ -21,6 +21,7 @@ Contract notes (each mirrors a reference behaviour):
 """
 from __future__ import annotations
 
+import weakref
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -123,25 +124,20 @@ class accumulate_grads_inplace:
         return False
 
 
+_LN_PARTIALS = {}   # id(LayerNorm weight) -> (weak reference to it, its fp32 partial-sum buffer).  Not an attribute of the parameter:
+                    # whole-object pickles of the model (the reference's checkpoint format) must not carry 2 MB of scratch per weight
+
+
 def _ln_partials(param):
-    """The persistent fp32 partial-sum buffer of a LayerNorm weight (created on first use, lives with the parameter)."""
-    buf = getattr(param, "_obte_ln_partials", None)
-    if buf is None or buf.device != param.device or buf.numel() != L.lib().obte_layernorm_bwd_ws_rows() * param.numel():
-        buf = ops.ln_partials_buffer(param.numel(), param.device)
-        param._obte_ln_partials = buf
+    """The persistent fp32 partial-sum buffer of a LayerNorm weight (created on first use, dropped with the parameter)."""
+    key = id(param)
+    ent = _LN_PARTIALS.get(key)
+    if ent is not None and ent[0]() is param and ent[1].device == param.device and \
+            ent[1].numel() == L.lib().obte_layernorm_bwd_ws_rows() * param.numel():
+        return ent[1]
+    buf = ops.ln_partials_buffer(param.numel(), param.device)
+    _LN_PARTIALS[key] = (weakref.ref(param, lambda _r, k=key: _LN_PARTIALS.pop(k, None)), buf)
     return buf
-
-
-def _grad_slot(param):
-    """The existing gradient of ``param`` if in-place accumulation is on and applicable, else None.  (The HIP entry
-    points that receive it insist on bf16 themselves; the protocol is dtype-agnostic so that the CPU multi-process tests
-    can drive it with a stub model.)"""
-    if not _ACCUMULATE_INPLACE:
-        return None
-    g = getattr(param, "grad", None)
-    if g is None or g.dtype != param.dtype or not g.is_contiguous() or g.shape != param.shape:
-        return None
-    return g
 
 
 # ------------------------------------------------------------------------------------------------- autograd glue

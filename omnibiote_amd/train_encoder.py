@@ -303,6 +303,8 @@ class TrainStep:
             st = dict(mask_pin=torch.empty((rows, T), dtype=torch.bool).pin_memory(), rows_pin=torch.empty(rows * T, dtype=torch.int64).pin_memory(),
                       mask_dev=torch.empty((rows, T), dtype=torch.bool, device=dev), rows_dev=torch.empty(rows * T, dtype=torch.int64, device=dev),
                       done=None)
+            if len(self._host_bufs) >= 4:          # --batch_ramp walks through many row counts: keep a few
+                self._host_bufs.pop(next(iter(self._host_bufs)))
             self._host_bufs[(rows, T, dev)] = st
         if st["done"] is not None:
             st["done"].synchronize()        # the previous step's copies out of these pinned buffers (long finished)
