@@ -67,6 +67,9 @@ def parse():
     p.add_argument("--no_variants", action="store_true", help="skip the extra measurements (masked-rows readout, dropout 0.1, dense-mask calling convention)")
     p.add_argument("--pipeline_streams", type=int, default=2, choices=[1, 2],
                    help="2: forward of micro-batch j+1 beside the backward of micro-batch j on a second HIP stream (bitwise the same results)")
+    p.add_argument("--micro_batches_per_pass", type=int, default=1,
+                   help="k > 1: k micro-batches per forward/backward pass (k * mini_batch_size rows per launch), the loss keeping the "
+                        "per-micro-batch normalisation; an execution option, 1 in the headline")
     p.add_argument("--plan_cache", default="", help="JSON file of tuned GEMM plans: loaded if present (no tuning launches), else tuned and written")
     p.add_argument("--shapes_out", default="", help="write the per-shape launch table (from the profiler step) to this file")
     return p.parse_args()
@@ -328,7 +331,7 @@ def main():
     total_iters = 1000
     opt, sched = TE.build_optimizer(m, h, total_iters)
     step = TE.TrainStep(model, opt, sched, mini_batch_size=a.mini_batch_size, n_head=cfg["n_head"],
-                        lm_head_impl=a.readout, pipeline_streams=a.pipeline_streams,
+                        lm_head_impl=a.readout, pipeline_streams=a.pipeline_streams, micro_batches_per_pass=a.micro_batches_per_pass,
                         mask_impl="dense" if a.dense_mask else "ranges")
     rng = np.random.default_rng(1234 + rank)
     T = cfg["ctx_len"]
@@ -448,6 +451,19 @@ def main():
                                                        "note": "the reference's literal graph: dense [M,V] d(logits) and full-size readout backward products "
                                                                "(85 % of those rows are exact zeros); identical loss and gradients"}
             _step.lm_head_impl = a.readout
+        if a.readout == "dense" and a.micro_batches_per_pass == 1 and (a.rows_per_rank // a.mini_batch_size) % 2 == 0:
+            _step.per_pass = 2
+            tune.tune_model_shapes(2 * a.mini_batch_size * cfg["ctx_len"], cfg["n_embd"], 2 ** 16, device=dev)   # plans for the 16-row shapes
+            if world > 1:
+                box = [tune.export_plans() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                if rank != 0:
+                    tune.import_plans(box[0])
+            variants["two_micro_batches_per_pass"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
+                                                      "note": "an execution option, off in the headline: two micro-batches of 8 rows go through the model in one "
+                                                              "16-row pass, every masked row weighted by its own micro-batch's count, so loss and gradients are those of "
+                                                              "separate passes (tested); every kernel sees twice the rows per launch"}
+            _step.per_pass = 1
         if a.dropout == 0.0:
             TE.set_dropout(m, 0.1)
             variants["dropout_0.1"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,

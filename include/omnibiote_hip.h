@@ -241,10 +241,11 @@ int obte_masked_ce_fwd_bwd_reuse(const obte_bf16* logits, const int64_t* target,
  * d(logits) is an exact zero.  row_index: int64 [n_rows], ascending positions (rows of the dense [total_rows, vocab]
  * logits) that are masked; target is indexed by position; row_loss [n_rows] and dlogits_rows [n_rows, vocab] are
  * compact.  The readout's backward then contracts over n_rows instead of total_rows — the zero rows it leaves out
- * contribute nothing to either gradient. */
+ * contribute nothing to either gradient.  row_scale_vec (nullable, fp32 [n_rows]): an extra weight per listed row, for a call
+ * that covers several micro-batches, each normalised by its own count of masked tokens (train_encoder.py:305). */
 int obte_masked_ce_rows(const obte_bf16* logits, const int64_t* target, const int64_t* row_index, const float* grad_scale,
-                        float row_scale, float* row_loss, obte_bf16* dlogits_rows, int64_t n_rows, int64_t total_rows,
-                        int64_t vocab, obte_stream s);
+                        float row_scale, const float* row_scale_vec, float* row_loss, obte_bf16* dlogits_rows, int64_t n_rows,
+                        int64_t total_rows, int64_t vocab, obte_stream s);
 
 /* ---- fused AdamW step, bf16 params/grads/moments as the reference trains (train_encoder.py:170,199,316-317) ---
  * One launch per tensor: p -= lr*(m_hat/(sqrt(v_hat)+eps) + wd*p), grads pre-multiplied by clip_coef[0]

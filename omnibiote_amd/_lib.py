@@ -100,7 +100,7 @@ SYMBOLS = {
     "obte_embedding_bwd_acc": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int64, C.c_int, c_stream]),
     "obte_masked_ce_fwd_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int64, C.c_int64, c_stream]),
     "obte_masked_ce_fwd_bwd_reuse": (C.c_int, [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 2 + [C.c_int64, C.c_int64, c_stream]),
-    "obte_masked_ce_rows": (C.c_int, [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 2 + [C.c_int64, C.c_int64, C.c_int64, c_stream]),
+    "obte_masked_ce_rows": (C.c_int, [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int64, C.c_int64, C.c_int64, c_stream]),
     "obte_adamw_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int32, C.c_void_p, c_stream]),
     "obte_sumsq_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, c_stream]),
     "obte_adamw_multi_bf16": (C.c_int, [C.POINTER(MtArgs), C.c_float, C.c_float, C.c_float, C.c_void_p, c_stream]),

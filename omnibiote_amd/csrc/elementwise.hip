@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void masked_ce_kernel(const bf16* __restrict__
                                                          const uint8_t* __restrict__ mlm_mask, const uint8_t* __restrict__ prev_mask,
                                                          const float* __restrict__ grad_scale, float row_scale,
                                                          float* __restrict__ row_loss, bf16* __restrict__ dlogits, int64_t vocab,
-                                                         const int64_t* __restrict__ row_index) {
+                                                         const int64_t* __restrict__ row_index, const float* __restrict__ row_scale_vec) {
     // row_index (nullable): compact form — workgroup r serves logits row row_index[r] (a masked position) and writes
     // gradient row r of a [n_masked, vocab] buffer; mlm_mask / prev_mask are not consulted
     __shared__ float red[8];
@@ -244,9 +244,10 @@ __global__ __launch_bounds__(256) void masked_ce_kernel(const bf16* __restrict__
     const float lse = bm + __logf(bl);
     int64_t tgt = target[src];
     tgt = tgt < 0 ? 0 : (tgt >= vocab ? vocab - 1 : tgt);
-    if (threadIdx.x == 0 && row_loss) row_loss[r] = (lse - bf2f(lrow[tgt])) * row_scale;
+    const float rsc = row_scale_vec ? row_scale * row_scale_vec[r] : row_scale;   // per-row weight (compact form, several micro-batches in one call)
+    if (threadIdx.x == 0 && row_loss) row_loss[r] = (lse - bf2f(lrow[tgt])) * rsc;
     // pass 2 (row is L2-resident): gradient
-    const float gs = row_scale * grad_scale[0];
+    const float gs = rsc * grad_scale[0];
     for (int64_t c = (int64_t)threadIdx.x * 8; c < vocab; c += 256 * 8) {
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(lrow + c);
         bf16x8 o;
@@ -532,20 +533,21 @@ extern "C" int obte_masked_ce_fwd_bwd_reuse(const obte_bf16* logits, const int64
     OBTE_REQUIRE(logits && target && mlm_mask && grad_scale && dlogits, "obte_masked_ce_fwd_bwd: null pointer");
     OBTE_REQUIRE(rows > 0 && rows < (1ll << 31) && vocab > 0 && vocab % 8 == 0, "obte_masked_ce_fwd_bwd: vocab must be a multiple of 8");
     hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)s, (const bf16*)logits, target, mlm_mask,
-                       prev_mask, grad_scale, row_scale, row_loss, (bf16*)dlogits, vocab, (const int64_t*)nullptr);
+                       prev_mask, grad_scale, row_scale, row_loss, (bf16*)dlogits, vocab, (const int64_t*)nullptr, (const float*)nullptr);
     OBTE_CHECK_LAUNCH("obte_masked_ce_fwd_bwd");
     return OBTE_OK;
 }
 
 extern "C" int obte_masked_ce_rows(const obte_bf16* logits, const int64_t* target, const int64_t* row_index, const float* grad_scale,
-                                   float row_scale, float* row_loss, obte_bf16* dlogits_rows, int64_t n_rows, int64_t total_rows,
-                                   int64_t vocab, obte_stream s) {
+                                   float row_scale, const float* row_scale_vec, float* row_loss, obte_bf16* dlogits_rows, int64_t n_rows,
+                                   int64_t total_rows, int64_t vocab, obte_stream s) {
     OBTE_REQUIRE(logits && target && row_index && grad_scale && dlogits_rows && row_loss, "obte_masked_ce_rows: null pointer");
     OBTE_REQUIRE(n_rows > 0 && n_rows <= total_rows && total_rows < (1ll << 31) && vocab > 0 && vocab % 8 == 0,
                  "obte_masked_ce_rows: need 0 < n_rows <= total_rows and vocab %% 8 == 0");
     const int prof = obte_prof_begin((hipStream_t)s, 112, n_rows, vocab, 1);   // algorithmic bytes = 4 * n_rows * vocab (read + write)
     hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)s, (const bf16*)logits, target,
-                       (const uint8_t*)nullptr, (const uint8_t*)nullptr, grad_scale, row_scale, row_loss, (bf16*)dlogits_rows, vocab, row_index);
+                       (const uint8_t*)nullptr, (const uint8_t*)nullptr, grad_scale, row_scale, row_loss, (bf16*)dlogits_rows, vocab, row_index,
+                       row_scale_vec);
     obte_prof_end(prof, (hipStream_t)s);
     OBTE_CHECK_LAUNCH("obte_masked_ce_rows");
     return OBTE_OK;

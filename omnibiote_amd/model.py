@@ -140,6 +140,18 @@ def _ln_partials(param):
     return buf
 
 
+def _grad_slot(param):
+    """The existing gradient of ``param`` if in-place accumulation is on and applicable, else None.  (The HIP entry
+    points that receive it insist on bf16 themselves; the protocol is dtype-agnostic so that the CPU multi-process tests
+    can drive it with a stub model.)"""
+    if not _ACCUMULATE_INPLACE:
+        return None
+    g = getattr(param, "grad", None)
+    if g is None or g.dtype != param.dtype or not g.is_contiguous() or g.shape != param.shape:
+        return None
+    return g
+
+
 # ------------------------------------------------------------------------------------------------- autograd glue
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod

@@ -378,19 +378,23 @@ def masked_ce(logits, targets, mlm_mask, n_accum: int, reuse: Optional[DLogitsBu
     return loss, dlogits
 
 
-def masked_ce_rows(logits, targets, rows, n_accum: int):
+def masked_ce_rows(logits, targets, rows, n_accum: int, row_weights: Optional[torch.Tensor] = None):
     """The same loss on a compact list of masked positions: ``rows`` int64 (n,) ascending row indices into the dense
-    logits (viewed [M, V]).  Returns (loss, dlogits_rows bf16 [n, V]) — the rows of d(logits) that are not exact zeros."""
+    logits (viewed [M, V]).  Returns (loss, dlogits_rows bf16 [n, V]) — the rows of d(logits) that are not exact zeros.
+    row_weights (fp32 (n,), optional): replaces the 1/n normalisation by a weight per listed row — a call that covers
+    several micro-batches passes 1 / (masked tokens of the row's own micro-batch)."""
     _need(logits, "logits"); _need(targets, "targets", torch.int64); _need(rows, "rows", torch.int64)
     V = logits.shape[-1]
     M = logits.numel() // V
     n = rows.numel()
     assert targets.numel() == M and 0 < n <= M
-    inv_count = torch.full((1,), 1.0 / n, dtype=torch.float32, device=logits.device)
+    if row_weights is not None:
+        _need(row_weights, "row_weights", torch.float32); assert row_weights.numel() == n
+    inv_count = torch.full((1,), 1.0 if row_weights is not None else 1.0 / n, dtype=torch.float32, device=logits.device)
     row_loss = torch.empty(n, dtype=torch.float32, device=logits.device)
     dl = torch.empty((n, V), dtype=bf16, device=logits.device)
-    L.check(L.lib().obte_masked_ce_rows(_ptr(logits), _ptr(targets), _ptr(rows), _ptr(inv_count), 1.0 / n_accum, _ptr(row_loss), _ptr(dl),
-                                        n, M, V, _stream()), "obte_masked_ce_rows")
+    L.check(L.lib().obte_masked_ce_rows(_ptr(logits), _ptr(targets), _ptr(rows), _ptr(inv_count), 1.0 / n_accum, _ptr(row_weights),
+                                        _ptr(row_loss), _ptr(dl), n, M, V, _stream()), "obte_masked_ce_rows")
     return row_loss.sum() * inv_count[0], dl
 
 

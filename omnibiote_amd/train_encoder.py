@@ -167,11 +167,18 @@ class TrainStep:
     def __init__(self, model, optimizer, scheduler=None, *, mini_batch_size: int, n_head: int, use_padding: bool = False,
                  loss_impl: str = "fused", mask_impl: str = "ranges", sync_every_micro_step: bool = False,
                  max_grad_norm: float = 1.0, lm_head_impl: str = "dense", pipeline_streams: int = 1,
-                 fused_loss_fn: Optional[Callable] = None):
+                 fused_loss_fn: Optional[Callable] = None, micro_batches_per_pass: int = 1):
         """fused_loss_fn: ``(logits, targets, mlm_mask, n_accum) -> (loss, dlogits)`` used by loss_impl="fused" instead of
         the HIP kernel (ops.masked_ce) — lets the CPU multi-process tests drive the product scheduling (in-place
         accumulation, no_sync, hand-delivered d(logits)) with a stub model and a torch loss."""
         self.fused_loss_fn = fused_loss_fn
+        # micro_batches_per_pass = k > 1 (default readout path only): k consecutive micro-batches go through the model in ONE
+        # forward/backward of k * mini_batch_size rows.  Rows never interact across a batch (attention is per row, the mask
+        # builder's per-micro-batch quirk is kept), and the loss keeps the reference's normalisation — every masked row is
+        # weighted 1 / (n_accum * masked tokens of ITS micro-batch), train_encoder.py:301-305 — so loss and gradients are those
+        # of k separate passes up to summation order; every kernel simply sees k times the rows per launch.  An execution
+        # option like pipeline_streams, off by default: --mini_batch_size keeps its meaning either way.
+        self.per_pass = max(1, int(micro_batches_per_pass))
         self.model, self.optimizer, self.scheduler = model, optimizer, scheduler
         self.mini, self.n_head, self.use_padding = mini_batch_size, n_head, use_padding
         self.loss_impl, self.mask_impl = loss_impl, mask_impl
@@ -208,10 +215,10 @@ class TrainStep:
             ln_partial_mode = 0
         return accumulate_grads_inplace(enabled, ln_partial_mode)
 
-    def _mask(self, tokens: torch.Tensor, dtype, j: int = -1):
+    def _mask(self, tokens: torch.Tensor, dtype, j: int = -1, k: int = 1):
         from . import masks
         if j >= 0 and self._all_ranges is not None:   # built once per optimizer step for every micro-batch
-            rm = masks.RangeMask(self._all_ranges[j * self.mini:(j + 1) * self.mini])
+            rm = masks.RangeMask(self._all_ranges[j * k * self.mini:(j + 1) * k * self.mini])
         else:
             rm = masks.RangeMask.from_tokens(tokens, padding=self.use_padding)
         if self.mask_impl == "ranges":
@@ -244,19 +251,32 @@ class TrainStep:
         if self._prev_bwd_done is not None:
             torch.cuda.current_stream().wait_event(self._prev_bwd_done)
 
-    def _dense_logits_sparse_backward(self, x, y, mk, attn_mask, n_accum):
+    def _pass_rows(self, j: int, k: int, rows_per_mb: int):
+        """Masked positions of pass j (micro-batches j*k .. j*k + k-1) as row indices into the pass's k * mini rows, and —
+        for k > 1 — the weight 1 / (masked tokens of its own micro-batch) of each."""
+        lists = self._mask_rows_host[j * k:(j + 1) * k]
+        if k == 1:
+            return lists[0], None
+        keep = [(i, r) for i, r in enumerate(lists) if r.numel() > 0]
+        if not keep:
+            return lists[0], None
+        rows = torch.cat([r + i * rows_per_mb for i, r in keep])
+        w = torch.cat([torch.full((r.numel(),), 1.0 / r.numel(), dtype=torch.float32, device=r.device) for _, r in keep])
+        return rows, w
+
+    def _dense_logits_sparse_backward(self, x, y, mk, attn_mask, n_accum, k: int = 1):
         """lm_head_impl="dense": full logits in the forward, backward over the masked rows (see __init__)."""
         from . import ops
         from .model import _ReadoutRowsGradFn
         emb = self.model(x, attn_mask=attn_mask, return_embeddings=True)
         core = self.model.module if hasattr(self.model, "module") else self.model
-        rows = self._mask_rows_host[self._mb]
+        rows, weights = self._pass_rows(self._mb, k, self.mini * x.shape[1])
         with torch.no_grad():
             logits = core.lm_head(emb)                     # (B, T, V): every position, as model.py:253 computes them
             if rows.numel() == 0:
                 loss, dl = None, None
             else:
-                loss, dl = ops.masked_ce_rows(logits, y.reshape(-1), rows, n_accum)
+                loss, dl = ops.masked_ce_rows(logits, y.reshape(-1), rows, n_accum, row_weights=weights)
         del logits
         self._order_backward()
         if dl is None:    # nothing masked: zero gradients for every parameter (the reference would produce 0/0 = NaN here)
@@ -352,15 +372,17 @@ class TrainStep:
                 self._mask_rows_host = [torch.nonzero(mh[j], as_tuple=False).reshape(-1).to(input_ids.device) for j in range(mh.shape[0])]
         dtype = next(self.model.parameters()).dtype
         core_model = self.model.module if hasattr(self.model, "module") else self.model
+        k = self.per_pass if (sparse_rows and self.lm_head_impl == "dense" and n_accum % self.per_pass == 0) else 1
+        n_pass, span = n_accum // k, k * self.mini          # passes through the model, rows per pass
         emb_orders = None
         if input_ids.is_cuda and self.loss_impl == "fused" and self.fused_loss_fn is None and hasattr(core_model, "transformer"):
             # the embedding backward sums gradient rows in sorted-token order: ONE segmented sort for all micro-batches of
             # the step instead of a radix sort (four launches) per micro-batch
-            emb_orders = torch.sort(masked_ids.reshape(n_accum, -1), dim=1, stable=True).indices.to(torch.int32)
+            emb_orders = torch.sort(masked_ids.reshape(n_pass, -1), dim=1, stable=True).indices.to(torch.int32)
         cum_loss = torch.zeros((), dtype=torch.float32, device=input_ids.device)
         from . import masks
         self._all_ranges = masks.RangeMask.from_tokens(input_ids, padding=self.use_padding, group=self.mini).key_ranges
-        pipelined = (self.pipeline_streams == 2 and input_ids.is_cuda and self.loss_impl == "fused" and n_accum > 2
+        pipelined = (self.pipeline_streams == 2 and input_ids.is_cuda and self.loss_impl == "fused" and n_pass > 2
                      and not self.sync_every)
         main = torch.cuda.current_stream() if input_ids.is_cuda else None
         if pipelined:
@@ -374,13 +396,13 @@ class TrainStep:
                 st.wait_stream(main)
         partial = [cum_loss, torch.zeros_like(cum_loss)] if pipelined else [cum_loss]
         self._prev_bwd_done = None
-        for j in range(n_accum):
+        for j in range(n_pass):
             self._mb = j
-            x = masked_ids[j * self.mini:(j + 1) * self.mini]
-            y = input_ids[j * self.mini:(j + 1) * self.mini]
-            last = j == n_accum - 1
+            x = masked_ids[j * span:(j + 1) * span]
+            y = input_ids[j * span:(j + 1) * span]
+            last = j == n_pass - 1
             side = pipelined and not last
-            if pipelined and last:   # the last micro-batch (DDP's reducer hooks) runs on the caller's stream, after everything
+            if pipelined and last:   # the last pass (DDP's reducer hooks) runs on the caller's stream, after everything
                 for st in self._streams:
                     main.wait_stream(st)
                 self._prev_bwd_done = None
@@ -388,23 +410,23 @@ class TrainStep:
             with (torch.cuda.stream(self._streams[j % 2]) if side else contextlib.nullcontext()):
                 if emb_orders is not None:
                     core_model._embedding_order = emb_orders[j]
-                attn_mask = self._mask(y, dtype, j)
+                attn_mask = self._mask(y, dtype, j, k)
                 ctx = contextlib.nullcontext()
                 if hasattr(self.model, "no_sync") and not last and not self.sync_every:
                     ctx = self.model.no_sync()
-                # all but the last micro-batch: nobody observes the per-micro-batch gradients, so the big matrices are
+                # all but the last pass: nobody observes the per-micro-batch gradients, so the big matrices are
                 # accumulated by the wgrad epilogues themselves (model.accumulate_grads_inplace)
-                # LayerNorm weight gradients: micro-batch 0 delivers through autograd (there is no .grad yet), 1 .. n-2 carry
+                # LayerNorm weight gradients: pass 0 delivers through autograd (there is no .grad yet), 1 .. n-2 carry
                 # fp32 partial sums (first / more), the last one folds them in and delivers the total through autograd
                 ln_mode = 0
-                if n_accum > 2 and not self.sync_every and j >= 1:
+                if n_pass > 2 and not self.sync_every and j >= 1:
                     ln_mode = 1 if j == 1 else (3 if last else 2)
                 with ctx, self._inplace(not last and not self.sync_every, ln_mode):
-                    mk = mask[j * self.mini:(j + 1) * self.mini]
+                    mk = mask[j * span:(j + 1) * span]
                     if self.lm_head_impl == "masked":
                         partial[self._slot] += self._masked_rows_loss_backward(x, y, mk, attn_mask, n_accum)
                     elif sparse_rows:
-                        partial[self._slot] += self._dense_logits_sparse_backward(x, y, mk, attn_mask, n_accum)
+                        partial[self._slot] += self._dense_logits_sparse_backward(x, y, mk, attn_mask, n_accum, k)
                     else:
                         logits = self.model(x, attn_mask=attn_mask)
                         partial[self._slot] += self._loss_backward(logits, y, mk, n_accum)

@@ -604,3 +604,57 @@ def test_host_side_mlm_prelude_gives_the_same_step():
     assert out["device"][0] == out["host"][0]
     for k in out["device"][1]:
         assert torch.equal(out["device"][1][k], out["host"][1][k]), k
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_micro_batches_per_pass_gives_the_step_of_separate_passes(k):
+    """TrainStep(micro_batches_per_pass=k) sends k micro-batches through the model in one pass and weights every masked row
+    by 1 / (n_accum x masked tokens of its own micro-batch): the reference's per-micro-batch loss normalisation
+    (train_encoder.py:301-305).  Loss and gradients must be those of separate passes (k = 1) up to summation order, and
+    both must match the oracle run micro-batch by micro-batch.  Micro-batches get deliberately different mask counts."""
+    from omnibiote_amd import train_encoder as TE
+    from omnibiote_amd.masks import RangeMask
+    from omnibiote_amd.mup_compat import set_base_shapes
+    from omnibiote_amd.model import OmniBioTA, OmniBioTAConfig
+    C, H, Lyr, V, T, rows, mini = 128, 2, 2, 512, 64, 16, 2          # 8 micro-batches
+    cfg = R.RefConfig(block_size=T, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C)
+    w = R.hash_weights(cfg)
+    ids_cpu = torch.from_numpy(TE.synthetic_rows(rows, T, V, np.random.default_rng(12), single_document=False))
+    rng = np.random.default_rng(13)
+    mlm = torch.from_numpy(rng.random((rows, T)) < np.repeat(rng.uniform(0.05, 0.4, size=rows // mini), mini)[:, None])
+    out = {}
+    for kk in (1, k):
+        c = OmniBioTAConfig(); c.block_size, c.vocab_size, c.n_layer, c.n_head, c.n_embd, c.dropout, c.flash = T, V, Lyr, H, C, 0.0, True
+        m = OmniBioTA(c)
+        cb = OmniBioTAConfig(); cb.block_size, cb.vocab_size, cb.n_layer, cb.dropout, cb.flash = T, V, Lyr, 0.0, True
+        cb.n_embd, cb.n_head = 24, 3
+        base = OmniBioTA(cb)
+        cb.n_embd, cb.n_head = 48, 12
+        delta = OmniBioTA(cb)
+        set_base_shapes(m, base, delta=delta, rescale_params=False)
+        m.load_state_dict(w, strict=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m.to(BF)
+        m.to(DEV)
+        step = TE.TrainStep(m, torch.optim.SGD(m.parameters(), lr=0.0), None, mini_batch_size=mini, n_head=H, max_grad_norm=1e9,
+                            micro_batches_per_pass=kk)
+        loss = step(ids_cpu.to(DEV), mlm_mask=mlm.to(DEV))["loss"].item()
+        out[kk] = (loss, {n: p.grad.float().cpu().clone() for n, p in m.named_parameters()})
+    wb = {n: v.to(BF).float().requires_grad_(True) for n, v in w.items()}
+    rope = R.cast_rope_table(R.rope_table(C // H, T), BF)
+    mask_eff = mlm & (ids_cpu != 1) & (ids_cpu != R.EOS_TOKEN)
+    masked_ids = ids_cpu.masked_fill(mask_eff, 2)
+    ref_loss = 0.0
+    for j in range(rows // mini):
+        sl = slice(j * mini, (j + 1) * mini)
+        dense = RangeMask.from_tokens(ids_cpu[sl]).dense(torch.float32).unsqueeze(1)
+        lj = R.masked_lm_loss(R.model_forward(wb, cfg, masked_ids[sl], dense, rope=rope), ids_cpu[sl], mask_eff[sl], rows // mini)
+        lj.backward()
+        ref_loss += lj.item()
+    assert abs(out[1][0] - out[k][0]) <= 2e-3 and abs(out[k][0] - ref_loss) <= 0.02, (out[1][0], out[k][0], ref_loss)
+    for n in out[1][1]:
+        a, b, ref = out[k][1][n].flatten(), out[1][1][n].flatten(), wb[n].grad.flatten()
+        assert ((a - b).norm() / (b.norm() + 1e-12)).item() <= 0.02, n
+        cos = (torch.dot(a, ref) / (a.norm() * ref.norm() + 1e-30)).item()
+        assert cos >= 0.998 and ((a - ref).norm() / (ref.norm() + 1e-12)).item() <= 0.05, (n, cos)
