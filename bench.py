@@ -487,7 +487,7 @@ def main():
                                    f"{READOUT_TEXT[a.readout]}, dropout {a.dropout:g}, {'multi' if a.multi_document else 'single'}-document rows",
                        "global_batch_rows": a.rows_per_rank * world, "mini_batch_size": a.mini_batch_size, "seq_len": T,
                        "parallelism": f"dp{world}", "dropout": a.dropout, "vocab": 65536,
-                       "collectives": (f"RCCL ({dist.get_backend()}) over {world} ranks: one bucketed gradient all-reduce per optimizer step"
+                       "collectives": (f"{'RCCL (torch.distributed backend nccl)' if dist.get_backend() == 'nccl' else dist.get_backend()} over {world} ranks: one bucketed gradient all-reduce per optimizer step"
                                        if world > 1 else "none (single rank)")},
             "flops_per_token": fpt,
             "mfma_fraction_whole_step": round(value * fpt / (PEAK_BF16_TFLOPS * 1e12 * world), 4),
