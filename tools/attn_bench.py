@@ -10,6 +10,7 @@ ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--B", type=int, default=8); ap.add_argument("--H", type=int, default=8)
 ap.add_argument("--T", type=int, default=1024); ap.add_argument("--hs", type=int, default=128)
 ap.add_argument("--dense", action="store_true", help="pass the mask as the reference's dense additive (B,H,T,T) expand() view")
+ap.add_argument("--nomask", action="store_true", help="no mask at all (rows without EOS attend everywhere)")
 ap.add_argument("--multi", action="store_true", help="multi-document rows (block-diagonal mask) instead of one document per row")
 a = ap.parse_args()
 B, H, T, hs = a.B, a.H, a.T, a.hs
@@ -23,6 +24,8 @@ if a.multi:
         tok[b, torch.randint(8, T - 8, (3,))] = 3
 rm = masks.RangeMask.from_tokens(tok)
 spec = ops.MaskSpec(ranges=rm.key_ranges)
+if a.nomask:
+    spec = None
 if a.dense:
     spec = ops.MaskSpec.from_user(rm.dense(torch.bfloat16).unsqueeze(1).expand(-1, H, -1, -1), B, T, H, dev)
 scale = 8.0 / (H * hs)
