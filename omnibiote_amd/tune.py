@@ -18,11 +18,29 @@ from . import ops
 _done: Dict[tuple, tuple] = {}
 
 
+_flush = {}
+
+
+def _flush_caches(device) -> None:
+    """Write 512 MiB: the operands of the next timed launch then come from HBM, as they do inside a training step (the
+    256-MiB Infinity Cache would otherwise serve every repetition of a shape whose tensors fit it, and the plan picked on
+    those timings is not always the one that is fastest cold)."""
+    import os
+    if os.environ.get("OBTE_TUNE_WARM") == "1":
+        return
+    buf = _flush.get(str(device))
+    if buf is None:
+        buf = torch.empty(512 << 20, dtype=torch.uint8, device=device)
+        _flush[str(device)] = buf
+    buf.zero_()
+
+
 def _time_once(a, b, M, N, K, ak, bk, epi, aux, out, reps=6) -> float:
     ops.gemm(a, b, M, N, K, ak, bk, epi, aux, out=out)
     torch.cuda.synchronize()
     best = float("inf")
     for _ in range(reps):
+        _flush_caches(a.device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         ops.gemm(a, b, M, N, K, ak, bk, epi, aux, out=out)
@@ -105,6 +123,7 @@ def tune_model_shapes(rows: int, n_embd: int, vocab: int, device="cuda", verbose
     for (M, N, K, ak, bk, epi) in model_gemm_shapes(rows, n_embd, vocab):
         tune_gemm(M, N, K, ak, bk, epi, device=device, verbose=verbose)
     torch.cuda.synchronize()
+    _flush.clear()
     torch.cuda.empty_cache()
 
 
