@@ -104,6 +104,7 @@ def data_loader_parallel(batch_queue: "queue.Queue", batch_generator, device, st
             data = next(batch_generator)
         except StopIteration:
             break
+        host = data
         if copy_stream is not None:
             pinned = data.pin_memory()
             with torch.cuda.stream(copy_stream):
@@ -111,6 +112,7 @@ def data_loader_parallel(batch_queue: "queue.Queue", batch_generator, device, st
             copy_stream.synchronize()
         else:
             data = data.to(dev)
+        data._obte_host_copy = host.numpy()   # the batch as it was on the host: the trainer draws its MLM mask there (no device round trip)
         while True:   # bounded queue (train_encoder.py:141): wait for room, but notice a stop request
             try:
                 batch_queue.put(data, timeout=0.2)

@@ -617,9 +617,14 @@ def make_batch_source(args, batch_size: int, device, rng):
         def real(rows):
             while sum(b.shape[0] for b in pool) < rows:              # the reference's grand_batch top-up (:258-261)
                 pool.append(q.get(block=True))
+            hosts = [getattr(b, "_obte_host_copy", None) for b in pool]
             cat = torch.cat(pool, dim=0) if len(pool) > 1 else pool[0]
-            pool[:] = [cat[rows:]]
-            return cat[:rows]
+            host = None if any(h is None for h in hosts) else (np.concatenate(hosts) if len(hosts) > 1 else hosts[0])
+            rest, out = cat[rows:], cat[:rows]
+            if host is not None:      # the host copies travel with the rows they belong to
+                rest._obte_host_copy, out._obte_host_copy = host[rows:], host[:rows]
+            pool[:] = [rest]
+            return out
 
         def close():
             stop.set()
