@@ -315,7 +315,8 @@ def main():
     else:
         # every rank times the candidates on its own GPU (in parallel), then all adopt rank 0's table, so that the N
         # replicas run the same kernels (same arithmetic, same speed)
-        tune.tune_model_shapes(a.mini_batch_size * cfg["ctx_len"], cfg["n_embd"], 2 ** 16, device=dev, verbose=(rank == 0 and bool(a.shapes_out)))
+        tune.tune_model_shapes(a.micro_batches_per_pass * a.mini_batch_size * cfg["ctx_len"], cfg["n_embd"], 2 ** 16, device=dev,
+                               verbose=(rank == 0 and bool(a.shapes_out)))
         if world > 1:
             box = [tune.export_plans() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
