@@ -304,3 +304,10 @@ def test_small_config_full_depth_one_microbatch_vs_oracle():
     """small = 8L / 1024d / 8h, T = 1024, full 65 536-way logits: one micro-batch row end to end against the oracle."""
     cfg = R.RefConfig(block_size=1024, vocab_size=65536, n_layer=8, n_head=8, n_embd=1024)
     _model_vs_oracle(cfg, B=1, T=1024, seed=21, n_docs=3, emb_bar=(0.15, 1e-2), logit_bar=(3e-3, 4e-4), grad_cos=0.9995, grad_rel=0.04)   # measured: 0.076/5.7e-3, 6e-4/8e-5, 0.99992/0.013
+
+
+def test_small_config_ctx4096_one_row_vs_oracle():
+    """BASELINE config 4 end to end: small = 8L / 1024d / 8h at T = 4096 (block_size 4096, RoPE table of 4096 positions),
+    one multi-document row through embedding, 8 blocks, ln_f, the 65 536-way readout, the loss and every gradient."""
+    cfg = R.RefConfig(block_size=4096, vocab_size=65536, n_layer=8, n_head=8, n_embd=1024)
+    _model_vs_oracle(cfg, B=1, T=4096, seed=31, n_docs=6, emb_bar=(0.15, 1e-2), logit_bar=(3e-3, 4e-4), grad_cos=0.9995, grad_rel=0.04)
