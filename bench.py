@@ -256,6 +256,32 @@ def cpu_baseline(cfg, mini_rows=8, steps=5, warmup=2, device="cpu", rows=None):
                       f"fp32: median of {n32} steps, each after {warmup} warm-ups"}
 
 
+class Watchdog:
+    """Fail loudly instead of hanging: if the guarded phase (process-group set-up, the first collective, the timed steps)
+    has not finished after ``seconds`` of wall time, say where on stderr and end THIS process with a non-zero code —
+    torchrun then stops the other ranks and reports failure (the parent of `self_launch` passes that exit code on).  A rank
+    stuck inside a collective cannot be interrupted from Python, hence os._exit."""
+
+    def __init__(self, seconds: float, what: str):
+        import threading
+        self.what, self.seconds = what, seconds
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+
+    def _fire(self):
+        print(f"[bench] FATAL rank {os.environ.get('RANK', '0')}: '{self.what}' not finished after {self.seconds:.0f} s — "
+              "giving up (non-zero exit) instead of hanging", file=sys.stderr, flush=True)
+        os._exit(97)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
 def self_launch(n_gpus: int) -> int:
     """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process group (one rank per GPU,
     `python -m torch.distributed.run`, rendezvous on 127.0.0.1) before this process has made any HIP call, pass the
@@ -293,10 +319,26 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1 and rehearse:
-        dist.init_process_group("gloo")
-    elif world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # RCCL; device_id binds the communicator to this rank's GPU up front
+    init_s = float(os.environ.get("OBTE_BENCH_INIT_TIMEOUT_S", "240"))
+    if world > 1:
+        import datetime
+        n_dev = torch.cuda.device_count()
+        if not rehearse and local >= n_dev:
+            raise SystemExit(f"bench.py: rank {rank} wants cuda:{local} but this node shows {n_dev} GPU(s)")
+        with Watchdog(init_s, f"init_process_group + first all-reduce over {world} ranks"):
+            if rehearse:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=init_s))
+            else:   # RCCL; device_id binds the communicator to this rank's GPU up front (eager init: no lazy connect inside the timed region)
+                dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=max(init_s, 600.0)))
+            # first contact: every rank contributes 1 to a device all-reduce; anything but `world` back means the ranks are
+            # not the job we think they are (mis-launch, wrong communicator) — stop before timing nonsense
+            probe = torch.ones(1, dtype=torch.float32, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world or dist.get_world_size() != world:
+                raise SystemExit(f"bench.py: rank {rank}: first all-reduce returned {probe.item()} over a group of "
+                                 f"{dist.get_world_size()}, expected {world}")
+        log(f"process group up: backend {dist.get_backend()}, world {dist.get_world_size()}, first all-reduce ok")
     from omnibiote_amd import _lib
     from omnibiote_amd import train_encoder as TE
     _lib.lib()   # fail loudly, before any timing, if the HIP library is missing
@@ -310,7 +352,8 @@ def main():
         m = TE.build_model(h, dev)
     n_params = m.get_num_params()
     from omnibiote_amd import tune
-    if a.plan_cache and os.path.exists(a.plan_cache):
+    plans_loaded = bool(a.plan_cache and os.path.exists(a.plan_cache))
+    if plans_loaded:
         tune.load_plans(a.plan_cache)
     else:
         # every rank times the candidates on its own GPU (in parallel), then all adopt rank 0's table, so that the N
@@ -353,14 +396,16 @@ def main():
 
     log(f"model built, plans ready; timing {a.warmup}+{a.steps} steps")
     losses = []
-    for i in range(a.warmup):
-        losses.append(step(batches[i % len(batches)])["loss"])
-    sync()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        losses.append(step(batches[(a.warmup + i) % len(batches)])["loss"])
-    sync()
-    elapsed = time.perf_counter() - t0
+    step_budget_s = float(os.environ.get("OBTE_BENCH_STEP_TIMEOUT_S", "30")) * (4.0 if rehearse else 1.0)
+    with Watchdog(120.0 + step_budget_s * (a.warmup + a.steps), f"{a.warmup}+{a.steps} train steps"):
+        for i in range(a.warmup):
+            losses.append(step(batches[i % len(batches)])["loss"])
+        sync()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            losses.append(step(batches[(a.warmup + i) % len(batches)])["loss"])
+        sync()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -372,6 +417,8 @@ def main():
     fpt_exec = fpt - skipped   # 15 % of the positions are MLM-masked (train_encoder.py:271); their share of the readout products remains
 
     log(f"timed region done: {value:,.0f} tokens/s")
+    tail_guard = Watchdog(900.0, "profiled step + variants (they contain collectives at N > 1)")
+    tail_guard.__enter__()
     roofline = None
     if not a.no_roofline:
         # per-launch durations are only meaningful when launches do not share the chip: the profiled step runs on one
@@ -477,8 +524,25 @@ def main():
             _step.mask_impl = "ranges"
     if world > 1:
         dist.barrier()
+    tail_guard.__exit__()
 
+    for x in losses:    # every rank: a non-finite loss is a failed run, not a number to report
+        if not bool(torch.isfinite(x).item()):
+            raise SystemExit(f"bench.py: rank {rank}: non-finite loss {float(x.item())}")
     if rank == 0:
+        import hashlib
+        plans = tune.export_plans()
+        plan_rows = [f"{'k' if r['a_kmajor'] else 'm'}{'k' if r['b_kmajor'] else 'n'} epi{r['epilogue']} {r['M']}x{r['N']}x{r['K']}: "
+                     f"{STRUCT_NAMES.get(r['variant'], r['variant'])} bn{r['bn']} split{r['splits']}" for r in plans]
+        plan_hash = hashlib.sha256("\n".join(plan_rows).encode()).hexdigest()[:16]
+        if world > 1:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+            collectives = {"backend": "RCCL (torch.distributed backend nccl)" if dist.get_backend() == "nccl" else dist.get_backend(),
+                           "rccl_version": rccl, "world_size": dist.get_world_size(), "ranks_in_first_all_reduce": world,
+                           "pattern": "one bucketed gradient all-reduce per optimizer step (DDP no_sync on all but the last micro-batch, "
+                                      "100-MB buckets) + one scalar all-reduce"}
+        else:
+            collectives = "none (single rank)"
         out = {
             "metric": METRIC if a.config == "small" else f"MLM train tokens/sec, {a.config} ctx={T}", "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -488,16 +552,18 @@ def main():
                                    f"{READOUT_TEXT[a.readout]}, dropout {a.dropout:g}, {'multi' if a.multi_document else 'single'}-document rows",
                        "global_batch_rows": a.rows_per_rank * world, "mini_batch_size": a.mini_batch_size, "seq_len": T,
                        "parallelism": f"dp{world}", "dropout": a.dropout, "vocab": 65536,
-                       "collectives": (f"{'RCCL (torch.distributed backend nccl)' if dist.get_backend() == 'nccl' else dist.get_backend()} over {world} ranks: one bucketed gradient all-reduce per optimizer step"
-                                       if world > 1 else "none (single rank)")},
-            "flops_per_token": fpt,
-            "mfma_fraction_whole_step": round(value * fpt / (PEAK_BF16_TFLOPS * 1e12 * world), 4),
-            # the reference's own 6N + 12LCT formula (train_encoder.py:360) counts the readout's backward over every row; the
-            # default path contracts it over the masked rows only (the other rows of d(logits) are exact zeros), so the FLOP
-            # actually executed per token are fewer: this is the fraction of the MFMA peak the step really sustains
+                       "collectives": collectives},
+            # FLOP the step actually executes per token: the reference's 6N + 12LCT (train_encoder.py:360) minus the part of the
+            # readout's backward the default path does not perform (it contracts over the ~15 % MLM-masked rows only; the other
+            # rows of d(logits) are exact zeros).  This is the fraction of the bf16 MFMA peak the whole step sustains.
             "flops_per_token_executed": fpt_exec,
             "mfma_fraction_whole_step_executed": round(value * fpt_exec / (PEAK_BF16_TFLOPS * 1e12 * world), 4),
+            # the reference's own formula, for comparison with its MFU log line only: it counts FLOP this step does not execute
+            "reference_formula": {"flops_per_token": fpt, "model_flops_fraction": round(value * fpt / (PEAK_BF16_TFLOPS * 1e12 * world), 4)},
             "final_loss": round(float(losses[-1].item()), 4),
+            # which kernel structure / tile width / split-K each GEMM shape ran with (tuned at start-up or loaded from
+            # --plan_cache): lets a rocprof summary under profiles/ be matched to this run
+            "gemm_plans": {"sha16": plan_hash, "source": ("cache " + a.plan_cache) if (a.plan_cache and plans_loaded) else "tuned at start-up", "table": plan_rows},
             "roofline": roofline,
         }
         if variants:

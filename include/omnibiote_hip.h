@@ -263,6 +263,10 @@ typedef struct {
     obte_bf16* p[OBTE_MT_MAX]; const obte_bf16* g[OBTE_MT_MAX]; obte_bf16* m[OBTE_MT_MAX]; obte_bf16* v[OBTE_MT_MAX];
     int64_t n[OBTE_MT_MAX]; float lr[OBTE_MT_MAX]; float weight_decay[OBTE_MT_MAX]; int32_t step[OBTE_MT_MAX];
     int32_t count;
+    /* obte_adamw_multi_bf16_ref only: the same two hyper-parameters in double (0 = use the float field).  Python holds lr and
+     * weight_decay as doubles and torch forms 1 - lr*wd and lr / bias_correction1 from them in double before rounding to fp32;
+     * passing them through the float fields first can move step_size by one fp32 ulp. */
+    double lr64[OBTE_MT_MAX]; double weight_decay64[OBTE_MT_MAX];
 } obte_mt_args;
 int obte_adamw_multi_bf16(const obte_mt_args* t, float beta1, float beta2, float eps, const float* clip_coef, obte_stream s);
 int obte_sumsq_multi_bf16(const obte_mt_args* t, float* out, obte_stream s);

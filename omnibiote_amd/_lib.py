@@ -61,7 +61,8 @@ MT_MAX = 32
 class MtArgs(C.Structure):
     _fields_ = [("p", C.c_void_p * MT_MAX), ("g", C.c_void_p * MT_MAX), ("m", C.c_void_p * MT_MAX), ("v", C.c_void_p * MT_MAX),
                 ("n", C.c_int64 * MT_MAX), ("lr", C.c_float * MT_MAX), ("weight_decay", C.c_float * MT_MAX),
-                ("step", C.c_int32 * MT_MAX), ("count", C.c_int32)]
+                ("step", C.c_int32 * MT_MAX), ("count", C.c_int32),
+                ("lr64", C.c_double * MT_MAX), ("weight_decay64", C.c_double * MT_MAX)]
 
 
 EPI_NONE, EPI_GELU, EPI_ADD, EPI_GELU_BWD, EPI_ADD_DROPOUT, EPI_ROPE_QK = 0, 1, 2, 3, 4, 5

@@ -856,10 +856,17 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
 
 }  // namespace
 
-// OBTE_ATTN_DEBUG=tiles:N -> max_tiles = N + 1 (N tiles per workgroup, N >= 0); unset -> 0 (off).  Timing only.
+// Timing-only diagnostics (they make the kernels return WRONG results), compiled in only with -DOBTE_DEBUG_HOOKS (`make debug`
+// builds libomnibiote_hip_debug.so; tools/attn_fixed_*.sh load it through OBTE_LIB_PATH): a stray environment variable cannot
+// reach them in the shipped library.  OBTE_ATTN_DEBUG=tiles:N -> max_tiles = N + 1 (N tiles per workgroup); =nowait -> no_wait.
+#ifdef OBTE_DEBUG_HOOKS
+static void debug_warn_once(const char* what) {
+    static bool said = false;
+    if (!said) { said = true; fprintf(stderr, "libomnibiote_hip (DEBUG build): %s is active — attention results are WRONG, timing only\n", what); }
+}
 static int debug_no_wait() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("OBTE_ATTN_DEBUG"); v = (e && !strcmp(e, "nowait")) ? 1 : 0; }
+    if (v < 0) { const char* e = getenv("OBTE_ATTN_DEBUG"); v = (e && !strcmp(e, "nowait")) ? 1 : 0; if (v) debug_warn_once("OBTE_ATTN_DEBUG=nowait"); }
     return v;
 }
 static int debug_max_tiles() {
@@ -867,9 +874,14 @@ static int debug_max_tiles() {
     if (v < 0) {
         const char* e = getenv("OBTE_ATTN_DEBUG");
         v = (e && !strncmp(e, "tiles:", 6)) ? atoi(e + 6) + 1 : 0;
+        if (v) debug_warn_once("OBTE_ATTN_DEBUG=tiles:N");
     }
     return v;
 }
+#else
+static int debug_no_wait() { return 0; }
+static int debug_max_tiles() { return 0; }
+#endif
 
 static int check_common(const char* who, const void* qkv, int64_t B, int64_t T, int H, int D, const int32_t* ranges,
                         const obte_bf16* mask) {

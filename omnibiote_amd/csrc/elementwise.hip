@@ -596,8 +596,11 @@ extern "C" int obte_adamw_multi_bf16_ref(const obte_mt_args* a, double beta1, do
     if (blocks < 0) return blocks;
     for (int i = 0; i < a->count; ++i) {   // Python forms these in double before they reach a kernel as fp32 scalars
         const double st = (double)(a->step[i] < 1 ? 1 : a->step[i]);
+        const double lr = a->lr64[i] != 0.0 ? a->lr64[i] : (double)a->lr[i];
+        const double wd = a->weight_decay64[i] != 0.0 ? a->weight_decay64[i] : (double)a->weight_decay[i];
         t.bc2s[i] = (float)sqrt(1.0 - pow(beta2, st));
-        t.step_size[i] = (float)((double)a->lr[i] / (1.0 - pow(beta1, st)));
+        t.step_size[i] = (float)(lr / (1.0 - pow(beta1, st)));
+        t.decay[i] = (float)(1.0 - lr * wd);
     }
     const float w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2);
     int64_t n_all = 0;

@@ -823,18 +823,22 @@ static void fill_params(const obte_gemm_args* g, void* workspace, GemmParams& p)
     p.M = g->M; p.N = g->N; p.K = g->K; p.lda = g->lda; p.ldb = g->ldb; p.ldd = g->ldd;
     p.a_elems = (g->a_kmajor ? g->M : g->K) * g->lda;
     p.b_elems = (g->b_kmajor ? g->N : g->K) * g->ldb;
-    {   // timing-only diagnostic: zero-record descriptors drop every LDS-DMA (results are wrong; never set in production)
+    p.store_rows = p.M;
+    p.nt_store = (g->M * g->N * 2 > (256ll << 20)) ? 1 : 0;
+#ifdef OBTE_DEBUG_HOOKS
+    {   // timing-only diagnostics of the debug build (results are wrong): zero-record descriptors drop every LDS-DMA / no stores
         static int noload = -1, nostore = -1, exit_now = -1;
         if (noload < 0) {
             const char* e = getenv("OBTE_GEMM_DEBUG");
             nostore = (e && strstr(e, "nostore")) ? 1 : 0;
             exit_now = (e && strstr(e, "exit")) ? 1 : 0;
             noload = (e && strstr(e, "noload")) ? 1 : 0;
+            if (noload || nostore || exit_now) fprintf(stderr, "libomnibiote_hip (DEBUG build): OBTE_GEMM_DEBUG=%s is active — GEMM results are WRONG, timing only\n", e);
         }
         if (noload) { p.a_elems = 0; p.b_elems = 0; }
-        p.store_rows = exit_now ? -1 : (nostore ? 0 : p.M);
-        p.nt_store = (g->M * g->N * 2 > (256ll << 20)) ? 1 : 0;
+        if (exit_now) p.store_rows = -1; else if (nostore) p.store_rows = 0;
     }
+#endif
 }
 
 extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64_t workspace_bytes, obte_stream s) {

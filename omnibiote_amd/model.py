@@ -92,59 +92,112 @@ def _require_hip(t: torch.Tensor, what: str) -> None:
 
 
 # ------------------------------------------------------------------------------------------ in-place grad accumulation
-# While this flag is set, the backward of the big matrices adds straight into an existing ``param.grad`` (the wgrad GEMM's
-# epilogue / the embedding scatter do the read-modify-write) and hands autograd ``None`` for them, which removes the
-# separate ``grad += new`` pass over 470 MB per micro-batch.  The arithmetic is the one autograd would do
-# (bf16(old + bf16(new))).  Only valid while nothing needs to observe per-micro-batch gradients: the harness sets it for
-# the micro-batches that run under DDP's no_sync(), never for the last one (whose AccumulateGrad hooks feed the reducer).
-_ACCUMULATE_INPLACE = False
-# LayerNorm weight gradients over micro-batches: instead of one reduction launch + one bf16 `grad += new` per LayerNorm
-# and micro-batch (17 LayerNorms x 16 micro-batches on the small config), the per-workgroup partial sums are carried in a
-# persistent fp32 buffer per weight (L.LN_PARTIAL_FIRST on the first such micro-batch, _MORE after it) and reduced ONCE,
-# by the micro-batch that runs with L.LN_PARTIAL_LAST and hands the total to autograd.  0 = off.  The total is
-# bf16(sum in fp32) — closer to the exact gradient than autograd's running bf16 sum, and not bitwise equal to it.
-_LN_PARTIAL_MODE = 0
+# How the backward of a micro-batch delivers its weight gradients is a property of the TRAINING STEP that built the graph,
+# not of the process: each autograd node below captures the active ``GradPolicy`` snapshot at FORWARD time (``ctx.pol``) and
+# its backward — which PyTorch runs on an autograd-engine thread — reads only that.  Two TrainSteps on two models in one
+# process, or forward passes issued from different threads, therefore cannot see each other's switches (a context variable
+# selects the snapshot; nothing here is a mutable module global).
+#   accumulate: the backward of the big matrices adds straight into an existing ``param.grad`` (the wgrad GEMM's epilogue /
+#       the embedding scatter do the read-modify-write) and hands autograd ``None`` for them, which removes the separate
+#       ``grad += new`` pass over 470 MB per micro-batch.  The arithmetic is the one autograd would do (bf16(old +
+#       bf16(new))).  Only valid while nothing needs to observe per-micro-batch gradients: the harness sets it for the
+#       micro-batches that run under DDP's no_sync(), never for the last one (whose AccumulateGrad hooks feed the reducer).
+#   ln_mode: LayerNorm weight gradients over micro-batches: instead of one reduction launch + one bf16 ``grad += new`` per
+#       LayerNorm and micro-batch (17 LayerNorms x 16 micro-batches on the small config), the per-workgroup partial sums are
+#       carried in a persistent fp32 buffer per weight (L.LN_PARTIAL_FIRST on the first such micro-batch, _MORE after it) and
+#       reduced ONCE, by the micro-batch that runs with L.LN_PARTIAL_LAST and hands the total to autograd.  0 = off.  The
+#       total is bf16(sum in fp32) — closer to the exact gradient than autograd's running bf16 sum, not bitwise equal to it.
+#   store: who owns those fp32 buffers (one ``LnPartialStore`` per TrainStep; a process-wide default for bare uses of the
+#       context manager).
+import contextvars
+
+
+class LnPartialStore:
+    """fp32 partial-sum buffers of LayerNorm weights, keyed by the parameter's identity (not an attribute of the parameter:
+    whole-object pickles of the model — the reference's checkpoint format — must not carry 2 MB of scratch per weight)."""
+
+    def __init__(self):
+        self._bufs = {}   # id(weight) -> (weak reference to it, buffer)
+
+    def get(self, param):
+        key = id(param)
+        ent = self._bufs.get(key)
+        if ent is not None and ent[0]() is param and ent[1].device == param.device and \
+                ent[1].numel() == L.lib().obte_layernorm_bwd_ws_rows() * param.numel():
+            return ent[1]
+        buf = ops.ln_partials_buffer(param.numel(), param.device)
+        bufs = self._bufs
+        self._bufs[key] = (weakref.ref(param, lambda _r, k=key: bufs.pop(k, None)), buf)
+        return buf
+
+
+class GradPolicy:
+    """Immutable snapshot of the switches above; what an autograd node keeps in ``ctx.pol``."""
+    __slots__ = ("accumulate", "ln_mode", "store")
+
+    def __init__(self, accumulate: bool = False, ln_mode: int = 0, store: Optional[LnPartialStore] = None):
+        object.__setattr__(self, "accumulate", bool(accumulate))
+        object.__setattr__(self, "ln_mode", int(ln_mode))
+        object.__setattr__(self, "store", store)
+
+    def __setattr__(self, *a):
+        raise AttributeError("GradPolicy is immutable: enter accumulate_grads_inplace(...) for different switches")
+
+
+_NO_POLICY = GradPolicy()
+_policy = contextvars.ContextVar("obte_grad_policy", default=_NO_POLICY)
+_default_store = LnPartialStore()
+_embedding_order = contextvars.ContextVar("obte_embedding_order", default=None)
+
+
+def current_grad_policy() -> GradPolicy:
+    """The snapshot an autograd node should capture in its forward (``ctx.pol = current_grad_policy()``)."""
+    return _policy.get()
 
 
 class accumulate_grads_inplace:
-    def __init__(self, enabled: bool = True, ln_partial_mode: int = 0):
-        self.enabled = enabled
-        self.ln_mode = ln_partial_mode
+    """``with accumulate_grads_inplace(enabled, ln_partial_mode, store=...)``: graphs BUILT inside deliver their gradients
+    that way when they run backward (inside the block or later, on whatever thread)."""
+
+    def __init__(self, enabled: bool = True, ln_partial_mode: int = 0, store: Optional[LnPartialStore] = None):
+        self.pol = GradPolicy(enabled, ln_partial_mode, store if store is not None else _default_store)
 
     def __enter__(self):
-        global _ACCUMULATE_INPLACE, _LN_PARTIAL_MODE
-        self.prev = (_ACCUMULATE_INPLACE, _LN_PARTIAL_MODE)
-        _ACCUMULATE_INPLACE = self.enabled
-        _LN_PARTIAL_MODE = self.ln_mode
+        self.token = _policy.set(self.pol)
         return self
 
     def __exit__(self, *exc):
-        global _ACCUMULATE_INPLACE, _LN_PARTIAL_MODE
-        _ACCUMULATE_INPLACE, _LN_PARTIAL_MODE = self.prev
+        _policy.reset(self.token)
         return False
 
 
-_LN_PARTIALS = {}   # id(LayerNorm weight) -> (weak reference to it, its fp32 partial-sum buffer).  Not an attribute of the parameter:
-                    # whole-object pickles of the model (the reference's checkpoint format) must not carry 2 MB of scratch per weight
+class embedding_order:
+    """``with embedding_order(order)``: the next OmniBioTA.forward in this context takes ``order`` (int32, a stable argsort of
+    its flattened token ids) for its embedding backward instead of sorting the ids itself — a harness that sorts a whole
+    optimizer step's ids in one call hands each micro-batch its slice this way.  Consumed by that forward."""
+
+    def __init__(self, order):
+        self.box = [order]
+
+    def __enter__(self):
+        self.token = _embedding_order.set(self.box)
+        return self
+
+    def __exit__(self, *exc):
+        _embedding_order.reset(self.token)
+        return False
 
 
-def _ln_partials(param):
-    """The persistent fp32 partial-sum buffer of a LayerNorm weight (created on first use, dropped with the parameter)."""
-    key = id(param)
-    ent = _LN_PARTIALS.get(key)
-    if ent is not None and ent[0]() is param and ent[1].device == param.device and \
-            ent[1].numel() == L.lib().obte_layernorm_bwd_ws_rows() * param.numel():
-        return ent[1]
-    buf = ops.ln_partials_buffer(param.numel(), param.device)
-    _LN_PARTIALS[key] = (weakref.ref(param, lambda _r, k=key: _LN_PARTIALS.pop(k, None)), buf)
-    return buf
+def _ln_partials(param, pol: GradPolicy):
+    """The persistent fp32 partial-sum buffer of a LayerNorm weight in the policy's store (created on first use)."""
+    return (pol.store if pol.store is not None else _default_store).get(param)
 
 
-def _grad_slot(param):
-    """The existing gradient of ``param`` if in-place accumulation is on and applicable, else None.  (The HIP entry
-    points that receive it insist on bf16 themselves; the protocol is dtype-agnostic so that the CPU multi-process tests
-    can drive it with a stub model.)"""
-    if not _ACCUMULATE_INPLACE:
+def _grad_slot(param, pol: Optional[GradPolicy] = None):
+    """The existing gradient of ``param`` if the node's policy says accumulate in place and that is applicable, else None.
+    (The HIP entry points that receive it insist on bf16 themselves; the protocol is dtype-agnostic so that the CPU
+    multi-process tests can drive it with a stub model.)"""
+    if pol is None or not pol.accumulate:
         return None
     g = getattr(param, "grad", None)
     if g is None or g.dtype != param.dtype or not g.is_contiguous() or g.shape != param.shape:
@@ -159,16 +212,18 @@ class _LayerNormFn(torch.autograd.Function):
         y, mean, rstd = ops.layernorm_fwd(x.contiguous(), w)
         ctx.save_for_backward(x, w, mean, rstd)
         ctx.w_param = w
+        ctx.pol = current_grad_policy()
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, mean, rstd = ctx.saved_tensors
-        if _LN_PARTIAL_MODE:
-            dx, dw = ops.layernorm_bwd(dy.contiguous(), x.contiguous(), w, mean, rstd, partials=_ln_partials(ctx.w_param),
-                                       partial_mode=_LN_PARTIAL_MODE)
+        pol = ctx.pol
+        if pol.ln_mode:
+            dx, dw = ops.layernorm_bwd(dy.contiguous(), x.contiguous(), w, mean, rstd, partials=_ln_partials(ctx.w_param, pol),
+                                       partial_mode=pol.ln_mode)
             return dx, dw
-        dx, dw = ops.layernorm_bwd(dy.contiguous(), x.contiguous(), w, mean, rstd, accumulate_into=_grad_slot(ctx.w_param))
+        dx, dw = ops.layernorm_bwd(dy.contiguous(), x.contiguous(), w, mean, rstd, accumulate_into=_grad_slot(ctx.w_param, pol))
         return dx, dw
 
 
@@ -180,6 +235,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.alpha = alpha
         ctx.w_param = w
+        ctx.pol = current_grad_policy()
         x2 = x.reshape(-1, x.shape[-1])
         y = ops.linear_fwd(x2.contiguous(), w, alpha=alpha)
         return y.view(*x.shape[:-1], w.shape[0])
@@ -191,16 +247,38 @@ class _LinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
-            dx, dw = ops.linear_bwd(dy2, x2, w, alpha=ctx.alpha, accumulate_into=_grad_slot(ctx.w_param))
+            dx, dw = ops.linear_bwd(dy2, x2, w, alpha=ctx.alpha, accumulate_into=_grad_slot(ctx.w_param, ctx.pol))
             return dx.view_as(x), dw, None
         if ctx.needs_input_grad[0]:
             dx = ops.linear_dgrad(dy2, w, alpha=ctx.alpha).view_as(x)
         if ctx.needs_input_grad[1]:
-            slot = _grad_slot(ctx.w_param)
+            slot = _grad_slot(ctx.w_param, ctx.pol)
             dw = ops.linear_wgrad(dy2, x2, alpha=ctx.alpha, accumulate_into=slot)
             if slot is not None:
                 dw = None
         return dx, dw, None
+
+
+class _LinearGeluFn(torch.autograd.Function):
+    """gelu_erf_1.41421(x W^T) (model.py:163-165) through the c_fc GEMM's fused epilogue — the same kernel, rounding and
+    saved derivative as inside ``Block`` (one erf evaluation yields the activation and gelu'(h))."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        der, act = ops.linear_fwd(x2, w, epilogue=L.EPI_GELU)
+        ctx.save_for_backward(x, w, der)
+        ctx.w_param = w
+        ctx.pol = current_grad_policy()
+        return act.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dact):
+        x, w, der = ctx.saved_tensors
+        dh = dact.reshape(-1, dact.shape[-1]) * der            # bf16(dact * gelu'(h)), as OBTE_EPI_GELU_BWD forms it
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        dx, dw = ops.linear_bwd(dh.contiguous(), x2, w, accumulate_into=_grad_slot(ctx.w_param, ctx.pol))
+        return dx.view_as(x), dw
 
 
 class _ReadoutRowsGradFn(torch.autograd.Function):
@@ -216,12 +294,13 @@ class _ReadoutRowsGradFn(torch.autograd.Function):
         ctx.save_for_backward(emb_rows, w, dlogits_rows)
         ctx.alpha = alpha
         ctx.w_param = w
+        ctx.pol = current_grad_policy()
         return torch.zeros((), dtype=torch.float32, device=emb_rows.device)
 
     @staticmethod
     def backward(ctx, dloss):
         emb_rows, w, dl = ctx.saved_tensors
-        slot = _grad_slot(ctx.w_param)
+        slot = _grad_slot(ctx.w_param, ctx.pol)
         dx, dw = ops.linear_bwd(dl, emb_rows.contiguous(), w, alpha=ctx.alpha, accumulate_into=slot)
         return dx, dw, None, None
 
@@ -234,12 +313,13 @@ class _EmbeddingFn(torch.autograd.Function):
         ctx.w_param = wte
         ctx.drop = (dropout_p, dropout_seed)
         ctx.order = order   # optional: a stable argsort of idx.reshape(-1) (int32) the caller already has
+        ctx.pol = current_grad_policy()
         return ops.embedding_fwd(idx.contiguous(), wte, dropout_p, dropout_seed)
 
     @staticmethod
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
-        return None, ops.embedding_bwd(idx.contiguous(), dout.contiguous(), ctx.vocab, accumulate_into=_grad_slot(ctx.w_param),
+        return None, ops.embedding_bwd(idx.contiguous(), dout.contiguous(), ctx.vocab, accumulate_into=_grad_slot(ctx.w_param, ctx.pol),
                                        dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1], order=ctx.order), None, None, None
 
 
@@ -255,16 +335,18 @@ class _BlockFn(torch.autograd.Function):
         ctx.n_head, ctx.mask = n_head, mask
         ctx.drop = (dropout_p, dropout_seed)
         ctx.w_params = params
+        ctx.pol = current_grad_policy()
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, act, rope_cos, rope_sin, *params = ctx.saved_tensors
-        slots = [_grad_slot(w) for w in ctx.w_params]
-        lnp = (_ln_partials(ctx.w_params[0]), _ln_partials(ctx.w_params[3])) if _LN_PARTIAL_MODE else None
+        pol = ctx.pol
+        slots = [_grad_slot(w, pol) for w in ctx.w_params]
+        lnp = (_ln_partials(ctx.w_params[0], pol), _ln_partials(ctx.w_params[3], pol)) if pol.ln_mode else None
         dx, grads = ops.block_bwd(x, dy.contiguous(), act, tuple(params), (rope_cos, rope_sin), ctx.n_head, ctx.mask,
                                   accumulate_into=slots, dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1], ln_partials=lnp,
-                                  ln_partial_mode=_LN_PARTIAL_MODE)
+                                  ln_partial_mode=pol.ln_mode)
         return (dx, *grads, None, None, None, None, None, None)
 
 
@@ -397,8 +479,7 @@ class MLP(nn.Module):
     def forward(self, x):
         _require_hip(x, "MLP")
         p = _active_p(self, self.dropout.p)
-        h = _LinearFn.apply(x, self.c_fc.weight, 1.0)
-        y = _LinearFn.apply(fused_gelu(h.float()).to(h.dtype), self.c_proj.weight, 1.0)
+        y = _LinearFn.apply(_LinearGeluFn.apply(x, self.c_fc.weight), self.c_proj.weight, 1.0)
         return _DropoutFn.apply(y, p, _new_seed(), L.SITE_MLP) if p > 0 else y
 
 
@@ -486,9 +567,11 @@ class OmniBioTA(nn.Module):
         mask = ops.MaskSpec.from_user(attn_mask, b, t, self.config.n_head, idx.device)
         p = _active_p(self, self.transformer.drop.p)
         # a training harness that sorts the token ids of a whole optimizer step in one call (the embedding backward sums
-        # gradient rows in sorted-id order) leaves this micro-batch's order here; consumed once
-        order = getattr(self, "_embedding_order", None)
-        self._embedding_order = None
+        # gradient rows in sorted-id order) hands this micro-batch's order through `with embedding_order(...)`; consumed once
+        box = _embedding_order.get()
+        order = None
+        if box is not None:
+            order, box[0] = box[0], None
         if order is not None and (order.numel() != idx.numel() or order.dtype != torch.int32 or order.device != idx.device):
             order = None
         x = _EmbeddingFn.apply(idx, wte, p, _new_seed() if p > 0 else 0, order)

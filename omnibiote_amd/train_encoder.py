@@ -128,6 +128,7 @@ class FusedAdamW(torch.optim.Optimizer):
                         raise RuntimeError("FusedAdamW needs bf16 GPU parameters with numel % 8 == 0")
                     a.p[j], a.g[j], a.m[j], a.v[j] = p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
                     a.n[j], a.lr[j], a.weight_decay[j], a.step[j] = p.numel(), float(group["lr"]), float(group["weight_decay"]), st["step"]
+                    a.lr64[j], a.weight_decay64[j] = float(group["lr"]), float(group["weight_decay"])   # un-rounded, for the _ref kernel's double-formed scalars
                 batches.append((a, group["betas"], group["eps"]))
         if not batches:
             return None
@@ -206,14 +207,17 @@ class TrainStep:
         self._slot = 0
         self._prev_bwd_done = None
         self._host_bufs = {}
+        self._ln_store = None
 
     def _inplace(self, enabled: bool, ln_partial_mode: int = 0):
         if self.loss_impl != "fused" or os.environ.get("OBTE_NO_INPLACE_ACCUM") == "1":   # CPU-oracle tests / A-B switch
             return contextlib.nullcontext()
-        from .model import accumulate_grads_inplace
+        from .model import LnPartialStore, accumulate_grads_inplace
         if self.fused_loss_fn is not None or os.environ.get("OBTE_NO_LN_PARTIALS") == "1":   # stub models / A-B switch
             ln_partial_mode = 0
-        return accumulate_grads_inplace(enabled, ln_partial_mode)
+        if self._ln_store is None:
+            self._ln_store = LnPartialStore()     # this step object's own fp32 LayerNorm partial sums
+        return accumulate_grads_inplace(enabled, ln_partial_mode, store=self._ln_store)
 
     def _mask(self, tokens: torch.Tensor, dtype, j: int = -1, k: int = 1):
         from . import masks
@@ -349,7 +353,10 @@ class TrainStep:
         """mlm_mask (optional, bool (rows, T)): the positions to corrupt instead of the host Bernoulli draw of
         train_encoder.py:273-274 (PAD/EOS are still excluded) — lets tests hand two runs the same corruption.
         input_ids_host (optional, the same batch as a host array/tensor, e.g. what the loader produced before its H2D copy):
-        lets the step form the MLM mask without waiting for the device (see _host_prelude); results are identical."""
+        lets the step form the MLM mask without waiting for the device (see _host_prelude); results are identical.
+        NEEDED for the sync-free path of the default readout (lm_head_impl="dense" / "masked" list the masked rows per
+        micro-batch): without it the final mask comes back from the device once per optimizer step — a blocking D2H copy that
+        waits for the previous step to drain (a one-time warning says so)."""
         rows = input_ids.shape[0] // self.mini * self.mini
         input_ids = input_ids[:rows]
         n_accum = rows // self.mini
@@ -368,6 +375,11 @@ class TrainStep:
             if sparse_rows:
                 # per-micro-batch row indices of the masked positions; mlm_corrupt drew the mask on the host, but PAD/EOS
                 # exclusions were applied on the device, so fetch the final mask once per optimizer step (one small D2H copy)
+                if input_ids.is_cuda and mlm_mask is None and not getattr(TrainStep, "_warned_no_host_copy", False):
+                    TrainStep._warned_no_host_copy = True
+                    import warnings
+                    warnings.warn("TrainStep: no input_ids_host given — the masked-row lists of the default readout path need a "
+                                  "blocking device-to-host copy per optimizer step (pass the loader's host copy of the batch to avoid it)")
                 mh = mask.reshape(rows // self.mini, -1).cpu()
                 self._mask_rows_host = [torch.nonzero(mh[j], as_tuple=False).reshape(-1).to(input_ids.device) for j in range(mh.shape[0])]
         dtype = next(self.model.parameters()).dtype
@@ -408,12 +420,15 @@ class TrainStep:
                 self._prev_bwd_done = None
             self._slot = (j % 2) if side else 0
             with (torch.cuda.stream(self._streams[j % 2]) if side else contextlib.nullcontext()):
-                if emb_orders is not None:
-                    core_model._embedding_order = emb_orders[j]
                 attn_mask = self._mask(y, dtype, j, k)
                 ctx = contextlib.nullcontext()
                 if hasattr(self.model, "no_sync") and not last and not self.sync_every:
                     ctx = self.model.no_sync()
+                if emb_orders is not None:    # this pass's slice of the step-wide id sort, for its embedding backward
+                    from .model import embedding_order
+                    ctx_order = embedding_order(emb_orders[j])
+                else:
+                    ctx_order = contextlib.nullcontext()
                 # all but the last pass: nobody observes the per-micro-batch gradients, so the big matrices are
                 # accumulated by the wgrad epilogues themselves (model.accumulate_grads_inplace)
                 # LayerNorm weight gradients: pass 0 delivers through autograd (there is no .grad yet), 1 .. n-2 carry
@@ -421,7 +436,7 @@ class TrainStep:
                 ln_mode = 0
                 if n_pass > 2 and not self.sync_every and j >= 1:
                     ln_mode = 1 if j == 1 else (3 if last else 2)
-                with ctx, self._inplace(not last and not self.sync_every, ln_mode):
+                with ctx, ctx_order, self._inplace(not last and not self.sync_every, ln_mode):
                     mk = mask[j * span:(j + 1) * span]
                     if self.lm_head_impl == "masked":
                         partial[self._slot] += self._masked_rows_loss_backward(x, y, mk, attn_mask, n_accum)
@@ -705,9 +720,15 @@ def run(args):
     on_gpu = getattr(args, "device", "cuda") == "cuda"
     if backend == "nccl" and not on_gpu:
         raise SystemExit("--backend nccl (RCCL) needs --device cuda; use --backend gloo for a CPU plumbing run")
-    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511"), ("RANK", "0"), ("WORLD_SIZE", "1")):
-        os.environ.setdefault(k, v)   # a bare `python train_encoder.py` is a world of one
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:   # a bare `python train_encoder.py` is a world of one;
+        os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"         # a launcher that set only one of the two is a mis-launch
+    elif "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
+        raise SystemExit("train_encoder: RANK and WORLD_SIZE must both be set by the launcher (or neither, for a single process)")
+    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29511")):
+        os.environ.setdefault(k, v)
+    # torchrun sets LOCAL_RANK; srun / mpirun style launchers set only RANK: then bind like the reference does,
+    # rank % GPUs on the node (train_encoder.py:110-111)
+    local = int(os.environ.get("LOCAL_RANK", int(os.environ["RANK"]) % max(torch.cuda.device_count(), 1) if on_gpu else 0))
     if on_gpu:
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)

@@ -140,6 +140,7 @@ def _stub_model(seed=3, V=64, C=16):
         def forward(ctx, x, w):
             ctx.save_for_backward(x, w)
             ctx.w_param = w
+            ctx.pol = M.current_grad_policy()          # captured when the graph is built, like the HIP nodes do
             return x @ w.t()
 
         @staticmethod
@@ -147,7 +148,7 @@ def _stub_model(seed=3, V=64, C=16):
             x, w = ctx.saved_tensors
             dx = dy @ w
             dw = dy.reshape(-1, dy.shape[-1]).t() @ x.reshape(-1, x.shape[-1])
-            slot = M._grad_slot(ctx.w_param)
+            slot = M._grad_slot(ctx.w_param, ctx.pol)
             if slot is not None:                       # what the wgrad epilogue does on the GPU
                 slot.add_(dw)
                 InplaceLinear.calls["inplace"] += 1

@@ -24,24 +24,35 @@ def _free_port():
 
 
 def _launch(world, backend, out_path, gpus):
+    """Each rank writes to its own log file: a rank that fills a pipe nobody drains would block in write(), its peer in a
+    collective, and the test would sit there until its timeout."""
+    import time
     port = _free_port()
-    procs = []
+    procs, logs = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, WORKER, backend, out_path, str(gpus)], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.STDOUT, text=True))
+        log = open(f"{out_path}.rank{r}.log", "w+")
+        logs.append(log)
+        procs.append(subprocess.Popen([sys.executable, WORKER, backend, out_path, str(gpus)], env=env, stdout=log, stderr=subprocess.STDOUT))
+    deadline = time.time() + 420
+    try:
+        while any(p.poll() is None for p in procs):
+            if time.time() > deadline or any(p.poll() not in (None, 0) for p in procs):   # too long, or one rank died: stop its peers
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
     outs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=420)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        outs.append(o)
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o[-3000:]
+    for log in logs:
+        log.seek(0)
+        outs.append(log.read())
+        log.close()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} exited with {p.returncode}:\n" + o[-3000:]
     return torch.load(out_path, weights_only=False)
 
 

@@ -658,3 +658,100 @@ def test_micro_batches_per_pass_gives_the_step_of_separate_passes(k):
         assert ((a - b).norm() / (b.norm() + 1e-12)).item() <= 0.02, n
         cos = (torch.dot(a, ref) / (a.norm() * ref.norm() + 1e-30)).item()
         assert cos >= 0.998 and ((a - ref).norm() / (ref.norm() + 1e-12)).item() <= 0.05, (n, cos)
+
+
+def _tiny_model(w, C, H, Lyr, V, T):
+    from omnibiote_amd.mup_compat import set_base_shapes
+    from omnibiote_amd.model import OmniBioTA, OmniBioTAConfig
+    c = OmniBioTAConfig(); c.block_size, c.vocab_size, c.n_layer, c.n_head, c.n_embd, c.dropout, c.flash = T, V, Lyr, H, C, 0.0, True
+    m = OmniBioTA(c)
+    cb = OmniBioTAConfig(); cb.block_size, cb.vocab_size, cb.n_layer, cb.dropout, cb.flash = T, V, Lyr, 0.0, True
+    cb.n_embd, cb.n_head = 24, 3
+    base = OmniBioTA(cb)
+    cb.n_embd, cb.n_head = 48, 12
+    delta = OmniBioTA(cb)
+    set_base_shapes(m, base, delta=delta, rescale_params=False)
+    m.load_state_dict(w, strict=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.to(BF)
+    return m.to(DEV)
+
+
+def test_two_train_steps_on_two_models_in_two_threads_share_no_state():
+    """The backward switches (in-place accumulation, fp32 LayerNorm partials, the embedding sort order) belong to the
+    TrainStep that built the graph: each autograd node captures them at forward time (model.GradPolicy on ctx), the fp32
+    partial buffers live in the step object.  Two steps on two different models running CONCURRENTLY in two threads of one
+    process must each produce, bit for bit, what they produce alone."""
+    import threading
+    from omnibiote_amd import train_encoder as TE
+    C, H, Lyr, V, T, rows, mini = 128, 2, 2, 512, 64, 24, 4          # 6 micro-batches: accumulate + LN partial modes 1/2/3 all occur
+    problems = []
+    for seed in (0, 1):
+        cfg = R.RefConfig(block_size=T, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C)
+        w = R.hash_weights(cfg, seed=seed)
+        ids = torch.from_numpy(TE.synthetic_rows(rows, T, V, np.random.default_rng(10 + seed), single_document=False)).to(DEV)
+        mlm = torch.from_numpy(np.random.default_rng(20 + seed).random((rows, T)) < 0.15).to(DEV)
+        problems.append((w, ids, mlm))
+
+    def run(i, out, barrier=None):
+        w, ids, mlm = problems[i]
+        torch.cuda.set_device(0)
+        m = _tiny_model(w, C, H, Lyr, V, T)
+        step = TE.TrainStep(m, TE.FusedAdamW(m.parameters(), lr=1e-3), None, mini_batch_size=mini, n_head=H)
+        losses = []
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for it in range(3):
+                if barrier is not None:
+                    barrier.wait()
+                losses.append(step(ids, mlm_mask=mlm)["loss"].item())
+            torch.cuda.current_stream().synchronize()
+        out[i] = (losses, {k: p.grad.clone() for k, p in m.named_parameters()}, {k: p.detach().clone() for k, p in m.named_parameters()})
+
+    alone, together = {}, {}
+    for i in (0, 1):
+        run(i, alone)
+    bar = threading.Barrier(2)
+    errs = []
+
+    def guarded(i):
+        try:
+            run(i, together, bar)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+            bar.abort()
+    ts = [threading.Thread(target=guarded, args=(i,)) for i in (0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in (0, 1):
+        assert alone[i][0] == together[i][0], (alone[i][0], together[i][0])
+        for k in alone[i][1]:
+            assert torch.equal(alone[i][1][k], together[i][1][k]), ("grad", i, k)
+            assert torch.equal(alone[i][2][k], together[i][2][k]), ("weight", i, k)
+
+
+def test_standalone_mlp_module_uses_the_fused_gelu_epilogue():
+    """block.mlp(x) called directly (an eval script may) runs c_fc with the same fused erf-GELU epilogue as Block, not a
+    torch-side GELU: forward and both weight gradients against the oracle's gelu_erf (model.py:23-25,162-168)."""
+    from omnibiote_amd.model import MLP, OmniBioTAConfig
+    C, M = 256, 512
+    c = OmniBioTAConfig(); c.n_embd, c.dropout, c.flash = C, 0.0, True
+    torch.manual_seed(0)
+    mlp = MLP(c).to(BF).to(DEV)
+    mlp.eval()
+    x = (torch.randn(2, M // 2, C) * 1.5).to(BF)
+    dy = (torch.randn(2, M // 2, C) * 0.1).to(BF)
+    xg = x.to(DEV).requires_grad_(True)
+    y = mlp(xg)
+    y.backward(dy.to(DEV))
+    wf, wp = mlp.c_fc.weight.detach().float().cpu().requires_grad_(True), mlp.c_proj.weight.detach().float().cpu().requires_grad_(True)
+    xf = x.float().requires_grad_(True)
+    ref = R.gelu_erf(xf @ wf.t()) @ wp.t()
+    ref.backward(dy.float())
+    for got, want, name in ((y, ref, "y"), (xg.grad, xf.grad, "dx"), (mlp.c_fc.weight.grad, wf.grad, "dW_fc"), (mlp.c_proj.weight.grad, wp.grad, "dW_proj")):
+        g, r = got.detach().float().cpu().flatten(), want.detach().flatten()
+        rel = ((g - r).norm() / (r.norm() + 1e-30)).item()
+        assert rel <= 0.012, (name, rel)    # bf16 storage of h, gelu(h), gelu'(h): ~2^-8 relative each

@@ -208,3 +208,32 @@ def test_config1_cpu_gloo_harness_is_launchable_and_fails_loudly_at_the_model(tm
     with pytest.raises(RuntimeError, match="no CPU\\s+fallback|needs GPU tensors"):
         TE.run(args)
     assert not dist.is_initialized()      # torn down on the way out
+
+
+def test_grad_policy_is_captured_per_graph_not_per_process():
+    """model.GradPolicy: the switches of the backward pass are a snapshot taken where the graph is built (a context
+    variable), immutable afterwards; another thread starts from the default and never sees this thread's setting."""
+    import threading
+    from omnibiote_amd import model as M
+    assert M.current_grad_policy().accumulate is False and M.current_grad_policy().ln_mode == 0
+    store = M.LnPartialStore()
+    seen = {}
+    with M.accumulate_grads_inplace(True, 2, store=store):
+        inner = M.current_grad_policy()
+        assert inner.accumulate and inner.ln_mode == 2 and inner.store is store
+        t = threading.Thread(target=lambda: seen.setdefault("other", M.current_grad_policy()))
+        t.start(); t.join()
+        with M.accumulate_grads_inplace(False):
+            assert not M.current_grad_policy().accumulate
+        assert M.current_grad_policy() is inner
+    assert seen["other"].accumulate is False and seen["other"].ln_mode == 0
+    assert M.current_grad_policy().accumulate is False
+    with pytest.raises(AttributeError):
+        inner.accumulate = False
+    p = torch.nn.Parameter(torch.zeros(4, 4))
+    p.grad = torch.ones(4, 4)
+    assert M._grad_slot(p, inner) is p.grad and M._grad_slot(p, M.current_grad_policy()) is None and M._grad_slot(p) is None
+    box_order = torch.arange(3, dtype=torch.int32)
+    with M.embedding_order(box_order):
+        assert M._embedding_order.get()[0] is box_order
+    assert M._embedding_order.get() is None

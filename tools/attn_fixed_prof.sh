@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 for n in 0 4 full; do
   d=gpurun_out/afp_$n; rm -rf $d
   if [ $n = full ]; then env_s=""; else env_s="tiles:$n"; fi
-  OBTE_ATTN_DEBUG=$env_s rocprofv3 --kernel-trace --stats --output-format csv -d $d -o x -- python3 tools/attn_bench.py --reps 5 > /dev/null 2>&1
+  OBTE_LIB_PATH=$PWD/omnibiote_amd/libomnibiote_hip_debug.so OBTE_ATTN_DEBUG=$env_s rocprofv3 --kernel-trace --stats --output-format csv -d $d -o x -- python3 tools/attn_bench.py --reps 5 > /dev/null 2>&1
   echo "== tiles $n"; python3 - <<PY
 import csv,glob
 for r in csv.DictReader(open(glob.glob("$d/**/x_kernel_stats.csv", recursive=True)[0])):
