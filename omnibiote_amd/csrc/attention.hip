@@ -42,53 +42,61 @@ struct AttnParams {
     int max_tiles;  // timing-only diagnostic (OBTE_ATTN_DEBUG=tiles:N): every workgroup stops after N tiles (results are wrong; 0 = off)
 };
 
+// LDS image of a [rows][D] bf16 tile: groups of 8 rows (16*D bytes), each cut into 8-row x 32-column subtiles of 512 B whose
+// 64-B rows hold their four 16-B chunks XOR-ed with row bits 2-3 (cdna_hip_programming.md T10, image (a)).  Both kinds of
+// fragment read are bank-conflict free, and — unlike plain rows with a 4-bit XOR — every read of a kernel is ONE of two
+// lane-dependent base offsets plus an immediate: the address arithmetic leaves the tile loops and ~8 VGPRs with it.
 template <int D>
 __device__ __forceinline__ int swz(int row, int ch) {
-    if (D == 128) return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
-    return row * 128 + ((ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) << 4);
+    return (16 * D) * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
 }
 
 // A/B fragment of v_mfma_f32_32x32x16_bf16 read by rows: lane l -> tile row row0 + (l&31), k = 16s + 8(l>>5) + j.
+// row0 % 32 == 0.  = tile + swz(row0 + (l&31), 2s + (l>>5)), written as lane base (two values: s even / odd) + immediate.
 template <int D>
 __device__ __forceinline__ bf16x8 row_frag(const char* tile, int row0, int s, int lane) {
-    return *reinterpret_cast<const bf16x8*>(tile + swz<D>(row0 + (lane & 31), 2 * s + (lane >> 5)));
+    const int r = lane & 31;
+    const int base = (16 * D) * (r >> 3) + 64 * (r & 7) + 16 * ((((lane >> 5) ^ (r >> 2)) & 3) ^ (2 * (s & 1)));
+    return *reinterpret_cast<const bf16x8*>(tile + base + (16 * D) * (row0 >> 3) + 512 * (s >> 1));
 }
 
 // A fragment of the TRANSPOSED tile: MFMA row = tile column 32*dt + (l&31), MFMA k element j = tile row
 // krow0 + 8(j>>2) + 4(l>>5) + (j&3)  — the row order in which a 32x32 f32 accumulator, converted in place,
 // serves as the other operand (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand").
+// krow0 % 16 == 0.  Lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of a 4 x 16 block:
+// = tile + swz(krow0 + 4(l>>5) + q [+ 8], 4dt + 2((l>>4)&1) + (p>>1)) + 8(p&1); the two reads differ by the bit-5 flip.
 template <int D>
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int krow0, int dt, int lane) {
-    const int li = lane & 15;
-    const int row = krow0 + 4 * (lane >> 5) + (li >> 2);
-    const int ch = 4 * dt + 2 * ((lane >> 4) & 1) + ((li & 3) >> 1);
-    const int sub = (li & 1) * 8;
-    const bf16x4 lo = lds_read_tr16(tile + swz<D>(row, ch) + sub);
-    const bf16x4 hi = lds_read_tr16(tile + swz<D>(row + 8, ch) + sub);
+    const int li = lane & 15, h = lane >> 5;
+    const int c2 = 2 * ((lane >> 4) & 1) + ((li & 3) >> 1);
+    const int base = 64 * (4 * h + (li >> 2)) + 16 * (c2 ^ h) + (li & 1) * 8;
+    const char* t = tile + (16 * D) * (krow0 >> 3) + 512 * dt;
+    const bf16x4 lo = lds_read_tr16(t + base);
+    const bf16x4 hi = lds_read_tr16(t + (base ^ 32) + 16 * D);
     return join8(lo, hi);
 }
 
 // Global -> LDS staging of a ROWS x D tile by LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPR round trip).
-// The DMA writes LDS linearly (wave base + lane*16), so the swizzle is applied to the SOURCE chunk each lane fetches:
-// LDS position `pos` of row r holds logical chunk pos ^ X(r) — exactly what swz<D>() reads back.  The descriptor ends
-// at the end of this batch element's rows, so rows past T arrive as zeros.  256 threads = 4 waves; wave w issues
-// pieces w, w+4, ...  Completion: the issuing wave's s_waitcnt vmcnt(0), then the workgroup barrier.
+// The DMA writes LDS linearly (wave base + lane*16), so the image is produced by choosing the SOURCE chunk each lane fetches:
+// LDS byte o = 1024*piece + 16*lane belongs to row 8*(o / 16D) + (o % 512)/64 and holds logical chunk
+// 4*((o % 16D)/512) + (((o % 64)/16) ^ ((row>>2)&3)) of it — exactly what swz<D>() reads back.  Per 1-KiB piece the wave
+// fetches 8 rows x 128 contiguous bytes (whole cache lines).  The descriptor ends at the end of this batch element's rows,
+// so rows past T arrive as zeros.  NW waves; wave w issues pieces w, w+NW, ...  Completion: the issuing wave's
+// s_waitcnt vmcnt, then the workgroup barrier.
 template <int D, int ROWS, int NW = 4>
 struct TileDma {
     static constexpr int PIECES = ROWS * 2 * D / 1024;   // 1-KiB pieces in the tile
     static constexpr int NP = PIECES >= NW ? PIECES / NW : 1;   // per wave (a tile with fewer pieces than waves: the first PIECES waves)
     static_assert(PIECES >= NW ? NP * NW == PIECES : true, "tile does not split evenly over the waves");
-    static constexpr int RPP = 1024 / (2 * D);            // rows per piece: 4 (D=128) or 8 (D=64)
-    static constexpr int CPR = D / 8;                     // chunks per row
+    static constexpr int PPG = D / 64;                    // pieces per 8-row group: 2 (D=128) or 1 (D=64)
     int voff[NP];
     __device__ __forceinline__ void init(int wave, int lane, int64_t row_stride) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int piece = wave + NW * i;
-            const int row = piece * RPP + lane / CPR;
-            const int pos = lane % CPR;
-            const int x = (D == 128) ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
-            voff[i] = (int)((row * row_stride + (pos ^ x) * 8) * 2);
+            const int row = 8 * (piece / PPG) + ((lane >> 2) & 7);
+            const int chunk = 4 * (2 * (piece % PPG) + (lane >> 5)) + ((lane & 3) ^ ((row >> 2) & 3));
+            voff[i] = (int)((row * row_stride + chunk * 8) * 2);
         }
     }
     // g: address of the tile's first row (head column applied); bytes_left: bytes from g to the end of the rows that
@@ -588,6 +596,13 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dq_kernel
 // ==========================================================================================================
 // 256 keys (eight waves) per workgroup: the Q / dO tiles every workgroup streams are then shared by
 // twice as many keys (half the L2 -> LDS traffic per key).
+// Measured and dropped this round (A/B on one box, T = 1024, B = H = 8, key ranges): running the second half of the waves one
+// phase late — every wave executes C(t-1) | A(t) B(t) per iteration, the first half places the step boundary between C and A,
+// the second after B, so that one wave's softmax arithmetic always has its SIMD partner's MFMAs beside it
+// (MI355X_MICROARCH.md "Two waves per SIMD" item 9; three Q/dO slots, P / dS carried over the loop edge, bitwise the same
+// results) took 95.3 us against 89.5 un-staggered (333 vs 316 us at T = 4096): the loop is paced by fragment reads and their
+// waits (320 KiB of LDS reads per step per CU, 40 KiB per wave), not by the vector pipe, and de-phasing the halves puts both
+// LDS-heavy phases (A: 24 x b128, C: 32 x tr_b64) side by side.
 template <int D, int MODE, bool DROP>
 __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
