@@ -74,6 +74,15 @@ int obte_layernorm_bwd_partial(const obte_bf16* dy, const obte_bf16* x, const ob
                                const float* rstd, const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dw, float* partials,
                                int64_t rows, int cols, int mode, obte_stream s);
 
+/* The same backward with a second output: dx_dropped = dropout(dx), element (row, col) of (seed, site) as obte_dropout_bf16
+ * forms it — the masked gradient the attention projection of the same block consumes (x1 = x + dropout(y W_proj^T),
+ * model.py:151,179) without a pass of its own.  partial_mode 0: ws_or_partials is the fp32 scratch of obte_layernorm_bwd_acc
+ * (accumulate_dw as there); else OBTE_LN_PARTIAL_* with ws_or_partials the persistent partial buffer. */
+int obte_layernorm_bwd_dropout(const obte_bf16* dy, const obte_bf16* x, const obte_bf16* w, const float* mean,
+                               const float* rstd, const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dx_dropped, obte_bf16* dw,
+                               float* ws_or_partials, int64_t rows, int cols, int partial_mode, int accumulate_dw,
+                               float p, uint64_t seed, int32_t site, obte_stream s);
+
 /* ---- bf16 GEMM on MFMA, fp32 accumulate (nn.Linear fwd/dgrad/wgrad: training/model.py:102,151,163,166,253)
  * D[M,N] = epilogue(alpha * sum_k A(m,k) * B(n,k)).
  *   a_kmajor=1: A(m,k) = a[m*lda + k]   (k contiguous)      a_kmajor=0: A(m,k) = a[k*lda + m]

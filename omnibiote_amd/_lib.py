@@ -80,6 +80,7 @@ SYMBOLS = {
     "obte_layernorm_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, c_stream]),
     "obte_layernorm_bwd_acc": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, C.c_int, c_stream]),
     "obte_layernorm_bwd_partial": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int, C.c_int, c_stream]),
+    "obte_layernorm_bwd_dropout": (C.c_int, [C.c_void_p] * 10 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int32, c_stream]),
     "obte_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), c_stream]),
     "obte_gemm_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "obte_gemm_bf16_ws": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_int64, c_stream]),

@@ -196,13 +196,17 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     const int lnp = d->ln_partial_mode;
     if (lnp) OBTE_REQUIRE(d->ln1_partials && d->ln2_partials && lnp >= OBTE_LN_PARTIAL_FIRST && lnp <= OBTE_LN_PARTIAL_LAST,
                           "obte_block_bwd: ln_partial_mode needs both partial buffers and a valid mode");
-    if (lnp) TRY(obte_layernorm_bwd_partial(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, d->ln2_partials, M, C, lnp, s));
-    else TRY(obte_layernorm_bwd_acc(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, lnws, M, C, acc_ln, s));                     // dx1 = dy + LN2'(dh2)
-    // attention: x1 = x + dropout(y W_proj^T)
+    // dx1 = dy + LN2'(dh2); attention: x1 = x + dropout(y W_proj^T), so its projection sees dx1 under the (seed, site 2) mask:
+    // with dropout on, the LayerNorm backward writes that masked copy beside dx1 (it used to be a pass of its own)
     const obte_bf16* dx1_proj = dx1;
     if (drop) {
-        TRY(obte_dropout_bf16(dx1, dym2, M * C, C, d->dropout_p, d->dropout_seed, SITE_RESID, s));
+        TRY(obte_layernorm_bwd_dropout(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dym2, dln2_w, lnp ? d->ln2_partials : lnws, M, C, lnp, acc_ln,
+                                       d->dropout_p, d->dropout_seed, SITE_RESID, s));
         dx1_proj = dym2;
+    } else if (lnp) {
+        TRY(obte_layernorm_bwd_partial(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, d->ln2_partials, M, C, lnp, s));
+    } else {
+        TRY(obte_layernorm_bwd_acc(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, lnws, M, C, acc_ln, s));
     }
     TRY(gemm(dx1_proj, d->proj_w, dyattn, M, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dy_attn = dx1 W_proj
     if (!grouped) TRY(gemm(dx1_proj, yat, dproj_w, C, C, M, C, C, 0, 0, wepi, accumulate_matrices ? dproj_w : nullptr, nullptr, s, gws, W.gemmws_bytes));                       // dW_proj = dx1^T y

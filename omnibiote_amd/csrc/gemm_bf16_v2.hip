@@ -825,6 +825,10 @@ static void fill_params(const obte_gemm_args* g, void* workspace, GemmParams& p)
     p.b_elems = (g->b_kmajor ? g->N : g->K) * g->ldb;
     p.store_rows = p.M;
     p.nt_store = (g->M * g->N * 2 > (256ll << 20)) ? 1 : 0;
+    // the GELU epilogue's d (the derivative, 67 MB at the hot-path shape) is read again only in the backward pass: stored
+    // non-temporally it does not push the activation d2 — the next GEMM's operand — and the operand panels out of L2 /
+    // Infinity Cache (c_fc + GELU 97.8 -> 94.5 us, cold operands)
+    if (g->epilogue == OBTE_EPI_GELU) p.nt_store = 1;
 #ifdef OBTE_DEBUG_HOOKS
     {   // timing-only diagnostics of the debug build (results are wrong): zero-record descriptors drop every LDS-DMA / no stores
         static int noload = -1, nostore = -1, exit_now = -1;

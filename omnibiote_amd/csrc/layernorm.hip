@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int LN_BWD_MAX_BLOCKS = 512;   // measured at 8192 x 1024: 256 / 384 / 512 / 768 / 1024 workgroups -> 24.5 / 23.4 / 22.9 / 25.3 / 28.1 us (backward + dw reduce)
+constexpr int LN_BWD_MAX_BLOCKS = 512;   // rows of the fp32 partial workspace; the grid itself is 256 workgroups (see the pipelined kernel)
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
@@ -142,6 +142,124 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
     }
 }
 
+// ---- pipelined backward (default) -------------------------------------------------------------------------------------
+// One row per wave at a time, as above, but the wave fetches row i+1 (x, dy, residual gradient, statistics) while it reduces
+// and stores row i: the un-pipelined kernel is a chain of dependent load -> reduce -> store rounds per wave.  Measured at
+// 8192 x 1024 with the residual gradient and the dw reduction: 24.0 us un-pipelined (512 workgroups) -> 23.3 (512), 22.3 (384),
+// 21.4 (256 workgroups: eight rows per wave).  The forward got the same treatment and gained nothing (9.7 us either way at
+// 512 / 1024 / 2048 workgroups: its 8192 waves are all resident at once, so it is one HBM round trip plus launch ramp as it
+// stands) — not kept.  Same arithmetic per row; the weight-gradient partial sums group rows by workgroup, so their fp32
+// summation order follows the grid size.
+// DROP2: also write dropout(dx) (the library's counter-based mask, element (row, col) of `dc`) to dx_drop — the gradient the
+// attention projection of the same block consumes (x1 = x + dropout(y W_proj^T): block.cpp), which used to be a pass of its own.
+template <int NCH, bool HAS_RESID, bool DROP2>
+__global__ __launch_bounds__(256) void ln_bwd_pipe_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                           const bf16* __restrict__ w, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const bf16* __restrict__ dresid,
+                                                           bf16* __restrict__ dx, float* __restrict__ ws, int64_t rows, int cols, int ws_accumulate,
+                                                           bf16* __restrict__ dx_drop, DropCfg dc) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = reinterpret_cast<float*>(smem_raw);  // [4][cols]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float wv[NCH][8], dwacc[NCH][8];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        bf16x8 t = {};
+        if (c < cols) t = *reinterpret_cast<const bf16x8*>(w + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { wv[i][j] = bf2f(t[j]); dwacc[i][j] = 0.f; }
+    }
+    const float inv_c = 1.0f / (float)cols;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    bf16x8 cx[NCH], cd[NCH], cr[NCH], nx[NCH], nd[NCH], nr[NCH];
+    float cmu = 0.f, crs = 0.f, nmu = 0.f, nrs = 0.f;
+    auto fetch = [&](int64_t r, bf16x8 (&fx)[NCH], bf16x8 (&fd)[NCH], bf16x8 (&fr)[NCH], float& fmu, float& frs) {
+        fmu = mean[r]; frs = rstd[r];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 8;
+            fx[i] = bf16x8{}; fd[i] = bf16x8{}; fr[i] = bf16x8{};
+            if (c < cols) {
+                if (HAS_RESID) fr[i] = *reinterpret_cast<const bf16x8*>(dresid + r * cols + c);
+                fx[i] = *reinterpret_cast<const bf16x8*>(x + r * cols + c);
+                fd[i] = *reinterpret_cast<const bf16x8*>(dy + r * cols + c);
+            }
+        }
+    };
+    if (row < rows) fetch(row, cx, cd, cr, cmu, crs);
+    for (; row < rows; row += stride) {
+        if (row + stride < rows) fetch(row + stride, nx, nd, nr, nmu, nrs);
+        const float mu = cmu, rs = crs;
+        float xh[NCH][8], g[NCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 8;
+            if (c < cols) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = bf2f(cd[i][j]);
+                    xh[i][j] = (bf2f(cx[i][j]) - mu) * rs;
+                    g[i][j] = d * wv[i][j];
+                    dwacc[i][j] += d * xh[i][j];
+                    s1 += g[i][j];
+                    s2 += g[i][j] * xh[i][j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { xh[i][j] = 0.f; g[i][j] = 0.f; }
+            }
+        }
+        s1 = wave_sum(s1) * inv_c;
+        s2 = wave_sum(s2) * inv_c;
+        const uint32_t rk = DROP2 ? drop_rowkey((uint64_t)row, dc) : 0u;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 8;
+            if (c < cols) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float d = rs * (g[i][j] - s1 - xh[i][j] * s2);
+                    if (HAS_RESID) d += bf2f(cr[i][j]);
+                    o[j] = f2bf(d);
+                }
+                *reinterpret_cast<bf16x8*>(dx + row * cols + c) = o;
+                if (DROP2) {
+                    bf16x8 od;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const uint32_t bits = drop_pair_bits(rk, (uint32_t)(c >> 1) + jj);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            od[2 * jj + e] = drop_keep_bits(bits, (uint32_t)e, dc) ? f2bf(bf2f(o[2 * jj + e]) * dc.scale) : f2bf(0.f);
+                    }
+                    *reinterpret_cast<bf16x8*>(dx_drop + row * cols + c) = od;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) { cx[i] = nx[i]; cd[i] = nd[i]; cr[i] = nr[i]; }
+        cmu = nmu; crs = nrs;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < cols) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wave * cols + c + j] = dwacc[i][j];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        const float t = red[c] + red[cols + c] + red[2 * cols + c] + red[3 * cols + c];
+        float* dst = ws + (int64_t)blockIdx.x * cols + c;
+        *dst = ws_accumulate ? *dst + t : t;
+    }
+}
+
 // dw[c] = sum over the per-workgroup partial rows; 32 columns x 8 row-groups per workgroup, 128-B row segments.
 // accumulate: dw = bf16(dw + bf16(sum)) — what autograd's `grad += new` would compute, without the extra launch.
 __global__ __launch_bounds__(256) void ln_dw_reduce_kernel(const float* __restrict__ ws, bf16* __restrict__ dw, int nblk, int cols, int accumulate) {
@@ -212,14 +330,14 @@ extern "C" int obte_layernorm_bwd(const obte_bf16* dy, const obte_bf16* x, const
 
 static int ln_bwd_impl(const obte_bf16* dy, const obte_bf16* x, const obte_bf16* w, const float* mean, const float* rstd,
                        const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dw, float* ws, int64_t rows, int cols, int accumulate_dw,
-                       int ws_acc, bool reduce, bool clear_tail, obte_stream s) {
+                       int ws_acc, bool reduce, bool clear_tail, obte_stream s, obte_bf16* dx_drop = nullptr, DropCfg dc = DropCfg{0, 0, 0, 1.0f}) {
     OBTE_REQUIRE(dy && x && w && mean && rstd && dx && ws && (dw || !reduce), "obte_layernorm_bwd: null pointer");
     OBTE_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 4096, "obte_layernorm_bwd: bad shape rows=%lld cols=%d", (long long)rows, cols);
     static int blocks_cap = 0;
     if (!blocks_cap) {
         const char* e = getenv("OBTE_LN_BLOCKS");   // timing experiments; the workspace admits up to LN_BWD_MAX_BLOCKS
-        blocks_cap = e ? atoi(e) : 512;
-        if (blocks_cap < 1 || blocks_cap > LN_BWD_MAX_BLOCKS) blocks_cap = 512;
+        blocks_cap = e ? atoi(e) : 256;
+        if (blocks_cap < 1 || blocks_cap > LN_BWD_MAX_BLOCKS) blocks_cap = 256;
     }
     const int nblk = (int)(cdiv64(rows, 4) < blocks_cap ? cdiv64(rows, 4) : blocks_cap);
     const dim3 grid(nblk), block(256);
@@ -231,14 +349,22 @@ static int ln_bwd_impl(const obte_bf16* dy, const obte_bf16* x, const obte_bf16*
         return OBTE_ELAUNCH;
     }
     const int prof = obte_prof_begin(st, 111, rows, cols, dresid ? 1 : 0);   // algorithmic bytes = (6 + 2 * has_resid) * rows * cols
+    static int pipe_on = -1;   // OBTE_LN_PIPE=0: the un-pipelined kernel (A/B timing; bitwise the same results)
+    if (pipe_on < 0) { const char* e = getenv("OBTE_LN_PIPE"); pipe_on = (e && e[0] == '0') ? 0 : 1; }
+    const bool drop2 = dx_drop != nullptr && dc.thresh16 != 0;
+#define LN_BWD_GO(K, ...) hipLaunchKernelGGL((K), grid, block, smem, st, (const bf16*)dy, (const bf16*)x, (const bf16*)w, mean, rstd, __VA_ARGS__)
 #define LN_BWD(N)                                                                                                           \
     do {                                                                                                                    \
-        if (dresid)                                                                                                         \
-            hipLaunchKernelGGL((ln_bwd_kernel<N, true>), grid, block, smem, st, (const bf16*)dy, (const bf16*)x, (const bf16*)w, \
-                               mean, rstd, (const bf16*)dresid, (bf16*)dx, ws, rows, cols, ws_acc);                         \
-        else                                                                                                                \
-            hipLaunchKernelGGL((ln_bwd_kernel<N, false>), grid, block, smem, st, (const bf16*)dy, (const bf16*)x, (const bf16*)w, \
-                               mean, rstd, (const bf16*)nullptr, (bf16*)dx, ws, rows, cols, ws_acc);                        \
+        if (drop2) {                                                                                                        \
+            if (dresid) LN_BWD_GO((ln_bwd_pipe_kernel<N, true, true>), (const bf16*)dresid, (bf16*)dx, ws, rows, cols, ws_acc, (bf16*)dx_drop, dc);   \
+            else LN_BWD_GO((ln_bwd_pipe_kernel<N, false, true>), (const bf16*)nullptr, (bf16*)dx, ws, rows, cols, ws_acc, (bf16*)dx_drop, dc);      \
+        } else if (pipe_on) {                                                                                               \
+            if (dresid) LN_BWD_GO((ln_bwd_pipe_kernel<N, true, false>), (const bf16*)dresid, (bf16*)dx, ws, rows, cols, ws_acc, (bf16*)nullptr, dc); \
+            else LN_BWD_GO((ln_bwd_pipe_kernel<N, false, false>), (const bf16*)nullptr, (bf16*)dx, ws, rows, cols, ws_acc, (bf16*)nullptr, dc);    \
+        } else {                                                                                                            \
+            if (dresid) LN_BWD_GO((ln_bwd_kernel<N, true>), (const bf16*)dresid, (bf16*)dx, ws, rows, cols, ws_acc);        \
+            else LN_BWD_GO((ln_bwd_kernel<N, false>), (const bf16*)nullptr, (bf16*)dx, ws, rows, cols, ws_acc);             \
+        }                                                                                                                   \
     } while (0)
     switch (nch_for(cols)) {
         case 1: LN_BWD(1); break;
@@ -248,6 +374,7 @@ static int ln_bwd_impl(const obte_bf16* dy, const obte_bf16* x, const obte_bf16*
         default: LN_BWD(16); break;
     }
 #undef LN_BWD
+#undef LN_BWD_GO
     if (!reduce) obte_prof_end(prof, st);
     OBTE_CHECK_LAUNCH("obte_layernorm_bwd");
     if (reduce) {
@@ -272,4 +399,28 @@ extern "C" int obte_layernorm_bwd_partial(const obte_bf16* dy, const obte_bf16* 
     OBTE_REQUIRE(mode >= OBTE_LN_PARTIAL_FIRST && mode <= OBTE_LN_PARTIAL_LAST, "obte_layernorm_bwd_partial: bad mode %d", mode);
     return ln_bwd_impl(dy, x, w, mean, rstd, dresid, dx, dw, partials, rows, cols, 0, mode != OBTE_LN_PARTIAL_FIRST,
                        mode == OBTE_LN_PARTIAL_LAST, mode == OBTE_LN_PARTIAL_FIRST, s);
+}
+
+extern "C" int obte_layernorm_bwd_dropout(const obte_bf16* dy, const obte_bf16* x, const obte_bf16* w, const float* mean,
+                                          const float* rstd, const obte_bf16* dresid, obte_bf16* dx, obte_bf16* dx_dropped, obte_bf16* dw,
+                                          float* ws_or_partials, int64_t rows, int cols, int partial_mode, int accumulate_dw,
+                                          float p, uint64_t seed, int32_t site, obte_stream s) {
+    OBTE_REQUIRE(dx_dropped, "obte_layernorm_bwd_dropout: null dx_dropped");
+    OBTE_REQUIRE(p >= 0.f && p < 1.f, "obte_layernorm_bwd_dropout: dropout p must be in [0,1)");
+    OBTE_REQUIRE(partial_mode == 0 || (partial_mode >= OBTE_LN_PARTIAL_FIRST && partial_mode <= OBTE_LN_PARTIAL_LAST), "obte_layernorm_bwd_dropout: bad partial_mode %d", partial_mode);
+    if (p == 0.f) {   // nothing to drop: the plain backward, then a copy (callers normally do not come here with p = 0)
+        const int rc = partial_mode ? obte_layernorm_bwd_partial(dy, x, w, mean, rstd, dresid, dx, dw, ws_or_partials, rows, cols, partial_mode, s)
+                                    : obte_layernorm_bwd_acc(dy, x, w, mean, rstd, dresid, dx, dw, ws_or_partials, rows, cols, accumulate_dw, s);
+        if (rc != OBTE_OK) return rc;
+        if (hipMemcpyAsync(dx_dropped, dx, (size_t)rows * cols * 2, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess) {
+            obte_set_error("obte_layernorm_bwd_dropout: copy failed");
+            return OBTE_ELAUNCH;
+        }
+        return OBTE_OK;
+    }
+    const DropCfg dc = make_drop(p, seed, (uint32_t)site);
+    if (partial_mode)
+        return ln_bwd_impl(dy, x, w, mean, rstd, dresid, dx, dw, ws_or_partials, rows, cols, 0, partial_mode != OBTE_LN_PARTIAL_FIRST,
+                           partial_mode == OBTE_LN_PARTIAL_LAST, partial_mode == OBTE_LN_PARTIAL_FIRST, s, dx_dropped, dc);
+    return ln_bwd_impl(dy, x, w, mean, rstd, dresid, dx, dw, ws_or_partials, rows, cols, accumulate_dw, 0, true, false, s, dx_dropped, dc);
 }

@@ -55,10 +55,11 @@ def ln_partials_buffer(cols: int, device) -> torch.Tensor:
     return torch.empty(L.lib().obte_layernorm_bwd_ws_rows() * cols, dtype=torch.float32, device=device)
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dresid=None, accumulate_into=None, partials=None, partial_mode=0):
+def layernorm_bwd(dy, x, w, mean, rstd, dresid=None, accumulate_into=None, partials=None, partial_mode=0, dropout=None):
     """accumulate_into: an existing bf16 weight gradient to add into in place (then the returned dw is None).
     partials + partial_mode (L.LN_PARTIAL_*): accumulate the weight gradient over calls in the caller's fp32 buffer; dw is
-    returned only by LN_PARTIAL_LAST (None otherwise)."""
+    returned only by LN_PARTIAL_LAST (None otherwise).
+    dropout=(p, seed, site): also return dropout(dx) under that mask as a third value (obte_layernorm_bwd_dropout)."""
     _need(dy, "dy"); _need(x, "x"); _need(w, "weight")
     _need(mean, "mean", torch.float32); _need(rstd, "rstd", torch.float32)
     cols = x.shape[-1]
@@ -67,6 +68,21 @@ def layernorm_bwd(dy, x, w, mean, rstd, dresid=None, accumulate_into=None, parti
     if dresid is not None:
         _need(dresid, "dresid"); assert dresid.shape == x.shape
     dx = torch.empty_like(x)
+    if dropout is not None:
+        dp, dseed, dsite = dropout
+        dxd = torch.empty_like(x)
+        if partial_mode:
+            _need(partials, "partials", torch.float32)
+            assert accumulate_into is None and partials.numel() == L.lib().obte_layernorm_bwd_ws_rows() * cols
+            dw = torch.empty_like(w) if partial_mode == L.LN_PARTIAL_LAST else None
+            buf = partials
+        else:
+            dw = accumulate_into if accumulate_into is not None else torch.empty_like(w)
+            buf = torch.empty(L.lib().obte_layernorm_bwd_ws_rows() * cols, dtype=torch.float32, device=x.device)
+        L.check(L.lib().obte_layernorm_bwd_dropout(_ptr(dy), _ptr(x), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dresid), _ptr(dx), _ptr(dxd), _ptr(dw),
+                                                    _ptr(buf), rows, cols, int(partial_mode), int(accumulate_into is not None), float(dp), int(dseed),
+                                                    int(dsite), _stream()), "obte_layernorm_bwd_dropout")
+        return dx, (None if (accumulate_into is not None and not partial_mode) else dw), dxd
     if partial_mode:
         _need(partials, "partials", torch.float32)
         assert accumulate_into is None and partials.numel() == L.lib().obte_layernorm_bwd_ws_rows() * cols

@@ -153,6 +153,40 @@ def test_layernorm_fwd_bwd(rows, cols):
     assert torch.equal(slot.cpu(), (old.float() + dw.cpu().float()).to(BF))
 
 
+@pytest.mark.parametrize("rows,cols", [(8192, 1024), (8197, 1024), (4101, 2048), (2051, 256)])
+def test_layernorm_pipelined_rows_and_dropped_gradient(rows, cols):
+    """Row counts at which every wave of the LayerNorm kernels walks several rows (the pipelined forms: next row's loads in
+    flight under the current row's reductions), ragged tails included, against the oracle; and the backward's second output,
+    dropout(dx) under the library's counter-based mask, bit for bit what the stand-alone dropout pass gives."""
+    x, w, dy, dres = rnd(rows, cols, seed=1, scale=2.0), (1 + 0.3 * rnd(cols, seed=2).float()).to(BF), rnd(rows, cols, seed=3), rnd(rows, cols, seed=4)
+    xf, wf = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    yref = R.layer_norm(xf, wf)
+    yref.backward(dy.float())
+    o = ops()
+    y, mean, rstd = o.layernorm_fwd(x.to(DEV), w.to(DEV))
+    close(y, yref, atol=2e-3, what="ln fwd")
+    close(mean, x.float().mean(1), atol=1e-5, rtol=1e-5, what="ln mean")
+    close(rstd, 1.0 / torch.sqrt(x.float().var(1, unbiased=False) + 1e-5), atol=1e-5, rtol=1e-4, what="ln rstd")
+    dx, dw = o.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, dresid=dres.to(DEV))
+    close(dx, xf.grad + dres.float(), atol=8e-3, what="ln dx+resid")
+    close(dw, wf.grad, atol=0.02 * math.sqrt(rows), what="ln dw")
+    p, seed, site = 0.1, 1234567, 2
+    dx2, dw2, dxd = o.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, dresid=dres.to(DEV), dropout=(p, seed, site))
+    assert torch.equal(dx2, dx) and torch.equal(dw2, dw)
+    assert torch.equal(dxd, o.dropout(dx, p, seed, site))
+    kept = (dxd != 0).float().mean().item()
+    assert abs(kept - 0.9) < 0.01
+    # partial-sum mode with the dropped output: same dx / dropped dx, weight gradient from the fp32 partials
+    part = o.ln_partials_buffer(cols, DEV)
+    from omnibiote_amd import _lib as L
+    dx3, none, dxd3 = o.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, dresid=dres.to(DEV), partials=part, partial_mode=L.LN_PARTIAL_FIRST,
+                                      dropout=(p, seed, site))
+    assert none is None and torch.equal(dx3, dx) and torch.equal(dxd3, dxd)
+    _, dw3, _ = o.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, dresid=dres.to(DEV), partials=part, partial_mode=L.LN_PARTIAL_LAST,
+                                dropout=(p, seed, site))
+    close(dw3, 2.0 * wf.grad, atol=0.04 * math.sqrt(rows), what="ln dw from partials")
+
+
 # ------------------------------------------------------------------------------------------------------- RoPE
 @pytest.mark.parametrize("hs", [64, 128])
 @pytest.mark.parametrize("mode", ["complex", "cos_only"])
