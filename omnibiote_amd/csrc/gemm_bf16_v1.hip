@@ -184,6 +184,67 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
             for (int r = 0; r < 4; ++r) v[r] = f2bf(acc[ni][mi][r] * p.alpha);
             *reinterpret_cast<bf16x4*>(stg + (mi * 16 + em) * EPI_LD + (ni * 16 + en) * 2) = v;
         }
+    // interior tiles whose epilogue reads global memory: every such load before the first store (see gemm_bf16_v2.hip,
+    // tile_epilogue: vmcnt retires in issue order, so a load behind a store waits for the store)
+    constexpr bool READS = EPI == OBTE_EPI_ADD || EPI == OBTE_EPI_GELU_BWD || EPI == OBTE_EPI_ADD_DROPOUT || EPI == OBTE_EPI_ROPE_QK;
+    if (READS && m0 + 128 <= p.M && n0 + 128 <= p.N) {
+        const int row_l = lane >> 3, c8 = lane & 7;
+        const int64_t n = n0 + wn * 64 + c8 * 8;
+        const int64_t o0 = (m0 + wm * 64 + row_l) * p.ldd + n;
+        bf16x8 r[8];
+        f32x4 rc[8], rs[8];
+        bool rot = false;
+        if (EPI == OBTE_EPI_ROPE_QK) {
+            rot = n < 2 * (p.N / 3);
+            const uint32_t T32 = (uint32_t)p.rope_T, hs32 = (uint32_t)p.rope_hs, nu = (uint32_t)n;
+            const uint32_t dd = (hs32 & (hs32 - 1)) == 0 ? (nu & (hs32 - 1)) : (nu % hs32);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const uint32_t mu = (uint32_t)(m0 + wm * 64 + row_l + it * 8);
+                const uint32_t t = (T32 & (T32 - 1)) == 0 ? (mu & (T32 - 1)) : (mu % T32);
+                rc[it] = *reinterpret_cast<const f32x4*>(p.rope_cos + t * (hs32 / 2) + dd / 2);
+                rs[it] = *reinterpret_cast<const f32x4*>(p.rope_sin + t * (hs32 / 2) + dd / 2);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) r[it] = *reinterpret_cast<const bf16x8*>(p.aux + o0 + (int64_t)it * 8 * p.ldd);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + (it * 8 + row_l) * EPI_LD + c8 * 16);
+            if (EPI == OBTE_EPI_ADD) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(r[it][j]) + bf2f(v[j]));
+            } else if (EPI == OBTE_EPI_GELU_BWD) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * bf2f(r[it][j]));
+            } else if (EPI == OBTE_EPI_ROPE_QK) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xe = bf2f(v[2 * j]), xo = bf2f(v[2 * j + 1]);
+                    const bf16 ne = f2bf(xe * rc[it][j] - xo * rs[it][j]), no = f2bf(xe * rs[it][j] + xo * rc[it][j]);
+                    v[2 * j] = rot ? ne : v[2 * j];
+                    v[2 * j + 1] = rot ? no : v[2 * j + 1];
+                }
+            } else if (EPI == OBTE_EPI_ADD_DROPOUT) {
+                const int64_t m = m0 + wm * 64 + row_l + it * 8;
+                const uint32_t rk = drop_rowkey((uint64_t)m, p.drop);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const uint32_t bits = drop_pair_bits(rk, (uint32_t)(n >> 1) + jj);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * jj + e;
+                        const float t = drop_keep_bits(bits, (uint32_t)e, p.drop) ? bf2f(f2bf(bf2f(v[j]) * p.drop.scale)) : 0.f;
+                        v[j] = f2bf(bf2f(r[it][j]) + t);
+                    }
+                }
+            }
+            *reinterpret_cast<bf16x8*>(p.d + o0 + (int64_t)it * 8 * p.ldd) = v;
+        }
+        return;
+    }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
@@ -214,10 +275,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
                 // packed c_attn output [.., 3C]: rotate the (even, odd) pairs of the q and k thirds (columns < 2N/3),
                 // position = row % T; the v third passes through.  fp32 arithmetic on the bf16-rounded projection.
                 if (n < 2 * (p.N / 3)) {
-                    const int64_t t = m % p.rope_T;
-                    const int dd = (int)(n % p.rope_hs);
-                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + t * (p.rope_hs / 2) + dd / 2);
-                    const f32x4 sn = *reinterpret_cast<const f32x4*>(p.rope_sin + t * (p.rope_hs / 2) + dd / 2);
+                    // position and in-head column by 32-bit arithmetic, masks when T / head_dim are powers of two (uniform
+                    // branches): the 64-bit `%` this replaced was a software division per 16-byte chunk — 9 to 22 us of
+                    // the 65-us c_attn GEMM
+                    const uint32_t mu = (uint32_t)m, nu = (uint32_t)n, T32 = (uint32_t)p.rope_T, hs32 = (uint32_t)p.rope_hs;
+                    const uint32_t t = (T32 & (T32 - 1)) == 0 ? (mu & (T32 - 1)) : (mu % T32);
+                    const uint32_t dd = (hs32 & (hs32 - 1)) == 0 ? (nu & (hs32 - 1)) : (nu % hs32);
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + t * (hs32 / 2) + dd / 2);
+                    const f32x4 sn = *reinterpret_cast<const f32x4*>(p.rope_sin + t * (hs32 / 2) + dd / 2);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float xe = bf2f(v[2 * j]), xo = bf2f(v[2 * j + 1]);

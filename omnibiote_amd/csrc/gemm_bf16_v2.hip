@@ -52,6 +52,7 @@ struct GemmParams {
     int64_t M, N, K, lda, ldb, ldd;
     int64_t store_rows;   // = M; 0 in the timing-only 'nostore' diagnostic
     int nt_store;         // non-temporal output stores (outputs that exceed the 256-MiB Infinity Cache)
+    int delay_sleeps;     // debug build only: every second workgroup of a CU (odd hardware wave slot) sleeps this many x 3.4 us first
     int64_t a_elems, b_elems;
     int tiles_m, tiles_n, splits, k_per_split;   // k_per_split in K-tiles
     float alpha;
@@ -118,7 +119,7 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, int mn0, int s, in
 // Tile epilogue shared by both main-loop structures: stage the accumulators through LDS, apply EPI, write 16-B pieces.
 template <int EPI, bool SPLIT, int BN>
 __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[BN / 32][4], char* smem, int wave, int lane,
-                                              int64_t m0, int64_t n0, int wm, int wn, int split) {
+                                              int64_t m0, int64_t n0, int wm, int wn, int split, int tile_n = BN) {
     constexpr int NJ = BN / 32, NW = BN / 2;
     __syncthreads();  // all fragment reads done (and no DMA outstanding): LDS becomes the epilogue staging area
 
@@ -164,6 +165,73 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
             for (int r = 0; r < 4; ++r) v[r] = f2bf(acc[ni][mi][r] * p.alpha);
             *reinterpret_cast<bf16x4*>(stg + (mi * 16 + em) * LDE + (ni * 16 + en) * 2) = v;
         }
+    // Interior tiles whose epilogue READS global memory (residual / gradient accumulation, GELU', dropout + residual, RoPE
+    // tables) take a branch-free path that issues every one of those loads BEFORE the first store.  In the guarded loop below
+    // each iteration is load -> s_waitcnt vmcnt(0) -> arithmetic -> store behind a bounds branch hipcc does not schedule
+    // across, and vmcnt retires in issue order: every load waited for the previous iteration's STORE to reach memory — 16
+    // dependent round trips per tile (c_fc dgrad + GELU': 38 of its 103 us were this epilogue).
+    constexpr bool READS = EPI == OBTE_EPI_ADD || EPI == OBTE_EPI_GELU_BWD || EPI == OBTE_EPI_ADD_DROPOUT || EPI == OBTE_EPI_ROPE_QK;
+    constexpr int NIT = 64 / RPI;
+    const bool interior = m0 + BM <= p.store_rows && n0 + tile_n <= p.N && (EPI != OBTE_EPI_ADD || p.aux != nullptr);
+    if (READS && interior) {
+        const int row_l = lane / CPRE, c8 = lane % CPRE;
+        const int64_t n = n0 + wn * NW + c8 * 8;
+        const int64_t o0 = (m0 + wm * 64 + row_l) * p.ldd + n;
+        bf16x8 r[NIT];
+        f32x4 rc[NIT], rs[NIT];
+        bool rot = false;
+        if (EPI == OBTE_EPI_ROPE_QK) {
+            rot = n < 2 * (p.N / 3);   // lanes on the v third load the same (valid) table rows and leave their values alone
+            const uint32_t T32 = (uint32_t)p.rope_T, hs32 = (uint32_t)p.rope_hs, nu = (uint32_t)n;
+            const uint32_t dd = (hs32 & (hs32 - 1)) == 0 ? (nu & (hs32 - 1)) : (nu % hs32);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const uint32_t mu = (uint32_t)(m0 + wm * 64 + row_l + it * RPI);
+                const uint32_t t = (T32 & (T32 - 1)) == 0 ? (mu & (T32 - 1)) : (mu % T32);
+                rc[it] = *reinterpret_cast<const f32x4*>(p.rope_cos + t * (hs32 / 2) + dd / 2);
+                rs[it] = *reinterpret_cast<const f32x4*>(p.rope_sin + t * (hs32 / 2) + dd / 2);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) r[it] = *reinterpret_cast<const bf16x8*>(p.aux + o0 + (int64_t)it * RPI * p.ldd);
+        }
+        __syncthreads();   // the staged tile is complete
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + (it * RPI + row_l) * LDE + c8 * 16);
+            const int64_t o = o0 + (int64_t)it * RPI * p.ldd;
+            if (EPI == OBTE_EPI_ADD) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(r[it][j]) + bf2f(v[j]));
+            } else if (EPI == OBTE_EPI_GELU_BWD) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * bf2f(r[it][j]));
+            } else if (EPI == OBTE_EPI_ROPE_QK) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xe = bf2f(v[2 * j]), xo = bf2f(v[2 * j + 1]);
+                    const bf16 ne = f2bf(xe * rc[it][j] - xo * rs[it][j]), no = f2bf(xe * rs[it][j] + xo * rc[it][j]);
+                    v[2 * j] = rot ? ne : v[2 * j];
+                    v[2 * j + 1] = rot ? no : v[2 * j + 1];
+                }
+            } else if (EPI == OBTE_EPI_ADD_DROPOUT) {
+                const int64_t m = m0 + wm * 64 + row_l + it * RPI;
+                const uint32_t rk = drop_rowkey((uint64_t)m, p.drop);   // dropout element = (row m, column n + j)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const uint32_t bits = drop_pair_bits(rk, (uint32_t)(n >> 1) + jj);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * jj + e;
+                        const float t = drop_keep_bits(bits, (uint32_t)e, p.drop) ? bf2f(f2bf(bf2f(v[j]) * p.drop.scale)) : 0.f;
+                        v[j] = f2bf(bf2f(r[it][j]) + t);
+                    }
+                }
+            }
+            *reinterpret_cast<bf16x8*>(p.d + o) = v;
+        }
+        return;
+    }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 64 / RPI; ++it) {
@@ -196,10 +264,14 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
                 // packed c_attn output [.., 3C]: rotate the (even, odd) pairs of the q and k thirds (columns < 2N/3),
                 // position = row % T; the v third passes through.  fp32 arithmetic on the bf16-rounded projection.
                 if (n < 2 * (p.N / 3)) {
-                    const int64_t t = m % p.rope_T;
-                    const int dd = (int)(n % p.rope_hs);
-                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + t * (p.rope_hs / 2) + dd / 2);
-                    const f32x4 sn = *reinterpret_cast<const f32x4*>(p.rope_sin + t * (p.rope_hs / 2) + dd / 2);
+                    // position and in-head column by 32-bit arithmetic, masks when T / head_dim are powers of two (uniform
+                    // branches): the 64-bit `%` this replaced was a software division per 16-byte chunk — 9 to 22 us of
+                    // the 65-us c_attn GEMM
+                    const uint32_t mu = (uint32_t)m, nu = (uint32_t)n, T32 = (uint32_t)p.rope_T, hs32 = (uint32_t)p.rope_hs;
+                    const uint32_t t = (T32 & (T32 - 1)) == 0 ? (mu & (T32 - 1)) : (mu % T32);
+                    const uint32_t dd = (hs32 & (hs32 - 1)) == 0 ? (nu & (hs32 - 1)) : (nu % hs32);
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(p.rope_cos + t * (hs32 / 2) + dd / 2);
+                    const f32x4 sn = *reinterpret_cast<const f32x4*>(p.rope_sin + t * (hs32 / 2) + dd / 2);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float xe = bf2f(v[2 * j]), xo = bf2f(v[2 * j + 1]);
@@ -621,6 +693,212 @@ int dispatch3(const GemmParams& p, int epi, hipStream_t st) {
     return OBTE_EINVAL;
 }
 
+// ---- fourth structure: 256x128 tile, FOUR waves, ring of THREE half K-tiles (24 KiB each), TWO workgroups per CU ------------
+// What the K = 1024 shapes of the block lose (measured with the timing-only hooks on c_fc + GELU, 8192 x 4096 x 1024: 96 us
+// as it stands, 68 us without its stores, 52 us without loads and stores) is the store phase: with one workgroup per CU and
+// one or two rounds of equal tiles every CU multiplies at the same time and then every CU stores at the same time — the
+// matrix pipes idle while 134 MB drain at HBM rate.  A wave's own stores cannot hide under its own next tile either: vmcnt
+// retires in issue order, so the first LDS-DMA wait behind a store burst waits for the burst.  The overlap has to come from a
+// SECOND workgroup on the same CU.  This structure is the half-tile ring cut to fit twice: 4 waves x (64 x 128) output per
+// wave (the same per-wave tile, fragments and MFMA interleave as the 256x256 structure), 256 threads, <= 256 VGPRs, 72 KiB of
+// LDS (three half-stages, two of them in flight), so that two independent workgroups share each CU and each SIMD hosts one
+// wave of either: their barriers, DMA waits and epilogues are unrelated and drift apart.
+constexpr int V4_THREADS = 256;
+constexpr int V4_BT = 128 * 32 * 2;             // 8 KiB: the B half tile (A: H_TILE = 16 KiB)
+constexpr int V4_STAGE = H_TILE + V4_BT;        // 24 KiB
+constexpr int V4_RING = 3 * V4_STAGE;           // 72 KiB
+constexpr int V4_EPI = 4 * 64 * 272;            // epilogue staging of four 64 x 128 wave tiles
+constexpr int V4_SMEM = V4_RING > V4_EPI ? V4_RING : V4_EPI;
+
+// byte offsets of the LDS-DMA pieces (piece = wave + 4*i) of a half tile [MN rows][32 k] (k-contiguous) or [32 k][MN] (k-strided)
+template <bool KMAJOR, int MN, int NP>
+__device__ __forceinline__ void dma_offsets_v4(int wave, int lane, int64_t ld, int (&voff)[NP]) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int piece = wave + 4 * i;
+        if (KMAJOR) {
+            const int row = piece * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((4 - (row >> 2)) & 3);
+            voff[i] = (int)((row * ld + chunk * 8) * 2);
+        } else {
+            constexpr int CPR = MN / 8;          // 16-B chunks per k-row: 32 (A) or 16 (B)
+            constexpr int RPP = 64 / CPR;        // k-rows per 1-KiB piece: 2 or 4
+            const int krow = piece * RPP + lane / CPR;
+            const int chunk = (lane % CPR) ^ mn_f(krow);
+            voff[i] = (int)((krow * ld + chunk * 8) * 2);
+        }
+    }
+}
+template <bool KMAJOR, int MN>
+__device__ __forceinline__ bf16x8 load_frag_v4(const char* tile, int mn0, int lane) {
+    if (KMAJOR) return *reinterpret_cast<const bf16x8*>(tile + kmaj32_off(mn0 + (lane & 15), lane >> 4));
+    return load_frag<false, MN>(tile, mn0, 0, lane);
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPLIT>
+__global__ __launch_bounds__(V4_THREADS, 2) void gemm_v4_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.store_rows < 0) return;
+#ifdef OBTE_DEBUG_HOOKS
+    if (p.delay_sleeps > 0 && blockIdx.x < 512) {   // first round only: HW_REG_HW_ID[3:0] = wave slot on the SIMD
+        const unsigned hw = __builtin_amdgcn_s_getreg(0x1804);
+        if (hw & 1) for (int i = 0; i < p.delay_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+    constexpr int NJ = 8;
+    const int wgid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.splits);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int split = wgid % p.splits;
+    const int tid_ = wgid / p.splits;
+    const int group_sz = 8 * p.tiles_n;
+    const int first_m = (tid_ / group_sz) * 8;
+    const int gsz = min(p.tiles_m - first_m, 8);
+    const int tm = first_m + (tid_ % group_sz) % gsz;
+    const int tn = (tid_ % group_sz) / gsz;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * 128;
+
+    int voff_a[4], voff_b[2];
+    dma_offsets_v4<A_KMAJOR, 256, 4>(wave, lane, p.lda, voff_a);
+    dma_offsets_v4<B_KMAJOR, 128, 2>(wave, lane, p.ldb, voff_b);
+
+    f32x4 acc[NJ][4];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk_total = (int)((p.K + BKT - 1) / BKT);
+    const int kt0 = split * p.k_per_split;
+    const int nh = 2 * min(p.k_per_split, nk_total - kt0);   // half-steps; even, >= 4 (checked by the host)
+
+    // LDS-DMA of half-stage u into ring slot `slot`: pieces g = 0..3 of A and 0..1 of B for this wave
+    auto dma_piece = [&](int u, int slot, int g) {
+        const int64_t k0 = (int64_t)kt0 * BKT + (int64_t)u * 32;
+        const int64_t ao = A_KMAJOR ? (m0 * p.lda + k0) : (k0 * p.lda + m0);
+        const uint32_t lds_st = lds_addr_of(smem + slot * V4_STAGE) + wave * 1024;
+        lds_dma16(make_rsrc_words(p.a + ao, (p.a_elems - ao) * 2), lds_st + 4 * g * 1024, voff_a[g]);
+        if (g < 2) {
+            const int64_t bo = B_KMAJOR ? (n0 * p.ldb + k0) : (k0 * p.ldb + n0);
+            lds_dma16(make_rsrc_words(p.b + bo, (p.b_elems - bo) * 2), lds_st + H_TILE + 4 * g * 1024, voff_b[g]);
+        }
+    };
+    auto issue = [&](int u, int slot) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dma_piece(u, slot, g);
+    };
+    auto load_frags = [&](int slot, bf16x8 (&af)[4], bf16x8 (&bfr)[NJ]) {
+        const char* ta = smem + slot * V4_STAGE;
+        const char* tb = ta + H_TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = load_frag_v4<A_KMAJOR, 256>(ta, wave * 64 + i * 16, lane);
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) bfr[i] = load_frag_v4<B_KMAJOR, 128>(tb, i * 16, lane);
+    };
+    auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[NJ]) {
+#pragma unroll
+        for (int ni = 0; ni < NJ; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    };
+    // half-step uu with F(uu) in (af, bfr): group g = {A fragment g and B fragments 2g, 2g+1 of half-step uu+1 from slot rs,
+    // the LDS-DMA pieces g of half-step uu+3 into slot ds (= the slot of uu: every wave holds F(uu) in registers since the
+    // barrier), the 8 MFMAs of n sub-tiles 2g, 2g+1}
+    auto istep = [&](int uu, int rs, int ds, const bf16x8 (&af)[4], const bf16x8 (&bfr)[NJ], bf16x8 (&an)[4], bf16x8 (&bn)[NJ]) {
+        const char* ta = smem + rs * V4_STAGE;
+        const char* tb = ta + H_TILE;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            an[g] = load_frag_v4<A_KMAJOR, 256>(ta, wave * 64 + g * 16, lane);
+            bn[2 * g] = load_frag_v4<B_KMAJOR, 128>(tb, (2 * g) * 16, lane);
+            bn[2 * g + 1] = load_frag_v4<B_KMAJOR, 128>(tb, (2 * g + 1) * 16, lane);
+            dma_piece(uu + 3, ds, g);
+#pragma unroll
+            for (int ni = 2 * g; ni < 2 * g + 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    bf16x8 a0[4], b0[NJ], a1[4], b1[NJ];
+    issue(0, 0); issue(1, 1); issue(2, 2);
+    __builtin_amdgcn_s_waitcnt(0x007C);   // vmcnt(12): half-stage 0 landed (two stages of six pieces stay in flight)
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, a0, b0);
+    int u = 0;
+    int s0 = 0, s1 = 1, s2 = 2;           // ring slots of half-steps u, u+1, u+2
+    for (; u + 4 < nh; u += 2) {
+        __builtin_amdgcn_s_waitcnt(0x0076);   // vmcnt(6) lgkmcnt(0): half-stage u+1 landed, F(u) reads complete
+        __builtin_amdgcn_s_barrier();
+        istep(u, s1, s0, a0, b0, a1, b1);      // DMA(u+3) -> slot of u
+        __builtin_amdgcn_s_waitcnt(0x0076);
+        __builtin_amdgcn_s_barrier();
+        istep(u + 1, s2, s1, a1, b1, a0, b0);  // DMA(u+4) -> slot of u+1
+        const int t = s0; s0 = s2; s2 = s1; s1 = t;   // slots of u+2, u+3 (= old s0), u+4 (= old s1)
+    }
+    // last four half-steps (u == nh - 4): half-stage u+3 is still to be issued, then the waits count down
+    __builtin_amdgcn_s_waitcnt(0x0076);
+    __builtin_amdgcn_s_barrier();
+    istep(u, s1, s0, a0, b0, a1, b1);          // DMA(u+3) -> s0; F(u+1) -> (a1, b1)
+    __builtin_amdgcn_s_waitcnt(0x0076);        // half-stage u+2 landed (u+3 in flight)
+    __builtin_amdgcn_s_barrier();
+    load_frags(s2, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0): half-stage u+3 landed
+    __builtin_amdgcn_s_barrier();
+    load_frags(s0, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0);
+    mma(a1, b1);
+    tile_epilogue<EPI, SPLIT, 256>(p, acc, smem, wave, lane, m0, n0, wave, 0, split, 128);   // the 64 x 128 wave tile of the 256-wide epilogue
+}
+
+#define OBTE_INST4(AK, BK)                                                                   \
+    template __global__ void gemm_v4_kernel<AK, BK, OBTE_EPI_NONE, true>(GemmParams);        \
+    template __global__ void gemm_v4_kernel<AK, BK, OBTE_EPI_NONE, false>(GemmParams);       \
+    template __global__ void gemm_v4_kernel<AK, BK, OBTE_EPI_GELU, false>(GemmParams);       \
+    template __global__ void gemm_v4_kernel<AK, BK, OBTE_EPI_ADD, false>(GemmParams);        \
+    template __global__ void gemm_v4_kernel<AK, BK, OBTE_EPI_GELU_BWD, false>(GemmParams);   \
+    template __global__ void gemm_v4_kernel<AK, BK, OBTE_EPI_ADD_DROPOUT, false>(GemmParams); \
+    template __global__ void gemm_v4_kernel<AK, BK, OBTE_EPI_ROPE_QK, false>(GemmParams);
+OBTE_INST4(true, true)
+OBTE_INST4(true, false)
+OBTE_INST4(false, true)
+OBTE_INST4(false, false)
+#undef OBTE_INST4
+
+template <bool AK, bool BK, int EPI, bool SPLIT>
+int launch4(const GemmParams& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_v4_kernel<AK, BK, EPI, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, V4_SMEM);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_v4_kernel<AK, BK, EPI, SPLIT>), dim3(p.tiles_m * p.tiles_n * p.splits), dim3(V4_THREADS), V4_SMEM, st, p);
+    OBTE_CHECK_LAUNCH("obte_gemm_bf16");
+    return OBTE_OK;
+}
+
+template <bool AK, bool BK>
+int dispatch4(const GemmParams& p, int epi, hipStream_t st) {
+    if (p.splits > 1) return launch4<AK, BK, OBTE_EPI_NONE, true>(p, st);
+    switch (epi) {
+        case OBTE_EPI_NONE: return launch4<AK, BK, OBTE_EPI_NONE, false>(p, st);
+        case OBTE_EPI_GELU: return launch4<AK, BK, OBTE_EPI_GELU, false>(p, st);
+        case OBTE_EPI_ADD: return launch4<AK, BK, OBTE_EPI_ADD, false>(p, st);
+        case OBTE_EPI_GELU_BWD: return launch4<AK, BK, OBTE_EPI_GELU_BWD, false>(p, st);
+        case OBTE_EPI_ADD_DROPOUT: return launch4<AK, BK, OBTE_EPI_ADD_DROPOUT, false>(p, st);
+        case OBTE_EPI_ROPE_QK: return launch4<AK, BK, OBTE_EPI_ROPE_QK, false>(p, st);
+    }
+    obte_set_error("obte_gemm_bf16: unknown epilogue %d", epi);
+    return OBTE_EINVAL;
+}
+
 // d[m][n] = bf16(alpha * sum_s slab[s][m][n]) in split order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, bf16* __restrict__ d, const bf16* aux,
                                                              int64_t MN4, int64_t MN, int splits, float alpha) {
@@ -690,13 +968,20 @@ bool use_v3(int variant) {
     return e && e[0] == 'v' && e[1] == '3';
 }
 
+// OBTE_GEMM=v4 forces the two-workgroups-per-CU structure wherever the plan is 128 wide (tests / A-B timing)
+bool use_v4(int variant) {
+    if (variant == 4) return true;
+    const char* e = getenv("OBTE_GEMM");   // not cached: the tests flip it
+    return e && e[0] == 'v' && e[1] == '4';
+}
+
 }  // namespace obte_gemm_v2
 using namespace obte_gemm_v2;
 
 // Tile width and split-K plan.  Prefer the 256-wide tile (higher FLOP per loaded byte) whenever it still yields
 // at least one workgroup per CU, directly or through a split of a long K; otherwise the 128-wide tile.
 // Split-K needs a workspace, epilogue NONE and ldd == N.
-struct Plan { int bn; int splits; int variant; };   // variant: 1 = first structure (gemm_bf16_v1.hip), 2 / 3 = this file (K-tile ring / half-tile ring)
+struct Plan { int bn; int splits; int variant; };   // variant: 1 = first structure (gemm_bf16_v1.hip), 2 / 3 / 4 = this file (K-tile ring / half-tile ring / half-tile ring at two workgroups per CU)
 static int splits_for(int64_t tiles, int64_t nk) {
     if (tiles >= 200 || nk < 16) return 1;
     int s = (int)(256 / tiles);   // the largest split whose tiles * s workgroups still fit ONE round of the 256 CUs (rounding up instead
@@ -757,8 +1042,9 @@ static bool lookup_plan(const obte_gemm_args* g, Plan* out, bool* near_match = n
 
 extern "C" int obte_gemm_plan_set(int a_kmajor, int b_kmajor, int epilogue, int64_t M, int64_t N, int64_t K, int variant,
                                   int bn, int splits) {
-    OBTE_REQUIRE(variant >= 1 && variant <= 3 && (bn == 128 || bn == 256) && splits >= 1 && splits <= 64, "obte_gemm_plan_set: bad plan");
+    OBTE_REQUIRE(variant >= 1 && variant <= 4 && (bn == 128 || bn == 256) && splits >= 1 && splits <= 64, "obte_gemm_plan_set: bad plan");
     OBTE_REQUIRE(!(variant == 3 && bn != 256), "obte_gemm_plan_set: the four-half-stage structure is 256 wide");
+    OBTE_REQUIRE(!(variant == 4 && bn != 128), "obte_gemm_plan_set: the two-workgroups-per-CU structure is 128 wide");
     OBTE_REQUIRE(!(variant == 1 && splits != 1), "obte_gemm_plan_set: the first structure has no split-K");
     std::lock_guard<std::mutex> lk(g_plan_mu);
     g_plans[PlanKey((a_kmajor ? 2 : 0) + (b_kmajor ? 1 : 0), epilogue, M, N, K)] = Plan{bn, splits, variant};
@@ -824,6 +1110,7 @@ static void fill_params(const obte_gemm_args* g, void* workspace, GemmParams& p)
     p.a_elems = (g->a_kmajor ? g->M : g->K) * g->lda;
     p.b_elems = (g->b_kmajor ? g->N : g->K) * g->ldb;
     p.store_rows = p.M;
+    p.delay_sleeps = 0;
     p.nt_store = (g->M * g->N * 2 > (256ll << 20)) ? 1 : 0;
     // the GELU epilogue's d (the derivative, 67 MB at the hot-path shape) is read again only in the backward pass: stored
     // non-temporally it does not push the activation d2 — the next GEMM's operand — and the operand panels out of L2 /
@@ -841,6 +1128,9 @@ static void fill_params(const obte_gemm_args* g, void* workspace, GemmParams& p)
         }
         if (noload) { p.a_elems = 0; p.b_elems = 0; }
         if (exit_now) p.store_rows = -1; else if (nostore) p.store_rows = 0;
+        static int delay = -1;
+        if (delay < 0) { const char* d = getenv("OBTE_GEMM_V4_DELAY"); delay = d ? atoi(d) : 0; }
+        p.delay_sleeps = delay;
     }
 #endif
 }
@@ -878,9 +1168,16 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     p.alpha = g->alpha;
     p.rope_cos = g->rope_cos; p.rope_sin = g->rope_sin; p.rope_T = g->rope_T; p.rope_hs = g->rope_head_dim;
     p.drop = make_drop(g->epilogue == OBTE_EPI_ADD_DROPOUT ? g->dropout_p : 0.f, g->dropout_seed, (uint32_t)g->dropout_site);
-    const bool v3 = use_v3(pl.variant) && pl.bn == 256 && p.k_per_split >= 2 && nk - (int64_t)(p.splits - 1) * p.k_per_split >= 2;
-    const int prof = obte_prof_begin(st, kind0 + (v3 ? 3000 : 2000), g->M, g->N, g->K);
-    if (v3) {
+    const bool long_enough = p.k_per_split >= 2 && nk - (int64_t)(p.splits - 1) * p.k_per_split >= 2;   // the half-tile rings need >= 4 half-steps
+    const bool v3 = use_v3(pl.variant) && pl.bn == 256 && long_enough;
+    const bool v4 = !v3 && use_v4(pl.variant) && pl.bn == 128 && long_enough;
+    const int prof = obte_prof_begin(st, kind0 + (v3 ? 3000 : (v4 ? 4000 : 2000)), g->M, g->N, g->K);
+    if (v4) {
+        if (g->a_kmajor && g->b_kmajor) rc = dispatch4<true, true>(p, g->epilogue, st);
+        else if (g->a_kmajor && !g->b_kmajor) rc = dispatch4<true, false>(p, g->epilogue, st);
+        else if (!g->a_kmajor && g->b_kmajor) rc = dispatch4<false, true>(p, g->epilogue, st);
+        else rc = dispatch4<false, false>(p, g->epilogue, st);
+    } else if (v3) {
         if (g->a_kmajor && g->b_kmajor) rc = dispatch3<true, true>(p, g->epilogue, st);
         else if (g->a_kmajor && !g->b_kmajor) rc = dispatch3<true, false>(p, g->epilogue, st);
         else if (!g->a_kmajor && g->b_kmajor) rc = dispatch3<false, true>(p, g->epilogue, st);

@@ -35,15 +35,15 @@ def _flush_caches(device) -> None:
     buf.zero_()
 
 
-def _time_once(a, b, M, N, K, ak, bk, epi, aux, out, reps=6) -> float:
-    ops.gemm(a, b, M, N, K, ak, bk, epi, aux, out=out)
+def _time_once(a, b, M, N, K, ak, bk, epi, aux, out, reps=6, rope=None) -> float:
+    ops.gemm(a, b, M, N, K, ak, bk, epi, aux, out=out, rope=rope)
     torch.cuda.synchronize()
     best = float("inf")
     for _ in range(reps):
         _flush_caches(a.device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ops.gemm(a, b, M, N, K, ak, bk, epi, aux, out=out)
+        ops.gemm(a, b, M, N, K, ak, bk, epi, aux, out=out, rope=rope)
         e1.record()
         e1.synchronize()
         best = min(best, e0.elapsed_time(e1))
@@ -53,6 +53,8 @@ def _time_once(a, b, M, N, K, ak, bk, epi, aux, out, reps=6) -> float:
 def candidates(M: int, N: int, K: int, epi: int) -> List[Tuple[int, int, int]]:
     """(variant, bn, splits)."""
     c = [(1, 128, 1), (2, 128, 1)]
+    if K >= 128:
+        c.append((4, 128, 1))      # the half-tile ring at two workgroups per CU
     if N >= 256:
         c.append((2, 256, 1))
         if K >= 128:
@@ -66,8 +68,7 @@ def candidates(M: int, N: int, K: int, epi: int) -> List[Tuple[int, int, int]]:
             for s in (2, 3, 4, 5, 6, 8, 10, 12, 16):
                 if nk // s >= 8 and tiles * s <= 1024:
                     c.append((2, bn, s))
-                    if bn == 256:
-                        c.append((3, bn, s))
+                    c.append((3, bn, s) if bn == 256 else (4, bn, s))
     return c
 
 
@@ -81,6 +82,12 @@ def tune_gemm(M: int, N: int, K: int, a_kmajor: bool, b_kmajor: bool, epi: int =
     b = torch.randn(N * K, device=device, generator=g).to(torch.bfloat16)
     aux = torch.randn(M * N, device=device, generator=g).to(torch.bfloat16) if epi in (L.EPI_ADD, L.EPI_GELU_BWD) else None
     out = torch.empty(M * N, device=device, dtype=torch.bfloat16)
+    rope = None
+    if epi == L.EPI_ROPE_QK:   # the c_attn projection is timed WITH its RoPE epilogue (tables of a plausible shape: the cost is the same)
+        hs = 128 if (N // 3) % 128 == 0 else 64
+        T = min(M, 1024)
+        tab = torch.randn(T, hs // 2, device=device, generator=g)
+        rope = (torch.cos(tab), torch.sin(tab), T, hs)
     # round-robin over the candidates (three rounds, best time kept): the clock the chip holds drifts while it is being
     # measured, and timing the candidates one after the other hands the later ones a different machine
     cands = candidates(M, N, K, epi)
@@ -89,7 +96,7 @@ def tune_gemm(M: int, N: int, K: int, a_kmajor: bool, b_kmajor: bool, epi: int =
         for c in cands:
             variant, bn, splits = c
             L.check(lib.obte_gemm_plan_set(int(a_kmajor), int(b_kmajor), epi, M, N, K, variant, bn, splits), "obte_gemm_plan_set")
-            best[c] = min(best[c], _time_once(a, b, M, N, K, a_kmajor, b_kmajor, epi, aux, out, reps=3))
+            best[c] = min(best[c], _time_once(a, b, M, N, K, a_kmajor, b_kmajor, epi, aux, out, reps=3, rope=rope))
     results = sorted((t, c[0], c[1], c[2]) for c, t in best.items())
     t, variant, bn, splits = results[0]
     L.check(lib.obte_gemm_plan_set(int(a_kmajor), int(b_kmajor), epi, M, N, K, variant, bn, splits), "obte_gemm_plan_set")
@@ -108,7 +115,7 @@ def model_gemm_shapes(rows: int, n_embd: int, vocab: int):
     Mm = max(64, int(round(0.15 * rows / 8)) * 8)
     E = L
     return [
-        (M, 3 * C, C, True, True, E.EPI_NONE), (M, C, C, True, True, E.EPI_ADD), (M, 4 * C, C, True, True, E.EPI_GELU),
+        (M, 3 * C, C, True, True, E.EPI_ROPE_QK if C % 64 == 0 else E.EPI_NONE), (M, C, C, True, True, E.EPI_ADD), (M, 4 * C, C, True, True, E.EPI_GELU),
         (M, C, 4 * C, True, True, E.EPI_ADD), (M, V, C, True, True, E.EPI_NONE),
         (M, 4 * C, C, True, False, E.EPI_GELU_BWD), (M, C, 4 * C, True, False, E.EPI_NONE), (M, C, C, True, False, E.EPI_NONE),
         (M, C, 3 * C, True, False, E.EPI_NONE), (M, C, V, True, False, E.EPI_NONE),

@@ -535,13 +535,16 @@ def test_gemm_linearity_full_size():
 
 
 def _force_gemm(monkeypatch, bn):
-    """'128' / '256': tile width of the K-tile ring; '256h': the 256-wide half-tile ring (structure 3)."""
+    """'128' / '256': tile width of the K-tile ring; '256h': the 256-wide half-tile ring (structure 3); '128q': the 128-wide
+    half-tile ring with four waves and two workgroups per CU (structure 4)."""
     monkeypatch.setenv("OBTE_GEMM_BN", bn[:3])
     if bn.endswith("h"):
         monkeypatch.setenv("OBTE_GEMM", "v3")
+    if bn.endswith("q"):
+        monkeypatch.setenv("OBTE_GEMM", "v4")
 
 
-@pytest.mark.parametrize("bn", ["128", "256", "256h"])
+@pytest.mark.parametrize("bn", ["128", "256", "256h", "128q"])
 def test_gemm_both_tile_widths(monkeypatch, bn):
     """Every layout, epilogue and the split-K path on both tile widths and both ring structures (the library picks
     per shape; here forced)."""
