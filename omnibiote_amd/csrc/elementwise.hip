@@ -2,6 +2,7 @@
 // masked-LM cross entropy (forward + backward in one kernel), bf16 AdamW, sum of squares.
 // All use 16-byte accesses per lane and grid sizes that fill 256 CUs.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -258,6 +259,73 @@ __global__ __launch_bounds__(256) void masked_ce_kernel(const bf16* __restrict__
             o[j] = f2bf(p * gs);
         }
         *reinterpret_cast<bf16x8*>(drow + c) = o;
+    }
+}
+
+// The same row arithmetic with the row held in registers (vocab <= 256 threads x NCH x 8 elements: 65 536 at NCH = 32): every
+// logit is loaded ONCE, all loads are in flight before the first reduction, and the gradient pass reads registers — the
+// two-pass kernel above re-reads the row (from L2) chunk by chunk with each load queued behind the previous chunk's store
+// (vmcnt retires in issue order).  Same operations in the same order per element; the per-thread online max / sum-exp is
+// evaluated over the same chunks in the same order, so loss and gradients are bitwise those of the kernel above.
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void masked_ce_regs_kernel(const bf16* __restrict__ logits, const int64_t* __restrict__ target,
+                                                              const float* __restrict__ grad_scale, float row_scale,
+                                                              float* __restrict__ row_loss, bf16* __restrict__ dlogits, int64_t vocab,
+                                                              const int64_t* __restrict__ row_index, const float* __restrict__ row_scale_vec) {
+    __shared__ float red[8];
+    const int64_t r = blockIdx.x;
+    const int64_t src = row_index[r];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bf16* drow = dlogits + r * vocab;
+    const bf16* lrow = logits + src * vocab;
+    bf16x8 v[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int64_t c = ((int64_t)i * 256 + threadIdx.x) * 8;
+        v[i] = bf16x8{};
+        if (c < vocab) v[i] = *reinterpret_cast<const bf16x8*>(lrow + c);
+    }
+    float m = -INFINITY, l = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int64_t c = ((int64_t)i * 256 + threadIdx.x) * 8;
+        if (c < vocab) {
+            float mx = bf2f(v[i][0]);
+#pragma unroll
+            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, bf2f(v[i][j]));
+            const float mn = fmaxf(m, mx);
+            float add = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) add += __expf(bf2f(v[i][j]) - mn);
+            l = l * __expf(m - mn) + add;
+            m = mn;
+        }
+    }
+    const float wm = wave_max(m);
+    l = wave_sum(m == -INFINITY ? 0.f : l * __expf(m - wm));
+    if (lane == 0) { red[wave] = wm; red[4 + wave] = l; }
+    __syncthreads();
+    const float bm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float bl = red[4] * __expf(red[0] - bm) + red[5] * __expf(red[1] - bm) + red[6] * __expf(red[2] - bm) + red[7] * __expf(red[3] - bm);
+    const float lse = bm + __logf(bl);
+    int64_t tgt = target[src];
+    tgt = tgt < 0 ? 0 : (tgt >= vocab ? vocab - 1 : tgt);
+    const float rsc = row_scale_vec ? row_scale * row_scale_vec[r] : row_scale;
+    if (threadIdx.x == 0 && row_loss) row_loss[r] = (lse - bf2f(lrow[tgt])) * rsc;
+    const float gs = rsc * grad_scale[0];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int64_t c = ((int64_t)i * 256 + threadIdx.x) * 8;
+        if (c < vocab) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float p = __expf(bf2f(v[i][j]) - lse);
+                if (c + j == tgt) p -= 1.0f;
+                o[j] = f2bf(p * gs);
+            }
+            *reinterpret_cast<bf16x8*>(drow + c) = o;
+        }
     }
 }
 
@@ -545,9 +613,18 @@ extern "C" int obte_masked_ce_rows(const obte_bf16* logits, const int64_t* targe
     OBTE_REQUIRE(n_rows > 0 && n_rows <= total_rows && total_rows < (1ll << 31) && vocab > 0 && vocab % 8 == 0,
                  "obte_masked_ce_rows: need 0 < n_rows <= total_rows and vocab %% 8 == 0");
     const int prof = obte_prof_begin((hipStream_t)s, 112, n_rows, vocab, 1);   // algorithmic bytes = 4 * n_rows * vocab (read + write)
-    hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)s, (const bf16*)logits, target,
-                       (const uint8_t*)nullptr, (const uint8_t*)nullptr, grad_scale, row_scale, row_loss, (bf16*)dlogits_rows, vocab, row_index,
-                       row_scale_vec);
+    static int regs_on = -1;   // OBTE_CE_REGS=0: the two-pass kernel (A/B timing; bitwise the same results)
+    if (regs_on < 0) { const char* e = getenv("OBTE_CE_REGS"); regs_on = (e && e[0] == '0') ? 0 : 1; }
+    if (regs_on && vocab <= 256 * 8 * 8)
+        hipLaunchKernelGGL((masked_ce_regs_kernel<8>), dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)s, (const bf16*)logits, target,
+                           grad_scale, row_scale, row_loss, (bf16*)dlogits_rows, vocab, row_index, row_scale_vec);
+    else if (regs_on && vocab <= 256 * 32 * 8)
+        hipLaunchKernelGGL((masked_ce_regs_kernel<32>), dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)s, (const bf16*)logits, target,
+                           grad_scale, row_scale, row_loss, (bf16*)dlogits_rows, vocab, row_index, row_scale_vec);
+    else
+        hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)s, (const bf16*)logits, target,
+                           (const uint8_t*)nullptr, (const uint8_t*)nullptr, grad_scale, row_scale, row_loss, (bf16*)dlogits_rows, vocab, row_index,
+                           row_scale_vec);
     obte_prof_end(prof, (hipStream_t)s);
     OBTE_CHECK_LAUNCH("obte_masked_ce_rows");
     return OBTE_OK;

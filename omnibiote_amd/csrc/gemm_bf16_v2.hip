@@ -173,7 +173,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     constexpr bool READS = EPI == OBTE_EPI_ADD || EPI == OBTE_EPI_GELU_BWD || EPI == OBTE_EPI_ADD_DROPOUT || EPI == OBTE_EPI_ROPE_QK;
     constexpr int NIT = 64 / RPI;
     const bool interior = m0 + BM <= p.store_rows && n0 + tile_n <= p.N && (EPI != OBTE_EPI_ADD || p.aux != nullptr);
-    if (READS && interior) {
+    if (interior) {   // (the epilogues without loads take it too: no bounds branches, so the staged reads are issued ahead of the arithmetic)
         const int row_l = lane / CPRE, c8 = lane % CPRE;
         const int64_t n = n0 + wn * NW + c8 * 8;
         const int64_t o0 = (m0 + wm * 64 + row_l) * p.ldd + n;
@@ -191,7 +191,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
                 rc[it] = *reinterpret_cast<const f32x4*>(p.rope_cos + t * (hs32 / 2) + dd / 2);
                 rs[it] = *reinterpret_cast<const f32x4*>(p.rope_sin + t * (hs32 / 2) + dd / 2);
             }
-        } else {
+        } else if (READS) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) r[it] = *reinterpret_cast<const bf16x8*>(p.aux + o0 + (int64_t)it * RPI * p.ldd);
         }
@@ -200,7 +200,17 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
         for (int it = 0; it < NIT; ++it) {
             bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + (it * RPI + row_l) * LDE + c8 * 16);
             const int64_t o = o0 + (int64_t)it * RPI * p.ldd;
-            if (EPI == OBTE_EPI_ADD) {
+            if (EPI == OBTE_EPI_GELU) {
+                bf16x8 g;
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    f32x2_t act, der;
+                    gelu_ref_both2(f32x2_t{bf2f(v[j]), bf2f(v[j + 1])}, act, der);
+                    g[j] = f2bf(act[0]); g[j + 1] = f2bf(act[1]);
+                    v[j] = f2bf(der[0]); v[j + 1] = f2bf(der[1]);
+                }
+                *reinterpret_cast<bf16x8*>(p.d2 + o) = g;
+            } else if (EPI == OBTE_EPI_ADD) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(r[it][j]) + bf2f(v[j]));
             } else if (EPI == OBTE_EPI_GELU_BWD) {
@@ -228,7 +238,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
                     }
                 }
             }
-            *reinterpret_cast<bf16x8*>(p.d + o) = v;
+            if (p.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p.d + o), "v"(v) : "memory");
+            else *reinterpret_cast<bf16x8*>(p.d + o) = v;
         }
         return;
     }
