@@ -536,7 +536,12 @@ def main():
                      f"{STRUCT_NAMES.get(r['variant'], r['variant'])} bn{r['bn']} split{r['splits']}" for r in plans]
         plan_hash = hashlib.sha256("\n".join(plan_rows).encode()).hexdigest()[:16]
         if world > 1:
-            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+            rccl = None
+            if dist.get_backend() == "nccl":
+                try:   # informational: nothing about the measurement depends on it
+                    rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+                except Exception as e:   # noqa: BLE001
+                    rccl = "unknown (" + type(e).__name__ + ")"
             collectives = {"backend": "RCCL (torch.distributed backend nccl)" if dist.get_backend() == "nccl" else dist.get_backend(),
                            "rccl_version": rccl, "world_size": dist.get_world_size(), "ranks_in_first_all_reduce": world,
                            "pattern": "one bucketed gradient all-reduce per optimizer step (DDP no_sync on all but the last micro-batch, "
