@@ -35,7 +35,7 @@ struct AttnParams {
     const int32_t* key_ranges; const bf16* mask; int64_t mask_sb, mask_sh, mask_sq;
     const int32_t* query_bounds;   // per-key [first, last+1) query bounds (obte_mask_bounds), nullable: loop bounds in dense mode,
                                    // the exact query range of every key in range mode (else the mask is taken to be symmetric)
-    const int32_t* gate; int gate_expect;   // nullable device flag: the kernel runs only if *gate == gate_expect (see launch_fwd)
+    const int32_t* gate;           // the *_gated_kernel entry points: device flag (obte_mask_bounds' ranges_exact), 1 = run the range-mode body
     int64_t B, T; int H; float scale;
     DropCfg drop;   // attention-probability dropout (site 1); thresh16 == 0: off
     int no_wait;    // timing-only diagnostic (OBTE_ATTN_DEBUG=nowait): the tile loops do not wait for their LDS-DMA (results are wrong)
@@ -215,9 +215,7 @@ __device__ __forceinline__ void block_minmax(int& lo, int& hi, int* scratch, int
 // at p = 0.1, against 47 / 160 us without dropout.)
 template <bool DROP> struct FwdShape { static constexpr int NW = 8; static constexpr int STAGES = 2; };   // a deeper ring (4 stages, 3 tiles ahead) measured slower: 48.9 vs 45.9 us
 template <int D, int MODE, bool DROP>
-__global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_fwd_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (p.gate && __builtin_amdgcn_readfirstlane(*p.gate) != p.gate_expect) return;   // the other mask representation's launch does the work
+__device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem) {
     constexpr int NW = FwdShape<DROP>::NW;
     constexpr int TB = 64 * 2 * D;  // bytes of one 64-row tile
     constexpr int NS = D / 16;      // k-steps over the head dim
@@ -427,9 +425,7 @@ __device__ __forceinline__ void rope_inv4(float (&g)[4], const float* cos_t, con
 // ==========================================================================================================
 // 256 queries (eight waves) per workgroup, for the same reason as the forward: K/V traffic per query.
 template <int D, int MODE, bool DROP>
-__global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dq_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (p.gate && __builtin_amdgcn_readfirstlane(*p.gate) != p.gate_expect) return;   // the other mask representation's launch does the work
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem) {
     constexpr int NW = FwdShape<DROP>::NW;
     constexpr int TB = 64 * 2 * D;
     constexpr int NS = D / 16, ND = D / 32;
@@ -604,9 +600,7 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dq_kernel
 // waits (320 KiB of LDS reads per step per CU, 40 KiB per wave), not by the vector pipe, and de-phasing the halves puts both
 // LDS-heavy phases (A: 24 x b128, C: 32 x tr_b64) side by side.
 template <int D, int MODE, bool DROP>
-__global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kernel(AttnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (p.gate && __builtin_amdgcn_readfirstlane(*p.gate) != p.gate_expect) return;   // the other mask representation's launch does the work
+__device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* smem) {
     constexpr int NW = FwdShape<DROP>::NW;
     constexpr int QB = 32 * 2 * D;  // bytes of one 32-row tile
     constexpr int NS = D / 16, ND = D / 32;
@@ -787,6 +781,28 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kern
     }
 }
 
+// The kernels proper: the bodies above behind their own entry points, and — for a dense additive mask whose device flag
+// (obte_mask_bounds) may say "this IS a range mask" — ONE entry point per pass that holds both bodies and branches on the flag
+// (uniform).  The host cannot read the flag without a sync; launching both representations with a gate in each cost three
+// empty launches per attention call (forward, dQ, dK/dV: ~6 us of stream time each, 2.3 ms per step with the reference's mask
+// tensors).
+#define OBTE_ATTN_KERNEL(NAME)                                                                                         \
+    template <int D, int MODE, bool DROP>                                                                              \
+    __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void NAME##_kernel(AttnParams p) {                        \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                                                    \
+        NAME##_body<D, MODE, DROP>(p, smem);                                                                           \
+    }                                                                                                                  \
+    template <int D, bool DROP>                                                                                        \
+    __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void NAME##_gated_kernel(AttnParams pr, AttnParams pd) {  \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                                                    \
+        if (__builtin_amdgcn_readfirstlane(*pr.gate) == 1) NAME##_body<D, MASK_RANGES, DROP>(pr, smem);                \
+        else NAME##_body<D, MASK_DENSE, DROP>(pd, smem);                                                               \
+    }
+OBTE_ATTN_KERNEL(attn_fwd)
+OBTE_ATTN_KERNEL(attn_bwd_dq)
+OBTE_ATTN_KERNEL(attn_bwd_dkdv)
+#undef OBTE_ATTN_KERNEL
+
 // Explicit instantiations (implicit instantiation alone left some host stubs undefined with hipcc / ROCm 7.2).
 #define OBTE_INST_ATTN(D, M)                                                       \
     template __global__ void attn_fwd_kernel<D, M, false>(AttnParams);             \
@@ -798,6 +814,15 @@ __global__ __launch_bounds__(FwdShape<DROP>::NW * 64, 1) void attn_bwd_dkdv_kern
 OBTE_INST_ATTN(64, 0) OBTE_INST_ATTN(64, 1) OBTE_INST_ATTN(64, 2)
 OBTE_INST_ATTN(128, 0) OBTE_INST_ATTN(128, 1) OBTE_INST_ATTN(128, 2)
 #undef OBTE_INST_ATTN
+#define OBTE_INST_GATED(D)                                                                      \
+    template __global__ void attn_fwd_gated_kernel<D, false>(AttnParams, AttnParams);           \
+    template __global__ void attn_fwd_gated_kernel<D, true>(AttnParams, AttnParams);            \
+    template __global__ void attn_bwd_dq_gated_kernel<D, false>(AttnParams, AttnParams);        \
+    template __global__ void attn_bwd_dq_gated_kernel<D, true>(AttnParams, AttnParams);         \
+    template __global__ void attn_bwd_dkdv_gated_kernel<D, false>(AttnParams, AttnParams);      \
+    template __global__ void attn_bwd_dkdv_gated_kernel<D, true>(AttnParams, AttnParams);
+OBTE_INST_GATED(64) OBTE_INST_GATED(128)
+#undef OBTE_INST_GATED
 
 template <typename K>
 void set_smem(K kern, int bytes) {
@@ -917,20 +942,49 @@ static int check_common(const char* who, const void* qkv, int64_t B, int64_t T, 
 template <int D>
 int launch_fwd_gated(AttnParams p, const int32_t* flag, hipStream_t st) {
     AttnParams pr = p;
-    pr.mask = nullptr; pr.gate = flag; pr.gate_expect = 1;
-    int rc = launch_fwd<D>(pr, MASK_RANGES, st);
-    if (rc != OBTE_OK) return rc;
-    p.gate = flag; p.gate_expect = 0;
-    return launch_fwd<D>(p, MASK_DENSE, st);
+    pr.mask = nullptr; pr.gate = flag;          // the range-mode view of the same call
+    p.gate = flag;
+    const int smem = 2 * FwdShape<false>::STAGES * 64 * 2 * D + 64;
+    const dim3 grid((unsigned)(cdiv64(p.T, 32 * FwdShape<false>::NW) * p.H * p.B)), block(64 * FwdShape<false>::NW);
+    if (p.drop.thresh16) {
+        set_smem(attn_fwd_gated_kernel<D, true>, smem);
+        hipLaunchKernelGGL((attn_fwd_gated_kernel<D, true>), grid, block, smem, st, pr, p);
+    } else {
+        set_smem(attn_fwd_gated_kernel<D, false>, smem);
+        hipLaunchKernelGGL((attn_fwd_gated_kernel<D, false>), grid, block, smem, st, pr, p);
+    }
+    OBTE_CHECK_LAUNCH("obte_attn_fwd(gated)");
+    return OBTE_OK;
 }
 template <int D>
 int launch_bwd_gated(AttnParams p, const int32_t* flag, hipStream_t st) {
     AttnParams pr = p;
-    pr.mask = nullptr; pr.gate = flag; pr.gate_expect = 1;   // pr.query_bounds: the exact per-key query ranges
-    int rc = launch_bwd<D>(pr, MASK_RANGES, st);
-    if (rc != OBTE_OK) return rc;
-    p.gate = flag; p.gate_expect = 0;
-    return launch_bwd<D>(p, MASK_DENSE, st);
+    pr.mask = nullptr; pr.gate = flag;          // pr.query_bounds: the exact per-key query ranges
+    p.gate = flag;
+    const dim3 grid((unsigned)(cdiv64(p.T, 32 * FwdShape<false>::NW) * p.H * p.B)), block(64 * FwdShape<false>::NW);
+    {
+        const int smem = 4 * 64 * 2 * D + 64;
+        if (p.drop.thresh16) {
+            set_smem(attn_bwd_dq_gated_kernel<D, true>, smem);
+            hipLaunchKernelGGL((attn_bwd_dq_gated_kernel<D, true>), grid, block, smem, st, pr, p);
+        } else {
+            set_smem(attn_bwd_dq_gated_kernel<D, false>, smem);
+            hipLaunchKernelGGL((attn_bwd_dq_gated_kernel<D, false>), grid, block, smem, st, pr, p);
+        }
+        OBTE_CHECK_LAUNCH("obte_attn_bwd(dq, gated)");
+    }
+    {
+        const int smem = 2 * (2 * 32 * 2 * D + 384) + 32 * FwdShape<false>::NW * 2 * D + 64;
+        if (p.drop.thresh16) {
+            set_smem(attn_bwd_dkdv_gated_kernel<D, true>, smem);
+            hipLaunchKernelGGL((attn_bwd_dkdv_gated_kernel<D, true>), grid, block, smem, st, pr, p);
+        } else {
+            set_smem(attn_bwd_dkdv_gated_kernel<D, false>, smem);
+            hipLaunchKernelGGL((attn_bwd_dkdv_gated_kernel<D, false>), grid, block, smem, st, pr, p);
+        }
+        OBTE_CHECK_LAUNCH("obte_attn_bwd(dkdv, gated)");
+    }
+    return OBTE_OK;
 }
 
 extern "C" int obte_attn_fwd(const obte_attn_fwd_args* a, obte_stream s) {
