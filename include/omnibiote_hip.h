@@ -202,8 +202,8 @@ int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s);
  * ranges_exact (nullable, int32 [1] on the device; needs col_scratch int32 [B*T]): set to 1 iff the mask IS a range mask —
  * every row's allowed keys are one contiguous run of exact zeros, the same for all heads, everything else <= -3e4, and
  * every key's queries are one contiguous run too (block-diagonal document masks, key-padding masks).  Passed on in the
- * `ranges_exact` fields, it lets the attention entry points run the range kernels for such a mask: both representations are
- * launched and the kernels of the one that does not apply return at once, so the host never reads the flag.
+ * `ranges_exact` fields, it lets the attention entry points run the range kernels for such a mask: the kernels hold both
+ * bodies and branch on the flag, so the host never reads it.
  * row_scratch: uint8 [B*T].  Replaces nothing in the reference (training/train_encoder.py:31-57 builds the mask, and
  * model.py:115-146 hands it to SDPA whole). */
 int obte_mask_bounds(const obte_bf16* mask, int64_t mask_sb, int64_t mask_sh, int64_t mask_sq, int64_t B, int32_t n_head,
