@@ -233,6 +233,13 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem) {
     const bool q_ok = q_row < T;
     const int q_c = q_ok ? q_row : T - 1;
 
+    // the key range of this query FIRST: the tile range (and with it the first LDS-DMA) depends on it, and vmcnt retires in
+    // issue order — loaded behind the Q fragments, it made the K/V stream wait for all of them
+    int r_lo = 0, r_hi = T;
+    if (MODE == MASK_RANGES || (MODE == MASK_DENSE && p.key_ranges)) {
+        r_lo = p.key_ranges[(b * T + q_c) * 2];
+        r_hi = p.key_ranges[(b * T + q_c) * 2 + 1];
+    }
     const bf16* qptr = p.qkv + (b * T + q_c) * ld + hd * D;
     bf16x8 qf[NS];
 #pragma unroll
@@ -242,14 +249,13 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem) {
 
     int ks = 0, ke = T;
     if (MODE == MASK_RANGES) {
-        ks = p.key_ranges[(b * T + q_c) * 2];
-        ke = min(p.key_ranges[(b * T + q_c) * 2 + 1], T);
-        ks = max(ks, 0);
+        ks = max(r_lo, 0);
+        ke = min(r_hi, T);
     }
     int lo = ks, hi = ke;
     if (MODE == MASK_DENSE && p.key_ranges) {   // dense arithmetic, but the loop may skip what every row masks out
-        lo = max(p.key_ranges[(b * T + q_c) * 2], 0);
-        hi = min(p.key_ranges[(b * T + q_c) * 2 + 1], T);
+        lo = max(r_lo, 0);
+        hi = min(r_hi, T);
         block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 2 * FwdShape<DROP>::STAGES * TB), wave, lane);
     }
     if (MODE == MASK_RANGES) block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 2 * FwdShape<DROP>::STAGES * TB), wave, lane);
@@ -285,11 +291,12 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem) {
         dma.issue(kbase + row0 * ld, (rows_left - (C + hd * D)) * 2, st, wave);
         dma.issue(vbase + row0 * ld, (rows_left - (2 * C + hd * D)) * 2, st + TB, wave);
     };
-    prologue_wait_all();   // the Q fragments have landed (and hipcc knows it) before the first LDS-DMA is in the queue
-#pragma unroll
-    for (int i = 0; i < R - 1; ++i)
-        if (t_begin + i < t_end) issue_kv(t_begin + i);
-    dma_wait_leave(OPS * min(max(t_end - t_begin - 1, 0), R - 2));
+    // the first tile(s) go out while the Q fragments are still in flight; the builtin wait that follows covers both (hipcc
+    // must KNOW the Q fragments have landed, or it keeps per-fragment vmcnt waits in front of the first MFMAs of every tile —
+    // and vmcnt counts the asm-issued LDS-DMA too)
+    static_assert(R == 2, "prologue written for a two-stage ring (one tile ahead)");
+    if (t_begin < t_end) issue_kv(t_begin);
+    prologue_wait_all();
     __syncthreads();
 
     for (int t = t_begin; t < t_end; ++t) {
@@ -442,6 +449,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
     const bool q_ok = q_row < T;
     const int q_c = q_ok ? q_row : T - 1;
 
+    int r_lo = 0, r_hi = T;   // the key range first (see the forward)
+    if (MODE == MASK_RANGES || (MODE == MASK_DENSE && p.key_ranges)) {
+        r_lo = p.key_ranges[(b * T + q_c) * 2];
+        r_hi = p.key_ranges[(b * T + q_c) * 2 + 1];
+    }
     const bf16* qptr = p.qkv + (b * T + q_c) * ld + hd * D;
     const bf16* doptr = p.d_o + (b * T + q_c) * C + hd * D;
     bf16x8 qf[NS], dof[NS];
@@ -469,13 +481,13 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
 
     int ks = 0, ke = T;
     if (MODE == MASK_RANGES) {
-        ks = max(p.key_ranges[(b * T + q_c) * 2], 0);
-        ke = min(p.key_ranges[(b * T + q_c) * 2 + 1], T);
+        ks = max(r_lo, 0);
+        ke = min(r_hi, T);
     }
     int lo = ks, hi = ke;
     if (MODE == MASK_DENSE && p.key_ranges) {
-        lo = max(p.key_ranges[(b * T + q_c) * 2], 0);
-        hi = min(p.key_ranges[(b * T + q_c) * 2 + 1], T);
+        lo = max(r_lo, 0);
+        hi = min(r_hi, T);
         block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 4 * TB), wave, lane);
     }
     if (MODE == MASK_RANGES) block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 4 * TB), wave, lane);
@@ -619,6 +631,15 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
     const bool k_ok = key < T;
     const int key_c = k_ok ? key : T - 1;
 
+    int r_lo = 0, r_hi = T;   // the query range of this key first (see the forward)
+    if (MODE == MASK_RANGES) {
+        const int32_t* src = p.query_bounds ? p.query_bounds : p.key_ranges;   // no per-key table: symmetric mask
+        r_lo = src[(b * T + key_c) * 2];
+        r_hi = src[(b * T + key_c) * 2 + 1];
+    } else if (MODE == MASK_DENSE && p.query_bounds) {
+        r_lo = p.query_bounds[(b * T + key_c) * 2];
+        r_hi = p.query_bounds[(b * T + key_c) * 2 + 1];
+    }
     const bf16* kptr = p.qkv + (b * T + key_c) * ld + C + hd * D;
     bf16x8 kf[NS];
 #pragma unroll
@@ -633,9 +654,8 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
     // by symmetry of the mask, the queries that see this key are the keys this position sees as a query
     int qs = 0, qe = T;
     if (MODE == MASK_RANGES) {
-        const int32_t* src = p.query_bounds ? p.query_bounds : p.key_ranges;   // no per-key table: symmetric mask
-        qs = max(src[(b * T + key_c) * 2], 0);
-        qe = min(src[(b * T + key_c) * 2 + 1], T);
+        qs = max(r_lo, 0);
+        qe = min(r_hi, T);
     }
     if (!k_ok) { qs = 0; qe = 0; }
     int lo = k_ok ? qs : T, hi = k_ok ? qe : 0;
@@ -643,8 +663,8 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
         block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 2 * STAGE + VB), wave, lane);
     } else if (MODE == MASK_DENSE && p.query_bounds) {
         if (k_ok) {
-            lo = max(p.query_bounds[(b * T + key_c) * 2], 0);
-            hi = min(p.query_bounds[(b * T + key_c) * 2 + 1], T);
+            lo = max(r_lo, 0);
+            hi = min(r_hi, T);
         }
         block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 2 * STAGE + VB), wave, lane);
     } else {
