@@ -312,12 +312,24 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem) {
         // simply carried at up to 64x their usual magnitude in fp32 / bf16, whose precision is relative).
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         f32x16 sc[2];
-        sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 0, 0, lane), qf[0], zero16, 0, 0, 0);
-        sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 32, 0, lane), qf[0], zero16, 0, 0, 0);
+        {
+            // every K fragment of the tile is requested before the first MFMA (and the order is pinned): left to itself hipcc
+            // sinks each ds_read to just before the MFMA that uses it — read, lgkmcnt(0), MFMA, sixteen times over, the LDS
+            // latency exposed every time (the forward has the registers for this since the subtile LDS image: 156 -> ~220)
+            bf16x8 kfr[2][NS];
 #pragma unroll
-        for (int s = 1; s < NS; ++s) {
-            sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 0, s, lane), qf[s], sc[0], 0, 0, 0);
-            sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 32, s, lane), qf[s], sc[1], 0, 0, 0);
+            for (int s = 0; s < NS; ++s) {
+                kfr[0][s] = row_frag<D>(Kt, 0, s, lane);
+                kfr[1][s] = row_frag<D>(Kt, 32, s, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0][0], qf[0], zero16, 0, 0, 0);
+            sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[1][0], qf[0], zero16, 0, 0, 0);
+#pragma unroll
+            for (int s = 1; s < NS; ++s) {
+                sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0][s], qf[s], sc[0], 0, 0, 0);
+                sc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[1][s], qf[s], sc[1], 0, 0, 0);
+            }
         }
         if (MODE == MASK_DENSE) {   // scores in the log2 domain, plus the additive mask
 #pragma unroll
@@ -381,13 +393,25 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem) {
                 }
             }
         l += rs;
-        // O^T += V^T P^T : P^T accumulators are the B operand as they stand
+        // O^T += V^T P^T : P^T accumulators are the B operand as they stand.  The V fragments of key step kk+1 are requested
+        // before the MFMAs of step kk (two register sets, order pinned).
+        {
+            bf16x8 vfr[2][ND];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const bf16x8 pf = pack8(sc[kk >> 1], 8 * (kk & 1));
+            for (int dt = 0; dt < ND; ++dt) vfr[0][dt] = tr_frag<D>(Vt, 0, dt, lane);
 #pragma unroll
-            for (int dt = 0; dt < ND; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Vt, 16 * kk, dt, lane), pf, o[dt], 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 pf = pack8(sc[kk >> 1], 8 * (kk & 1));
+                if (kk + 1 < 4) {
+#pragma unroll
+                    for (int dt = 0; dt < ND; ++dt) vfr[(kk + 1) & 1][dt] = tr_frag<D>(Vt, 16 * (kk + 1), dt, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kk & 1][dt], pf, o[dt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (!p.no_wait) dma_wait_leave(OPS * min(max(t_end - t - 2, 0), R - 2));   // tile t+1 landed; later ones may stay in flight
         __syncthreads();
