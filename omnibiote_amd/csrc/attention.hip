@@ -634,7 +634,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
 // (MI355X_MICROARCH.md "Two waves per SIMD" item 9; three Q/dO slots, P / dS carried over the loop edge, bitwise the same
 // results) took 95.3 us against 89.5 un-staggered (333 vs 316 us at T = 4096): the loop is paced by fragment reads and their
 // waits (320 KiB of LDS reads per step per CU, 40 KiB per wave), not by the vector pipe, and de-phasing the halves puts both
-// LDS-heavy phases (A: 24 x b128, C: 32 x tr_b64) side by side.
+// LDS-heavy phases (A: 24 x b128, C: 32 x tr_b64) side by side.  Also measured and dropped: 64-row Q/dO stages (two MFMA tiles
+// per barrier, half the barriers): 86.9 vs 87.0 us, 314.7 vs 312.5 at T = 4096 — the barrier count is not what parks the waves.
 template <int D, int MODE, bool DROP>
 __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* smem) {
     constexpr int NW = FwdShape<DROP>::NW;
