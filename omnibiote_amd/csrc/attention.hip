@@ -40,6 +40,8 @@ struct AttnParams {
     DropCfg drop;   // attention-probability dropout (site 1); thresh16 == 0: off
     int no_wait;    // timing-only diagnostic (OBTE_ATTN_DEBUG=nowait): the tile loops do not wait for their LDS-DMA (results are wrong)
     int max_tiles;  // timing-only diagnostic (OBTE_ATTN_DEBUG=tiles:N): every workgroup stops after N tiles (results are wrong; 0 = off)
+    int dbg_skip;   // timing-only diagnostic, debug build (OBTE_ATTN_SKIP=bits): dK/dV kernel — 1: no softmax arithmetic, 2: no phase-C MFMAs,
+                    // 4: no phase-A MFMAs, 8: no per-tile barrier (results are wrong)
 };
 
 // LDS image of a [rows][D] bf16 tile: groups of 8 rows (16*D bytes), each cut into 8-row x 32-column subtiles of 512 B whose
@@ -761,11 +763,17 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
         f32x16 sc, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#ifdef OBTE_DEBUG_HOOKS
+        if (!(p.dbg_skip & 4))
+#endif
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Qt, 0, s, lane), kf[s], sc, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Dt, 0, s, lane), row_frag<D>(Vblk, 32 * wave, s, lane), dp, 0, 0, 0);
         }
+#ifdef OBTE_DEBUG_HOOKS
+        if (!(p.dbg_skip & 1))
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(stats + 8 * i + 4 * h);
@@ -788,6 +796,9 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
                 dp[r] = pv * (dpd - d4[j]);    // dS
             }
         }
+#ifdef OBTE_DEBUG_HOOKS
+        if (!(p.dbg_skip & 2))
+#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const bf16x8 pf = pack8(sc, 8 * kk);
@@ -798,8 +809,14 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
                 dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Qt, 16 * kk, dt, lane), dsf, dk[dt], 0, 0, 0);
             }
         }
+#ifdef OBTE_DEBUG_HOOKS
+        if (p.dbg_skip & 2) { asm volatile("" ::"v"(sc), "v"(dp)); }
+#endif
         if (more) store_stats(smem + (cur ^ 1) * STAGE);
         if (!p.no_wait) dma_wait_all();
+#ifdef OBTE_DEBUG_HOOKS
+        if (!(p.dbg_skip & 8))
+#endif
         __syncthreads();
     }
 
@@ -963,9 +980,15 @@ static int debug_max_tiles() {
     }
     return v;
 }
+static int debug_skip() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OBTE_ATTN_SKIP"); v = e ? atoi(e) : 0; if (v) debug_warn_once("OBTE_ATTN_SKIP"); }
+    return v;
+}
 #else
 static int debug_no_wait() { return 0; }
 static int debug_max_tiles() { return 0; }
+static int debug_skip() { return 0; }
 #endif
 
 static int check_common(const char* who, const void* qkv, int64_t B, int64_t T, int H, int D, const int32_t* ranges,
@@ -1067,7 +1090,7 @@ extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
     p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
     OBTE_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "obte_attn_bwd: dropout p must be in [0,1)");
     p.drop = make_drop(a->dropout_p, a->dropout_seed, OBTE_SITE_ATTN);
-    p.max_tiles = debug_max_tiles(); p.no_wait = debug_no_wait();
+    p.max_tiles = debug_max_tiles(); p.no_wait = debug_no_wait(); p.dbg_skip = debug_skip();
     const int mode = mask_mode(a->key_ranges, a->mask);
     const int prof = obte_prof_begin((hipStream_t)s, 101, a->B * a->n_head, a->T, a->head_dim);
     if (mode == MASK_DENSE && a->key_ranges && a->query_bounds && a->ranges_exact)
