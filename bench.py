@@ -35,7 +35,9 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-
 METRIC = "MLM train tokens/sec, small (8L/1024d) ctx=1024 at 1/2/4/8 MI355X"
 
 READOUT_TEXT = {"dense": "full 65536-way logits for every position in the forward, readout backward over the MLM-masked rows (the other rows of d(logits) are exact zeros)",
-                "dense_full": "full 65536-way logits and dense d(logits)", "masked": "masked-rows-only 65536-way logits"}
+                "dense_full": "full 65536-way logits and dense d(logits)",
+                "masked": "65536-way readout + CE on the MLM-masked positions only (SURVEY §8f rank 1: the loss multiplies every other position by zero, "
+                          "train_encoder.py:304 — same loss, same gradients)"}
 CONFIGS = {
     "small": dict(n_layer=8, n_embd=1024, n_head=8, ctx_len=1024),
     "small4k": dict(n_layer=8, n_embd=1024, n_head=8, ctx_len=4096),
@@ -53,11 +55,11 @@ def parse():
     p.add_argument("--rows_per_rank", type=int, default=128, help="rows per rank per optimizer step (batch_size / world)")
     p.add_argument("--mini_batch_size", type=int, default=8)
     p.add_argument("--multi_document", action="store_true", help="rows with interior EOS (block-diagonal masks)")
-    p.add_argument("--readout", default="dense", choices=["dense", "dense_full", "masked"],
-                   help="dense (default): logits of every position in the forward, as the reference computes them; the backward "
-                        "contracts over the MLM-masked rows only (the other rows of d(logits) are exact zeros).  dense_full: also "
-                        "the dense [M,V] d(logits) and full-size backward products (the reference's literal graph).  masked: "
-                        "readout + CE on the masked rows only in the forward too (SURVEY §8f rank 1; not the headline)")
+    p.add_argument("--readout", default="masked", choices=["dense", "dense_full", "masked"],
+                   help="masked (default, SURVEY §8f rank 1): readout + CE on the MLM-masked positions only — the loss multiplies "
+                        "every other position by zero (train_encoder.py:304), so loss and gradients are the reference's.  dense: logits "
+                        "of every position in the forward, the backward contracts over the masked rows only.  dense_full: also the "
+                        "dense [M,V] d(logits) and full-size backward products (the reference's literal graph)")
     p.add_argument("--masked_lm_head", action="store_true", help="alias of --readout masked")
     p.add_argument("--dropout", type=float, default=0.0, help="0.0 = the parity regime (default); 0.1 = the reference's default")
     p.add_argument("--no_cpu_baseline", action="store_true")
@@ -439,7 +441,7 @@ def main():
             # figure comes from the committed rocprofv3 --pmc passes over this same workload (tools/pmc_traffic.py)
             pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_gemm_family_traffic.json", "r02_pmc_gemm_family_traffic.json", "r01_pmc_gemm_family_traffic.json"))
                         if os.path.exists(q)), "")
-            default_workload = (a.config == "small" and a.readout == "dense" and a.dropout == 0.0 and not a.multi_document
+            default_workload = (a.config == "small" and a.readout == "masked" and a.dropout == 0.0 and not a.multi_document
                                 and a.rows_per_rank == 128 and a.mini_batch_size == 8)
             if default_workload and pmc:
                 with open(pmc) as f:
@@ -462,8 +464,9 @@ def main():
                         f.write(f"{name:62s} {d0:7d} {d1:7d} {d2:7d} {n:6d} {tt / n * 1e3:9.1f} {fl * n / (tt * 1e-3) / 1e12:8.1f} {tt:8.2f}\n")
     # Not the headline — the same step in the other regimes a user of the reference meets, each timed over 3 steps after
     # 2 warm-ups and reported beside `value`:
-    #   masked_rows_readout  readout + CE restricted to the ~15 % MLM-masked rows (TrainStep lm_head_impl="masked": same
-    #                        loss and gradients, rows outside the mask contribute exact zeros);
+    #   dense_logits_forward / dense_dlogits_full_backward   the readout computed for every position in the forward, and also
+    #                        with the dense d(logits) backward (the reference's literal graph) — same loss and gradients as the
+    #                        headline's masked-rows readout, rows outside the mask contribute exact zeros;
     #   dropout_0.1          the reference's default --dropout (train_encoder.py:445); `value` is quoted at dropout 0,
     #                        the parity regime;
     #   dense_mask_calling_convention   the mask handed over as the reference's additive (B,H,T,T) expand() view
@@ -491,7 +494,13 @@ def main():
         if a.readout != "masked":
             _step.lm_head_impl = "masked"
             variants["masked_rows_readout"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
-                                               "note": "readout + CE on the MLM-masked rows only, forward included; identical loss and gradients; not the headline"}
+                                               "note": "readout + CE on the MLM-masked rows only, forward included; identical loss and gradients"}
+            _step.lm_head_impl = a.readout
+        if a.readout != "dense":
+            _step.lm_head_impl = "dense"
+            variants["dense_logits_forward"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
+                                                "note": "logits of EVERY position in the forward (model.py:253 as the reference calls it), readout backward over "
+                                                        "the masked rows; identical loss and gradients (rounds 1-2 quoted this form)"}
             _step.lm_head_impl = a.readout
         if a.readout != "dense_full":
             _step.lm_head_impl = "dense_full"
@@ -499,7 +508,7 @@ def main():
                                                        "note": "the reference's literal graph: dense [M,V] d(logits) and full-size readout backward products "
                                                                "(85 % of those rows are exact zeros); identical loss and gradients"}
             _step.lm_head_impl = a.readout
-        if a.readout == "dense" and a.micro_batches_per_pass == 1 and (a.rows_per_rank // a.mini_batch_size) % 2 == 0:
+        if a.readout in ("dense", "masked") and a.micro_batches_per_pass == 1 and (a.rows_per_rank // a.mini_batch_size) % 2 == 0:
             _step.per_pass = 2
             tune.tune_model_shapes(2 * a.mini_batch_size * cfg["ctx_len"], cfg["n_embd"], 2 ** 16, device=dev)   # plans for the 16-row shapes
             if world > 1:
@@ -559,8 +568,8 @@ def main():
                        "parallelism": f"dp{world}", "dropout": a.dropout, "vocab": 65536,
                        "collectives": collectives},
             # FLOP the step actually executes per token: the reference's 6N + 12LCT (train_encoder.py:360) minus the part of the
-            # readout's backward the default path does not perform (it contracts over the ~15 % MLM-masked rows only; the other
-            # rows of d(logits) are exact zeros).  This is the fraction of the bf16 MFMA peak the whole step sustains.
+            # readout the default path does not perform (its three products run over the ~15 % MLM-masked rows only; the other
+            # rows are multiplied by zero in the loss).  This is the fraction of the bf16 MFMA peak the whole step sustains.
             "flops_per_token_executed": fpt_exec,
             "mfma_fraction_whole_step_executed": round(value * fpt_exec / (PEAK_BF16_TFLOPS * 1e12 * world), 4),
             # the reference's own formula, for comparison with its MFU log line only: it counts FLOP this step does not execute

@@ -251,7 +251,9 @@ int obte_masked_ce_fwd_bwd_reuse(const obte_bf16* logits, const int64_t* target,
  * logits) that are masked; target is indexed by position; row_loss [n_rows] and dlogits_rows [n_rows, vocab] are
  * compact.  The readout's backward then contracts over n_rows instead of total_rows — the zero rows it leaves out
  * contribute nothing to either gradient.  row_scale_vec (nullable, fp32 [n_rows]): an extra weight per listed row, for a call
- * that covers several micro-batches, each normalised by its own count of masked tokens (train_encoder.py:305). */
+ * that covers several micro-batches, each normalised by its own count of masked tokens (train_encoder.py:305).
+ * row_index = NULL (then n_rows == total_rows): logits [n_rows, vocab] and target [n_rows] already hold the listed rows alone
+ * — the readout that computes the masked positions only.  dlogits_rows must not alias logits. */
 int obte_masked_ce_rows(const obte_bf16* logits, const int64_t* target, const int64_t* row_index, const float* grad_scale,
                         float row_scale, const float* row_scale_vec, float* row_loss, obte_bf16* dlogits_rows, int64_t n_rows,
                         int64_t total_rows, int64_t vocab, obte_stream s);

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void masked_ce_kernel(const bf16* __restrict__
     const int64_t src = row_index ? row_index[r] : r;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bf16* drow = dlogits + r * vocab;
-    if (!row_index && !mlm_mask[r]) {
+    if (!row_index && mlm_mask && !mlm_mask[r]) {   // neither list nor mask: every row is served (obte_masked_ce_rows without a list)
         if (threadIdx.x == 0 && row_loss) row_loss[r] = 0.f;
         if (prev_mask && !prev_mask[r]) return;   // still zero from before
         const bf16x8 z = {};
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void masked_ce_regs_kernel(const bf16* __re
                                                               const int64_t* __restrict__ row_index, const float* __restrict__ row_scale_vec) {
     __shared__ float red[8];
     const int64_t r = blockIdx.x;
-    const int64_t src = row_index[r];
+    const int64_t src = row_index ? row_index[r] : r;   // no list: the logits are already the listed rows ([n_rows, vocab])
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bf16* drow = dlogits + r * vocab;
     const bf16* lrow = logits + src * vocab;
@@ -609,9 +609,11 @@ extern "C" int obte_masked_ce_fwd_bwd_reuse(const obte_bf16* logits, const int64
 extern "C" int obte_masked_ce_rows(const obte_bf16* logits, const int64_t* target, const int64_t* row_index, const float* grad_scale,
                                    float row_scale, const float* row_scale_vec, float* row_loss, obte_bf16* dlogits_rows, int64_t n_rows,
                                    int64_t total_rows, int64_t vocab, obte_stream s) {
-    OBTE_REQUIRE(logits && target && row_index && grad_scale && dlogits_rows && row_loss, "obte_masked_ce_rows: null pointer");
+    OBTE_REQUIRE(logits && target && grad_scale && dlogits_rows && row_loss, "obte_masked_ce_rows: null pointer");
     OBTE_REQUIRE(n_rows > 0 && n_rows <= total_rows && total_rows < (1ll << 31) && vocab > 0 && vocab % 8 == 0,
                  "obte_masked_ce_rows: need 0 < n_rows <= total_rows and vocab %% 8 == 0");
+    OBTE_REQUIRE(row_index || n_rows == total_rows, "obte_masked_ce_rows: without a row list, logits and target hold exactly the n_rows listed rows");
+    OBTE_REQUIRE((const void*)logits != (const void*)dlogits_rows, "obte_masked_ce_rows: dlogits_rows must not alias logits");
     const int prof = obte_prof_begin((hipStream_t)s, 112, n_rows, vocab, 1);   // algorithmic bytes = 4 * n_rows * vocab (read + write)
     static int regs_on = -1;   // OBTE_CE_REGS=0: the two-pass kernel (A/B timing; bitwise the same results)
     if (regs_on < 0) { const char* e = getenv("OBTE_CE_REGS"); regs_on = (e && e[0] == '0') ? 0 : 1; }

@@ -396,13 +396,17 @@ def masked_ce(logits, targets, mlm_mask, n_accum: int, reuse: Optional[DLogitsBu
 
 def masked_ce_rows(logits, targets, rows, n_accum: int, row_weights: Optional[torch.Tensor] = None):
     """The same loss on a compact list of masked positions: ``rows`` int64 (n,) ascending row indices into the dense
-    logits (viewed [M, V]).  Returns (loss, dlogits_rows bf16 [n, V]) — the rows of d(logits) that are not exact zeros.
+    logits (viewed [M, V]) — or None when logits and targets already hold the listed rows alone ([n, V] and (n,): the
+    readout that computes the masked rows only).  Returns (loss, dlogits_rows bf16 [n, V]) — the rows of d(logits) that are
+    not exact zeros.
     row_weights (fp32 (n,), optional): replaces the 1/n normalisation by a weight per listed row — a call that covers
     several micro-batches passes 1 / (masked tokens of the row's own micro-batch)."""
-    _need(logits, "logits"); _need(targets, "targets", torch.int64); _need(rows, "rows", torch.int64)
+    _need(logits, "logits"); _need(targets, "targets", torch.int64)
     V = logits.shape[-1]
     M = logits.numel() // V
-    n = rows.numel()
+    if rows is not None:
+        _need(rows, "rows", torch.int64)
+    n = rows.numel() if rows is not None else M
     assert targets.numel() == M and 0 < n <= M
     if row_weights is not None:
         _need(row_weights, "row_weights", torch.float32); assert row_weights.numel() == n

@@ -167,13 +167,13 @@ class TrainStep:
 
     def __init__(self, model, optimizer, scheduler=None, *, mini_batch_size: int, n_head: int, use_padding: bool = False,
                  loss_impl: str = "fused", mask_impl: str = "ranges", sync_every_micro_step: bool = False,
-                 max_grad_norm: float = 1.0, lm_head_impl: str = "dense", pipeline_streams: int = 1,
+                 max_grad_norm: float = 1.0, lm_head_impl: str = "masked", pipeline_streams: int = 1,
                  fused_loss_fn: Optional[Callable] = None, micro_batches_per_pass: int = 1):
         """fused_loss_fn: ``(logits, targets, mlm_mask, n_accum) -> (loss, dlogits)`` used by loss_impl="fused" instead of
         the HIP kernel (ops.masked_ce) — lets the CPU multi-process tests drive the product scheduling (in-place
         accumulation, no_sync, hand-delivered d(logits)) with a stub model and a torch loss."""
         self.fused_loss_fn = fused_loss_fn
-        # micro_batches_per_pass = k > 1 (default readout path only): k consecutive micro-batches go through the model in ONE
+        # micro_batches_per_pass = k > 1 (the two row-compact readout paths): k consecutive micro-batches go through the model in ONE
         # forward/backward of k * mini_batch_size rows.  Rows never interact across a batch (attention is per row, the mask
         # builder's per-micro-batch quirk is kept), and the loss keeps the reference's normalisation — every masked row is
         # weighted 1 / (n_accum * masked tokens of ITS micro-batch), train_encoder.py:301-305 — so loss and gradients are those
@@ -185,14 +185,15 @@ class TrainStep:
         self.loss_impl, self.mask_impl = loss_impl, mask_impl
         self.sync_every = sync_every_micro_step
         self.max_grad_norm = max_grad_norm
-        # "dense" (default): the forward computes the logits of EVERY position, as the reference does (train_encoder.py:296);
-        #     the loss multiplies the unmasked ~85 % of the rows by zero (:304), so d(logits) has exact-zero rows there and
-        #     the readout's backward contracts over the masked rows only (ops.masked_ce_rows + model._ReadoutRowsGradFn):
-        #     same gradients, the zero rows simply are not multiplied.
+        # "masked" (default): the loss multiplies the unmasked ~85 % of the positions by zero
+        #     (train_encoder.py:304), so the readout (model.py:253, reached through forward(return_embeddings=True)) and the
+        #     cross entropy run on the MLM-masked positions alone: logits [n_masked, V] instead of [B*T, V], CE over those rows
+        #     (ops.masked_ce_rows), the two backward products over those rows (model._ReadoutRowsGradFn).  Same loss, same
+        #     gradients — the positions left out contribute exact zeros — for 1/6.7 of the lm_head work.
+        # "dense": the forward computes the logits of EVERY position, as the reference does (train_encoder.py:296); d(logits)
+        #     has exact-zero rows outside the mask, so the readout's backward contracts over the masked rows only.
         # "dense_full": the same forward, and the backward through the dense [M, V] d(logits) tensor — the literal
         #     translation of the reference's graph (logits.backward(dlogits)); kept for A/B and for callers of model(x).
-        # "masked" (SURVEY.md §8f rank 1): readout and cross entropy on the masked rows alone in the forward too — the
-        #     same loss and gradients for 1/6.7 of the lm_head work and none of the 1 GiB logits tensor.
         assert lm_head_impl in ("dense", "dense_full", "masked")
         self.lm_head_impl = lm_head_impl
         self._dlogits = {}
@@ -291,24 +292,29 @@ class TrainStep:
         _ReadoutRowsGradFn.apply(emb_rows, core.lm_head.weight, wm, dl).backward()
         return loss.detach()
 
-    def _masked_rows_loss_backward(self, x, y, mk, attn_mask, n_accum):
-        """Readout + CE on the masked rows only.  The row indices come from the host-side MLM draw (no device sync)."""
+    def _masked_rows_loss_backward(self, x, y, mk, attn_mask, n_accum, k: int = 1):
+        """lm_head_impl="masked" (SURVEY.md §8f rank 1): readout + CE on the masked rows only, forward included.  The row
+        indices come from the host-side MLM draw (no device sync); logits exist for the listed rows alone ([n_masked, V]),
+        the CE kernel turns them into d(logits) rows, and the two backward products are those of the "dense" path."""
         from . import ops
+        from .model import _ReadoutRowsGradFn
         emb = self.model(x, attn_mask=attn_mask, return_embeddings=True)
-        rows = self._mask_rows_host[self._mb]            # int64 tensor on the device, built from the NumPy draw
         core = self.model.module if hasattr(self.model, "module") else self.model
+        rows, weights = self._pass_rows(self._mb, k, self.mini * x.shape[1])
         if rows.numel() == 0:
-            # nothing masked in this micro-batch: still hand EVERY parameter a (zero) gradient — lm_head included — or
+            # nothing masked in this pass: still hand EVERY parameter a (zero) gradient — lm_head included — or
             # DDP's reducer would wait for it forever when this is the synchronising micro-batch
             self._order_backward()
             (emb.sum() * 0 + core.lm_head.weight.sum() * 0).backward()
             return torch.zeros((), dtype=torch.float32, device=x.device)
         emb_rows = emb.reshape(-1, emb.shape[-1]).index_select(0, rows)
-        logits = core.lm_head(emb_rows)
-        ones = torch.ones(rows.numel(), dtype=torch.bool, device=x.device)
-        loss, dlogits = ops.masked_ce(logits, y.reshape(-1).index_select(0, rows), ones, n_accum)
+        with torch.no_grad():
+            logits = core.lm_head(emb_rows)                # (n_masked, V): model.py:253 on the rows the loss keeps (:304)
+            loss, dl = ops.masked_ce_rows(logits, y.reshape(-1).index_select(0, rows), None, n_accum, row_weights=weights)
+        del logits
         self._order_backward()
-        logits.backward(dlogits)
+        wm = float(core.lm_head.output_mult) / float(core.lm_head.width_mult())
+        _ReadoutRowsGradFn.apply(emb_rows, core.lm_head.weight, wm, dl).backward()
         return loss.detach()
 
     def _host_prelude(self, input_ids, ids_host, rows, n_accum, want_rows):
@@ -361,7 +367,8 @@ class TrainStep:
         input_ids = input_ids[:rows]
         n_accum = rows // self.mini
         self.optimizer.zero_grad(set_to_none=True)
-        sparse_rows = self.lm_head_impl == "masked" or (self.lm_head_impl == "dense" and self.loss_impl == "fused" and self.fused_loss_fn is None)
+        # the two row-compact readouts need the HIP kernels; a stub model / torch loss (CPU tests) takes the generic graph
+        sparse_rows = self.lm_head_impl in ("dense", "masked") and self.loss_impl == "fused" and self.fused_loss_fn is None
         if mlm_mask is None and input_ids_host is not None and input_ids.is_cuda:
             masked_ids, mask, lists = self._host_prelude(input_ids, input_ids_host, rows, n_accum, sparse_rows)
             if sparse_rows:
@@ -384,7 +391,7 @@ class TrainStep:
                 self._mask_rows_host = [torch.nonzero(mh[j], as_tuple=False).reshape(-1).to(input_ids.device) for j in range(mh.shape[0])]
         dtype = next(self.model.parameters()).dtype
         core_model = self.model.module if hasattr(self.model, "module") else self.model
-        k = self.per_pass if (sparse_rows and self.lm_head_impl == "dense" and n_accum % self.per_pass == 0) else 1
+        k = self.per_pass if (sparse_rows and n_accum % self.per_pass == 0) else 1
         n_pass, span = n_accum // k, k * self.mini          # passes through the model, rows per pass
         emb_orders = None
         if input_ids.is_cuda and self.loss_impl == "fused" and self.fused_loss_fn is None and hasattr(core_model, "transformer"):
@@ -438,8 +445,8 @@ class TrainStep:
                     ln_mode = 1 if j == 1 else (3 if last else 2)
                 with ctx, ctx_order, self._inplace(not last and not self.sync_every, ln_mode):
                     mk = mask[j * span:(j + 1) * span]
-                    if self.lm_head_impl == "masked":
-                        partial[self._slot] += self._masked_rows_loss_backward(x, y, mk, attn_mask, n_accum)
+                    if sparse_rows and self.lm_head_impl == "masked":
+                        partial[self._slot] += self._masked_rows_loss_backward(x, y, mk, attn_mask, n_accum, k)
                     elif sparse_rows:
                         partial[self._slot] += self._dense_logits_sparse_backward(x, y, mk, attn_mask, n_accum, k)
                     else:

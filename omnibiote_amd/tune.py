@@ -121,8 +121,9 @@ def model_gemm_shapes(rows: int, n_embd: int, vocab: int):
         (M, C, 3 * C, True, False, E.EPI_NONE), (M, C, V, True, False, E.EPI_NONE),
         (C, 4 * C, M, False, False, E.EPI_NONE), (4 * C, C, M, False, False, E.EPI_NONE), (C, C, M, False, False, E.EPI_NONE),
         (3 * C, C, M, False, False, E.EPI_NONE), (V, C, M, False, False, E.EPI_NONE),
-        # the readout's backward over the MLM-masked rows (about 15 % of M; the library applies these two plans to counts within 20 %)
-        (Mm, C, V, True, False, E.EPI_NONE), (V, C, Mm, False, False, E.EPI_NONE),
+        # the readout over the MLM-masked rows (about 15 % of M; the library applies these plans to counts within 20 %): its
+        # two backward products, and the forward of the readout that computes the masked rows only
+        (Mm, C, V, True, False, E.EPI_NONE), (V, C, Mm, False, False, E.EPI_NONE), (Mm, V, C, True, True, E.EPI_NONE),
     ]
 
 

@@ -3,12 +3,14 @@
   * ``ops.masked_ce_rows`` (the compact CE forward+backward over the MLM-masked rows) at V = 65 536 against the oracle's
     ``R.masked_lm_loss`` (training/train_encoder.py:301-305), ragged row counts {1, 63, 65, 1167, 1312}, with and without
     per-row weights;
-  * ``TrainStep(lm_head_impl="dense")`` — the headline readout: logits of every position in the forward, d(logits) of the
-    masked rows only, split-K dgrad over K = 65 536 and accumulate-wgrad over K ~ 1229, d emb rows scattered back — on the
-    small config (8L / 1024d / 8h, V = 65 536, T = 1024) at the REAL micro-batch of 8 rows, four micro-batches, through the
-    host-side MLM prelude bench.py uses, on two streams and with the committed tuned plan table (all three GEMM structures
-    and the nearest-plan lookup for the ragged row counts), against the oracle run micro-batch by micro-batch in fp32
-    (train_encoder.py:284-311); and the same step with two micro-batches per pass;
+  * ``TrainStep(lm_head_impl="masked")`` — the headline readout since round 3: embeddings of the masked
+    positions gathered, logits [~1229, 65 536] for those rows only, compact CE, split-K dgrad over K = 65 536 and
+    accumulate-wgrad over K ~ 1229, d emb rows scattered back — and ``lm_head_impl="dense"`` (rounds 1-2's headline: logits of
+    every position in the forward, the same backward) — on the small config (8L / 1024d / 8h, V = 65 536, T = 1024) at the
+    REAL micro-batch of 8 rows, four micro-batches, through the host-side MLM prelude bench.py uses, on two streams and with
+    the committed tuned plan table (all GEMM structures and the nearest-plan lookup for the ragged row counts), against the
+    oracle run micro-batch by micro-batch in fp32 (train_encoder.py:284-311), which computes every position's logits and
+    multiplies the unmasked ones by zero as the reference does; and the same steps with two micro-batches per pass;
   * BASELINE config 5 at depth: 24L / 2048d / 16h, T = 1024, one row end to end against the oracle.
 
 The fp32 oracle costs ~12 s per 8-row micro-batch on the GPU box's 16 cores; it runs once per module."""
@@ -52,6 +54,10 @@ def test_masked_ce_rows_full_vocabulary_vs_oracle(n_rows, weighted):
     loss, dl = ops.masked_ce_rows(logits.to(DEV), targets.to(DEV), rows.to(DEV), n_accum,
                                   row_weights=None if w is None else w.to(DEV))
     assert tuple(dl.shape) == (n_rows, V) and dl.dtype == BF
+    # the form without a row list (logits and targets hold the listed rows alone: the masked-rows readout) — bitwise the same
+    loss_c, dl_c = ops.masked_ce_rows(logits[rows].contiguous().to(DEV), targets[rows].to(DEV), None, n_accum,
+                                      row_weights=None if w is None else w.to(DEV))
+    assert loss_c.item() == loss.item() and torch.equal(dl_c, dl)
     assert abs(loss.item() - ref_loss.item()) <= 2e-5 * abs(ref_loss.item()) + 1e-7, (loss.item(), ref_loss.item())
     got, want = dl.float().cpu(), lg.grad
     err = (got - want).abs()
@@ -100,7 +106,7 @@ def _small_problem():
     return _cache["ref"]
 
 
-def _run_headline_step(per_pass, pipeline_streams, tuned):
+def _run_headline_step(per_pass, pipeline_streams, tuned, impl="masked"):
     from omnibiote_amd import train_encoder as TE
     from omnibiote_amd import _lib as L
     from omnibiote_amd import tune
@@ -108,10 +114,10 @@ def _run_headline_step(per_pass, pipeline_streams, tuned):
     cfg, w, ids, mlm, ref_loss, ref_grads = _small_problem()
     m = _hip_model(cfg, w, s["T"])
     if tuned:   # the plan table committed with the profiles: structures 1/2/3, split-K 12 for the compact dgrad, nearest-plan lookup
-        tune.load_plans(os.path.join(ROOT, "profiles", "r02_gemm_plans_small.json"))
+        tune.load_plans(os.path.join(ROOT, "profiles", "r03_gemm_plans_small.json"))
     try:
         opt = torch.optim.SGD(m.parameters(), lr=0.0)
-        step = TE.TrainStep(m, opt, None, mini_batch_size=s["mini"], n_head=s["n_head"], lm_head_impl="dense", max_grad_norm=1e9,
+        step = TE.TrainStep(m, opt, None, mini_batch_size=s["mini"], n_head=s["n_head"], lm_head_impl=impl, max_grad_norm=1e9,
                             pipeline_streams=pipeline_streams, micro_batches_per_pass=per_pass)
         np.random.seed(s["seed"])                               # the same Bernoulli draw as the oracle's
         out = step(ids.to(DEV), input_ids_host=ids.numpy())     # bench.py's calling convention: host copy -> no device round trip
@@ -137,21 +143,29 @@ def _run_headline_step(per_pass, pipeline_streams, tuned):
     touched = torch.zeros(s["V"], dtype=torch.bool)
     touched[R.mlm_corrupt(ids, mlm)[0].reshape(-1)] = True
     assert not m.transformer.wte.weight.grad[~touched.to(DEV)].any()
-    print(f"[headline per_pass={per_pass} streams={pipeline_streams} tuned={tuned}] loss {loss:.4f} vs {ref_loss:.4f}; "
+    print(f"[headline readout={impl} per_pass={per_pass} streams={pipeline_streams} tuned={tuned}] loss {loss:.4f} vs {ref_loss:.4f}; "
           f"worst gradient {worst[2]} cos {worst[0]:.5f} rel {worst[1]:.4f}")
     return {k: p.grad.clone() for k, p in m.named_parameters()}, loss
 
 
-def test_headline_readout_step_small_config_vs_oracle():
-    """lm_head_impl="dense", pipeline_streams=2, tuned plans, B = 8 x 4 micro-batches: what BENCH times."""
-    _cache["g1"] = _run_headline_step(per_pass=1, pipeline_streams=2, tuned=True)
+@pytest.mark.parametrize("impl", ["masked", "dense"])
+def test_headline_readout_step_small_config_vs_oracle(impl):
+    """pipeline_streams=2, tuned plans, B = 8 x 4 micro-batches: what BENCH times ("masked"), and rounds 1-2's form ("dense")."""
+    _cache["g1", impl] = _run_headline_step(per_pass=1, pipeline_streams=2, tuned=True, impl=impl)
+    if ("g1", "masked") in _cache and ("g1", "dense") in _cache:   # the two readouts: the same mathematics, far inside the bar
+        (ga, la), (gb, lb) = _cache["g1", "masked"], _cache["g1", "dense"]
+        assert abs(la - lb) <= 2e-3
+        for k in ga:
+            a, b = ga[k].float().flatten(), gb[k].float().flatten()
+            assert ((a - b).norm() / (a.norm() + 1e-30)).item() <= 0.02, k
 
 
-def test_headline_step_two_micro_batches_per_pass_vs_oracle():
+@pytest.mark.parametrize("impl", ["masked", "dense"])
+def test_headline_step_two_micro_batches_per_pass_vs_oracle(impl):
     """micro_batches_per_pass=2 (16 rows per launch, every masked row weighted by its own micro-batch's count)."""
-    g2, loss2 = _run_headline_step(per_pass=2, pipeline_streams=1, tuned=False)
-    if "g1" in _cache:    # and the two executions of the same mathematics agree far inside the bar against the oracle
-        g1, loss1 = _cache["g1"]
+    g2, loss2 = _run_headline_step(per_pass=2, pipeline_streams=1, tuned=False, impl=impl)
+    if ("g1", impl) in _cache:    # and the two executions of the same mathematics agree far inside the bar against the oracle
+        g1, loss1 = _cache["g1", impl]
         assert abs(loss1 - loss2) <= 2e-3
         for k in g1:
             a, b = g1[k].float().flatten(), g2[k].float().flatten()
