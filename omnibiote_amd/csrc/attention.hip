@@ -20,6 +20,7 @@
 #include "common.h"
 #include <string.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -568,29 +569,34 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
                 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Kt, 32 * mt, s, lane), qf[s], sc, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(Vt, 32 * mt, s, lane), dof[s], dp, 0, 0, 0);
             }
+            // 32 keys that every query of the wave may see (the inside of a document): no per-element range test
+            auto ds_rows = [&](auto checked) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float mk[4] = {0.f, 0.f, 0.f, 0.f};
-                if (MODE == MASK_DENSE) mask4(mrow, key0 + 32 * mt + 8 * i + 4 * h, T, mvec, mk);
-                uint32_t bits[2] = {0u, 0u};
-                if (DROP) {
-                    const uint32_t g = (uint32_t)(key0 + 32 * mt + 8 * i + 4 * h) >> 1;
-                    bits[0] = drop_pair_bits(drop_rk, g);
-                    bits[1] = drop_pair_bits(drop_rk, g + 1);
-                }
+                for (int i = 0; i < 4; ++i) {
+                    float mk[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (MODE == MASK_DENSE) mask4(mrow, key0 + 32 * mt + 8 * i + 4 * h, T, mvec, mk);
+                    uint32_t bits[2] = {0u, 0u};
+                    if (DROP) {
+                        const uint32_t g = (uint32_t)(key0 + 32 * mt + 8 * i + 4 * h) >> 1;
+                        bits[0] = drop_pair_bits(drop_rk, g);
+                        bits[1] = drop_pair_bits(drop_rk, g + 1);
+                    }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * i + j;
-                    const int key = key0 + 32 * mt + acc_row(r, h);
-                    float x = sc[r] * scale2 - lse2;
-                    if (MODE == MASK_DENSE) x += mk[j];
-                    float pv = fast_exp2(x);
-                    if (key < ks || key >= ke) pv = 0.f;
-                    float dpd = dp[r];
-                    if (DROP) dpd = drop_keep_bits(bits[j >> 1], (uint32_t)(j & 1), p.drop) ? dpd * p.drop.scale : 0.f;
-                    sc[r] = pv * (dpd - dl);   // dS^T (without the scale factor)
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * i + j;
+                        const int key = key0 + 32 * mt + acc_row(r, h);
+                        float x = sc[r] * scale2 - lse2;
+                        if (MODE == MASK_DENSE) x += mk[j];
+                        float pv = fast_exp2(x);
+                        if (decltype(checked)::value && (key < ks || key >= ke)) pv = 0.f;
+                        float dpd = dp[r];
+                        if (DROP) dpd = drop_keep_bits(bits[j >> 1], (uint32_t)(j & 1), p.drop) ? dpd * p.drop.scale : 0.f;
+                        sc[r] = pv * (dpd - dl);   // dS^T (without the scale factor)
+                    }
                 }
-            }
+            };
+            if (MODE != MASK_DENSE && __all(key0 + 32 * mt >= ks && key0 + 32 * mt + 32 <= ke)) ds_rows(std::false_type{});
+            else ds_rows(std::true_type{});
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const bf16x8 dsf = pack8(sc, 8 * kk);
@@ -774,27 +780,35 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
 #ifdef OBTE_DEBUG_HOOKS
         if (!(p.dbg_skip & 1))
 #endif
+        {
+            // 32 queries that every key of the wave is seen by (the inside of a document): no per-element range test
+            auto p_ds_rows = [&](auto checked) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(stats + 8 * i + 4 * h);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(stats + 32 + 8 * i + 4 * h);
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(stats + 8 * i + 4 * h);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(stats + 32 + 8 * i + 4 * h);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 4 * i + j;
-                const int q = q0 + 8 * i + 4 * h + j;
-                float x = sc[r] * scale2 - l4[j];
-                if (MODE == MASK_DENSE) { if (q < T) x += bf2f(mcol[(int64_t)q * p.mask_sq]) * LOG2E; }
-                float pv = fast_exp2(x);
-                if (q < qs || q >= qe) pv = 0.f;
-                float pd = pv, dpd = dp[r];
-                if (DROP) {   // row key of query q from the stage's table, this lane's key as the column
-                    const bool kp = drop_keep(__float_as_uint(stats[64 + 8 * i + 4 * h + j]), (uint32_t)key_c, p.drop);
-                    pd = kp ? pv * p.drop.scale : 0.f;
-                    dpd = kp ? dpd * p.drop.scale : 0.f;
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * i + j;
+                        const int q = q0 + 8 * i + 4 * h + j;
+                        float x = sc[r] * scale2 - l4[j];
+                        if (MODE == MASK_DENSE) { if (q < T) x += bf2f(mcol[(int64_t)q * p.mask_sq]) * LOG2E; }
+                        float pv = fast_exp2(x);
+                        if (decltype(checked)::value && (q < qs || q >= qe)) pv = 0.f;
+                        float pd = pv, dpd = dp[r];
+                        if (DROP) {   // row key of query q from the stage's table, this lane's key as the column
+                            const bool kp = drop_keep(__float_as_uint(stats[64 + 8 * i + 4 * h + j]), (uint32_t)key_c, p.drop);
+                            pd = kp ? pv * p.drop.scale : 0.f;
+                            dpd = kp ? dpd * p.drop.scale : 0.f;
+                        }
+                        sc[r] = pd;                    // dropped probabilities feed dV
+                        dp[r] = pv * (dpd - d4[j]);    // dS
+                    }
                 }
-                sc[r] = pd;                    // dropped probabilities feed dV
-                dp[r] = pv * (dpd - d4[j]);    // dS
-            }
+            };
+            // (only where it pays and fits: the dense-mask and dropout forms sit at the 256-register limit and would spill)
+            if (MODE != MASK_DENSE && !DROP && __all(q0 >= qs && q0 + 32 <= qe)) p_ds_rows(std::false_type{});
+            else p_ds_rows(std::true_type{});
         }
 #ifdef OBTE_DEBUG_HOOKS
         if (!(p.dbg_skip & 2))

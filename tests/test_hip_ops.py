@@ -399,6 +399,29 @@ def test_masked_ce(rows, V):
     assert dl.float().sum(1).abs().max().item() < 1e-3
 
 
+@pytest.mark.parametrize("V", [512, 65536, 65536 + 4096])   # register kernel <8>, <32>, and the two-pass kernel beyond 65 536
+def test_masked_ce_rows_with_and_without_a_row_list(V):
+    """obte_masked_ce_rows: a list of positions into dense logits, or (list = NULL) logits that already are the listed rows —
+    against the oracle's masked loss on those rows, and the two forms against each other (bitwise)."""
+    M, n, n_accum = 24, 9, 4
+    logits = rnd(M, V, seed=3, scale=2.0)
+    tgt = torch.from_numpy(np.random.default_rng(3).integers(0, V, size=M))
+    rows = torch.tensor([0, 2, 3, 7, 11, 12, 20, 22, 23])
+    lf = logits[rows].float().requires_grad_(True)
+    ref = R.masked_lm_loss(lf, tgt[rows], torch.ones(n, dtype=torch.bool), n_accum)
+    ref.backward()
+    loss, dl = ops().masked_ce_rows(logits.to(DEV), tgt.to(DEV), rows.to(DEV), n_accum)
+    loss_c, dl_c = ops().masked_ce_rows(logits[rows].contiguous().to(DEV), tgt[rows].to(DEV), None, n_accum)
+    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item()) + 1e-6
+    close(dl, lf.grad, atol=2e-7, rtol=2.0 ** -7, what="dlogits rows")
+    assert loss_c.item() == loss.item() and torch.equal(dl_c, dl)
+    from omnibiote_amd import _lib as L
+    with pytest.raises(RuntimeError):   # no list: the logits must be exactly the listed rows
+        bad = torch.empty(1, dtype=torch.float32, device=DEV)
+        L.check(L.lib().obte_masked_ce_rows(logits.to(DEV).data_ptr(), tgt.to(DEV).data_ptr(), None, bad.data_ptr(), 1.0, None,
+                                            bad.data_ptr(), dl.data_ptr(), n, M, V, 0), "obte_masked_ce_rows")
+
+
 def test_full_size_properties_of_the_memory_bound_kernels():
     """BASELINE config 2 sizes (8192 rows, 1024 features, 65536 classes), size-independent properties:
     LayerNorm rows have zero mean / unit variance for w = 1 and its input gradient is orthogonal to the all-ones vector
