@@ -21,6 +21,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -43,7 +44,13 @@ struct AttnParams {
     int max_tiles;  // timing-only diagnostic (OBTE_ATTN_DEBUG=tiles:N): every workgroup stops after N tiles (results are wrong; 0 = off)
     int dbg_skip;   // timing-only diagnostic, debug build (OBTE_ATTN_SKIP=bits): dK/dV kernel — 1: no softmax arithmetic, 2: no phase-C MFMAs,
                     // 4: no phase-A MFMAs, 8: no per-tile barrier (results are wrong)
+    unsigned long long* dbg_times;   // debug build (OBTE_ATTN_TIMES=1): per workgroup, s_memrealtime at entry / loop start / loop end / stores issued / stores done
 };
+#ifdef OBTE_DEBUG_HOOKS
+#define OBTE_STAMP(p, k) do { if ((p).dbg_times && threadIdx.x == 0) (p).dbg_times[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define OBTE_STAMP(p, k) do { } while (0)
+#endif
 
 // LDS image of a [rows][D] bf16 tile: groups of 8 rows (16*D bytes), each cut into 8-row x 32-column subtiles of 512 B whose
 // 64-B rows hold their four 16-B chunks XOR-ed with row bits 2-3 (cdna_hip_programming.md T10, image (a)).  Both kinds of
@@ -216,6 +223,26 @@ __device__ __forceinline__ void block_minmax(int& lo, int& hi, int* scratch, int
 // cost two hash rounds and 64-bit index arithmetic and the kernels needed the 512-register budget; with the row key
 // hoisted and one hash per two keys — csrc/common.h — they fit 256 registers: forward 99 -> 58 us, backward 310 -> 189 us
 // at p = 0.1, against 47 / 160 us without dropout.)
+// Output / gradient rows leave through LDS.  The accumulators hold, per lane, 4 consecutive columns of ONE row (row = lane & 31):
+// stored as they lie that is 8-byte pieces of 32 different rows per wave instruction — partial lines, 4.7 us of store issue in the
+// dK/dV epilogue (s_memrealtime stamps, debug build).  Each wave instead writes its 32 x D block into a wave-private LDS region
+// (16-byte chunk XOR row) and reads it back as whole rows: 16-byte pieces, four full 256-byte rows (D = 128) per store instruction.
+// v[c] = the lane's columns 8 c + 4 h .. + 3; rows >= rows_ok (past T) are not stored.  No barrier: the region is the wave's own.
+template <int D>
+__device__ __forceinline__ void wave_rows_out(char* wl, const bf16x4 (&v)[D / 8], bf16* g0, int64_t ld, int rows_ok, int lane) {
+    constexpr int NCH = D / 8;   // 16-byte chunks per row
+    const int row = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) *reinterpret_cast<bf16x4*>(wl + row * (2 * D) + ((c ^ (row & (NCH - 1))) * 16) + 8 * h) = v[c];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ps = 0; ps < (32 * NCH) / 64; ++ps) {
+        const int idx = ps * 64 + lane, r = idx / NCH, c = idx % NCH;
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(wl + r * (2 * D) + ((c ^ (r & (NCH - 1))) * 16));
+        if (r < rows_ok) *reinterpret_cast<bf16x8*>(g0 + (int64_t)r * ld + 8 * c) = x;
+    }
+}
+
 template <bool DROP> struct FwdShape { static constexpr int NW = 8; static constexpr int STAGES = 2; };   // a deeper ring (4 stages, 3 tiles ahead) measured slower: 48.9 vs 45.9 us
 template <int D, int MODE, bool DROP>
 __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem) {
@@ -430,28 +457,48 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem) {
         // row; torch's fused SDPA backends return NaN for it.)
         const bool degenerate = m < -1.0e8f;
         if (h == 0) p.lse[(b * p.H + hd) * T + q_row] = (l_tot > 0.f && !degenerate) ? (m + __log2f(l_tot)) * LN2 : INFINITY;
-        bf16* orow = p.o + (b * T + q_row) * C + hd * D;
+    }
+    {   // every tile has been read (the loop ends on a barrier): the stage memory carries the output rows out (wave_rows_out)
+        bf16x4 ob[ND * 4];
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                bf16x4 v;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = f2bf(o[dt][4 * i + j] * inv);
-                *reinterpret_cast<bf16x4*>(orow + 32 * dt + 8 * i + 4 * h) = v;
-            }
+                for (int j = 0; j < 4; ++j) ob[4 * dt + i][j] = f2bf(o[dt][4 * i + j] * inv);
+        const int64_t row0 = (int64_t)q_row - (lane & 31);   // the wave's first query
+        wave_rows_out<D>(smem + wave * (32 * 2 * D), ob, p.o + (b * T + row0) * C + hd * D, C, (int)min((int64_t)32, (int64_t)T - row0), lane);
     }
 }
 
-// inverse RoPE on 4 consecutive head-dim elements (d0 multiple of 4) of a gradient row at position t
-__device__ __forceinline__ void rope_inv4(float (&g)[4], const float* cos_t, const float* sin_t, int64_t t, int D, int d0) {
-    if (!cos_t) return;
-    const float c0 = cos_t[t * (D / 2) + d0 / 2], c1 = cos_t[t * (D / 2) + d0 / 2 + 1];
-    const float s0 = sin_t[t * (D / 2) + d0 / 2], s1 = sin_t[t * (D / 2) + d0 / 2 + 1];
-    const float e0 = g[0] * c0 + g[1] * s0, o0 = -g[0] * s0 + g[1] * c0;
-    const float e1 = g[2] * c1 + g[3] * s1, o1 = -g[2] * s1 + g[3] * c1;
-    g[0] = e0; g[1] = o0; g[2] = e1; g[3] = o1;
-}
+// inverse RoPE on a gradient row at position t, four consecutive head-dim elements (d0 = 32 dt + 8 i + 4 h) at a time.  The
+// rotation-table entries of the WHOLE row are loaded first (load()), before the first gradient store of the epilogue: vmcnt
+// retires in issue order, so a table load issued behind a store waits for that store's acknowledgement — the former epilogue
+// (load cos, wait, load sin, wait, rotate, store, sixteen times over) cost ~1 us per group, ~15 us per kernel.
+template <int D>
+struct RopeRow {
+    float2 c[D / 8], s[D / 8];
+    bool on;
+    __device__ __forceinline__ void load(const float* cos_t, const float* sin_t, int64_t t, int h) {
+        on = cos_t != nullptr;
+        if (!on) return;
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t at = t * (D / 2) + (32 * dt + 8 * i + 4 * h) / 2;
+                c[4 * dt + i] = *reinterpret_cast<const float2*>(cos_t + at);
+                s[4 * dt + i] = *reinterpret_cast<const float2*>(sin_t + at);
+            }
+    }
+    __device__ __forceinline__ void apply(float (&g)[4], int dt, int i) const {
+        if (!on) return;
+        const float2 cc = c[4 * dt + i], ss = s[4 * dt + i];
+        const float e0 = g[0] * cc.x + g[1] * ss.x, o0 = -g[0] * ss.x + g[1] * cc.x;
+        const float e1 = g[2] * cc.y + g[3] * ss.y, o1 = -g[2] * ss.y + g[3] * cc.y;
+        g[0] = e0; g[1] = o0; g[2] = e1; g[3] = o1;
+    }
+};
 
 // ==========================================================================================================
 // backward, part 1: dQ (and delta).  Same shape as forward: 256 queries per workgroup, query on the lane.
@@ -609,8 +656,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
         __syncthreads();
     }
 
-    if (q_ok) {
-        bf16* drow = p.dqkv + (b * T + q_row) * ld + hd * D;
+    {   // rotation table of the row first (one latency, nothing stored yet), then the rows leave through the stage memory
+        RopeRow<D> rr;
+        rr.load(p.rope_cos, p.rope_sin, q_c, h);
+        bf16x4 gb[ND * 4];
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
@@ -618,13 +667,12 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
                 float g[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) g[j] = dq[dt][4 * i + j] * p.scale;
-                const int d0 = 32 * dt + 8 * i + 4 * h;
-                rope_inv4(g, p.rope_cos, p.rope_sin, q_row, D, d0);
-                bf16x4 v;
+                rr.apply(g, dt, i);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = f2bf(g[j]);
-                *reinterpret_cast<bf16x4*>(drow + d0) = v;
+                for (int j = 0; j < 4; ++j) gb[4 * dt + i][j] = f2bf(g[j]);
             }
+        const int64_t row0 = (int64_t)q_row - (lane & 31);   // the wave's first query
+        wave_rows_out<D>(smem + wave * (32 * 2 * D), gb, p.dqkv + (b * T + row0) * ld + hd * D, ld, (int)min((int64_t)32, (int64_t)T - row0), lane);
     }
 }
 
@@ -651,6 +699,7 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
     constexpr int NS = D / 16, ND = D / 32;
     constexpr int STAGE = 2 * QB + 384;  // Q tile, dO tile, 32 lse2 + 32 delta floats + 32 dropout row keys
     constexpr int VB = 32 * NW * 2 * D;  // the workgroup's own V rows, kept in LDS for the whole kernel (B operand of dP)
+    OBTE_STAMP(p, 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
@@ -753,6 +802,7 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
     dma_wait_all();
     prologue_wait_all();
     __syncthreads();
+    OBTE_STAMP(p, 1);
 
     for (int t = t_begin; t < t_end; ++t) {
         const int cur = (t - t_begin) & 1;
@@ -834,27 +884,41 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
         __syncthreads();
     }
 
-    if (k_ok) {
-        bf16* dkrow = p.dqkv + (b * T + key) * ld + C + hd * D;
-        bf16* dvrow = dkrow + C;
+    OBTE_STAMP(p, 2);
+    {
+        // dV needs no rotation: rounded first (64 fp32 registers become 32) and sent out through the wave's own V rows in LDS (no
+        // other wave reads them), the rotation table of the key's row requested before anything is stored, then dK the same way
+        const int64_t key0 = (int64_t)key - (lane & 31);   // the wave's first key
+        const int rows_ok = (int)min((int64_t)32, (int64_t)T - key0);
+        char* wl = Vblk + wave * (32 * 2 * D);
+        bf16* dk0 = p.dqkv + (b * T + key0) * ld + C + hd * D;
+        RopeRow<D> rr;
+        rr.load(p.rope_cos, p.rope_sin, key_c, h);
+        bf16x4 gb[ND * 4];
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gb[4 * dt + i][j] = f2bf(dv[dt][4 * i + j]);
+        wave_rows_out<D>(wl, gb, dk0 + C, ld, rows_ok, lane);
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int d0 = 32 * dt + 8 * i + 4 * h;
                 float g[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) g[j] = dk[dt][4 * i + j] * p.scale;
-                rope_inv4(g, p.rope_cos, p.rope_sin, key, D, d0);
-                bf16x4 v;
+                rr.apply(g, dt, i);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = f2bf(g[j]);
-                *reinterpret_cast<bf16x4*>(dkrow + d0) = v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = f2bf(dv[dt][4 * i + j]);
-                *reinterpret_cast<bf16x4*>(dvrow + d0) = v;
+                for (int j = 0; j < 4; ++j) gb[4 * dt + i][j] = f2bf(g[j]);
             }
+        wave_rows_out<D>(wl, gb, dk0, ld, rows_ok, lane);
     }
+#ifdef OBTE_DEBUG_HOOKS
+    OBTE_STAMP(p, 3);
+    if (p.dbg_times) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); OBTE_STAMP(p, 4); }
+#endif
 }
 
 // The kernels proper: the bodies above behind their own entry points, and — for a dense additive mask whose device flag
@@ -929,6 +993,30 @@ int launch_fwd(const AttnParams& p, int mode, hipStream_t st) {
     return OBTE_OK;
 }
 
+#ifdef OBTE_DEBUG_HOOKS
+// OBTE_ATTN_TIMES=1 (debug build): where a dK/dV launch spends its time, from s_memrealtime stamps (100 MHz) of every workgroup
+static void debug_report_times(unsigned long long* dev, int n, hipStream_t st) {
+    static std::vector<unsigned long long> h;
+    h.resize((size_t)n * 8);
+    if (hipStreamSynchronize(st) != hipSuccess) return;
+    if (hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    unsigned long long t0 = ~0ull, tend = 0, first_done = ~0ull;
+    double seg[4] = {0, 0, 0, 0};
+    unsigned long long last_start = 0;
+    for (int i = 0; i < n; ++i) {
+        const unsigned long long* r = &h[(size_t)i * 8];
+        if (r[0] < t0) t0 = r[0];
+        if (r[0] > last_start) last_start = r[0];
+        if (r[4] > tend) tend = r[4];
+        if (r[4] < first_done) first_done = r[4];
+        for (int k = 0; k < 4; ++k) seg[k] += (double)(r[k + 1] - r[k]);
+    }
+    fprintf(stderr, "[attn dkdv times, us] %d workgroups: first entry -> last entry %.2f | mean prologue %.2f, loop %.2f, epilogue issue %.2f, store drain %.2f | "
+            "first entry -> first done %.2f, -> last done %.2f\n", n, (last_start - t0) * 0.01, seg[0] / n * 0.01, seg[1] / n * 0.01, seg[2] / n * 0.01,
+            seg[3] / n * 0.01, (first_done - t0) * 0.01, (tend - t0) * 0.01);
+}
+#endif
+
 template <int D>
 int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
     {
@@ -966,6 +1054,9 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
         if (mode == MASK_NONE) GO(MASK_NONE); else if (mode == MASK_RANGES) GO(MASK_RANGES); else GO(MASK_DENSE);
 #undef GO
         OBTE_CHECK_LAUNCH("obte_attn_bwd(dkdv)");
+#ifdef OBTE_DEBUG_HOOKS
+        if (p.dbg_times) debug_report_times(p.dbg_times, (int)(p.drop.thresh16 ? grid_d.x : grid.x), st);
+#endif
     }
     return OBTE_OK;
 }
@@ -999,10 +1090,24 @@ static int debug_skip() {
     if (v < 0) { const char* e = getenv("OBTE_ATTN_SKIP"); v = e ? atoi(e) : 0; if (v) debug_warn_once("OBTE_ATTN_SKIP"); }
     return v;
 }
+static unsigned long long* debug_times_buffer(int64_t max_groups) {
+    static int on = -1;
+    static unsigned long long* buf = nullptr;
+    static int64_t cap = 0;
+    if (on < 0) { const char* e = getenv("OBTE_ATTN_TIMES"); on = (e && e[0] == '1') ? 1 : 0; }
+    if (!on) return nullptr;
+    if (cap < max_groups) {
+        if (buf) (void)hipFree(buf);
+        if (hipMalloc((void**)&buf, (size_t)max_groups * 64) != hipSuccess) { buf = nullptr; cap = 0; return nullptr; }
+        cap = max_groups;
+    }
+    return buf;
+}
 #else
 static int debug_no_wait() { return 0; }
 static int debug_max_tiles() { return 0; }
 static int debug_skip() { return 0; }
+static unsigned long long* debug_times_buffer(int64_t) { return nullptr; }
 #endif
 
 static int check_common(const char* who, const void* qkv, int64_t B, int64_t T, int H, int D, const int32_t* ranges,
@@ -1105,6 +1210,7 @@ extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
     OBTE_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "obte_attn_bwd: dropout p must be in [0,1)");
     p.drop = make_drop(a->dropout_p, a->dropout_seed, OBTE_SITE_ATTN);
     p.max_tiles = debug_max_tiles(); p.no_wait = debug_no_wait(); p.dbg_skip = debug_skip();
+    p.dbg_times = debug_times_buffer(a->B * a->n_head * ((a->T + 127) / 128));
     const int mode = mask_mode(a->key_ranges, a->mask);
     const int prof = obte_prof_begin((hipStream_t)s, 101, a->B * a->n_head, a->T, a->head_dim);
     if (mode == MASK_DENSE && a->key_ranges && a->query_bounds && a->ranges_exact)
