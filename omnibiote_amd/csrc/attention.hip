@@ -510,6 +510,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
     constexpr int NW = FwdShape<DROP>::NW;
     constexpr int TB = 64 * 2 * D;
     constexpr int NS = D / 16, ND = D / 32;
+    OBTE_STAMP(p, 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
@@ -538,21 +539,13 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
     }
     const float lse2 = p.lse_in[(b * p.H + hd) * T + q_c] * LOG2E;
     const uint32_t drop_rk = DROP ? drop_rowkey(((uint64_t)b * p.H + hd) * (uint64_t)T + (uint64_t)q_c, p.drop) : 0u;
-    // delta = rowsum(O * dO), computed here from the dO fragments already in registers (it used to be a kernel of its
-    // own: one 9-us launch per layer) and published for the dK/dV kernel, which runs after this one on the same stream
-    float dl = 0.f;
-    {
-        const bf16* optr = p.o_in + (b * T + q_c) * C + hd * D;
+    const bf16* optr = p.o_in + (b * T + q_c) * C + hd * D;
+    bf16x8 of[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const bf16x8 of = *reinterpret_cast<const bf16x8*>(optr + 16 * s + 8 * h);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dl += bf2f(of[j]) * bf2f(dof[s][j]);
-        }
-        dl += __shfl_xor(dl, 32, 64);
-        if (h == 0 && q_ok) p.delta[(b * p.H + hd) * T + q_row] = dl;
-    }
+    for (int s = 0; s < NS; ++s) of[s] = *reinterpret_cast<const bf16x8*>(optr + 16 * s + 8 * h);
 
+    // The key range was requested first, so it lands first (vmcnt retires in issue order): the tile range and the first K/V
+    // tile's LDS-DMA go out while the 24 row-fragment loads above are still travelling, instead of one latency behind them.
     int ks = 0, ke = T;
     if (MODE == MASK_RANGES) {
         ks = max(r_lo, 0);
@@ -575,13 +568,6 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
     if (MODE == MASK_DENSE) mrow = p.mask + b * p.mask_sb + hd * p.mask_sh + (int64_t)q_c * p.mask_sq;
     const bool mvec = MODE == MASK_DENSE && mask_vec_ok(p);
 
-    f32x16 dq[ND];
-#pragma unroll
-    for (int i = 0; i < ND; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
-    const float scale2 = p.scale * LOG2E;
-
     TileDma<D, 64, NW> dma;
     dma.init(wave, lane, ld);
     auto issue_kv = [&](int t, int stage) {
@@ -592,9 +578,31 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
         dma.issue(vbase + row0 * ld, (rows_left - (2 * C + hd * D)) * 2, st + TB, wave);
     };
     if (t_begin < t_end) issue_kv(t_begin, 0);
+
+    // delta = rowsum(O * dO), computed here from the dO fragments already in registers (it used to be a kernel of its
+    // own: one 9-us launch per layer) and published for the dK/dV kernel, which runs after this one on the same stream
+    float dl = 0.f;
+    {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += bf2f(of[s][j]) * bf2f(dof[s][j]);
+        dl += __shfl_xor(dl, 32, 64);
+        if (h == 0 && q_ok) p.delta[(b * p.H + hd) * T + q_row] = dl;
+    }
+
+    f32x16 dq[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+    const float scale2 = p.scale * LOG2E;
+
+    if (t_begin < t_end) issue_kv(t_begin, 0);
     dma_wait_all();
     prologue_wait_all();
     __syncthreads();
+    OBTE_STAMP(p, 1);
 
     for (int t = t_begin; t < t_end; ++t) {
         const int cur = (t - t_begin) & 1;
@@ -656,6 +664,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
         __syncthreads();
     }
 
+    OBTE_STAMP(p, 2);
     {   // rotation table of the row first (one latency, nothing stored yet), then the rows leave through the stage memory
         RopeRow<D> rr;
         rr.load(p.rope_cos, p.rope_sin, q_c, h);
@@ -674,6 +683,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
         const int64_t row0 = (int64_t)q_row - (lane & 31);   // the wave's first query
         wave_rows_out<D>(smem + wave * (32 * 2 * D), gb, p.dqkv + (b * T + row0) * ld + hd * D, ld, (int)min((int64_t)32, (int64_t)T - row0), lane);
     }
+#ifdef OBTE_DEBUG_HOOKS
+    OBTE_STAMP(p, 3);
+    if (p.dbg_times) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); OBTE_STAMP(p, 4); }
+#endif
 }
 
 // ==========================================================================================================
@@ -995,7 +1008,7 @@ int launch_fwd(const AttnParams& p, int mode, hipStream_t st) {
 
 #ifdef OBTE_DEBUG_HOOKS
 // OBTE_ATTN_TIMES=1 (debug build): where a dK/dV launch spends its time, from s_memrealtime stamps (100 MHz) of every workgroup
-static void debug_report_times(unsigned long long* dev, int n, hipStream_t st) {
+static void debug_report_times(const char* who, unsigned long long* dev, int n, hipStream_t st) {
     static std::vector<unsigned long long> h;
     h.resize((size_t)n * 8);
     if (hipStreamSynchronize(st) != hipSuccess) return;
@@ -1011,8 +1024,18 @@ static void debug_report_times(unsigned long long* dev, int n, hipStream_t st) {
         if (r[4] < first_done) first_done = r[4];
         for (int k = 0; k < 4; ++k) seg[k] += (double)(r[k + 1] - r[k]);
     }
-    fprintf(stderr, "[attn dkdv times, us] %d workgroups: first entry -> last entry %.2f | mean prologue %.2f, loop %.2f, epilogue issue %.2f, store drain %.2f | "
-            "first entry -> first done %.2f, -> last done %.2f\n", n, (last_start - t0) * 0.01, seg[0] / n * 0.01, seg[1] / n * 0.01, seg[2] / n * 0.01,
+    {   // loop time by XCD (workgroup id % 8) and its spread: who finishes late?
+        double xs[8] = {0}, lo = 1e30, hi = 0; int xn[8] = {0};
+        for (int i = 0; i < n; ++i) {
+            const double d = (double)(h[(size_t)i * 8 + 2] - h[(size_t)i * 8 + 1]) * 0.01;
+            xs[i & 7] += d; xn[i & 7]++; if (d < lo) lo = d; if (d > hi) hi = d;
+        }
+        fprintf(stderr, "[attn %s loop us] min %.2f max %.2f | by XCD:", who, lo, hi);
+        for (int x = 0; x < 8; ++x) fprintf(stderr, " %.2f", xn[x] ? xs[x] / xn[x] : 0.0);
+        fprintf(stderr, "\n");
+    }
+    fprintf(stderr, "[attn %s times, us] %d workgroups: first entry -> last entry %.2f | mean prologue %.2f, loop %.2f, epilogue issue %.2f, store drain %.2f | "
+            "first entry -> first done %.2f, -> last done %.2f\n", who, n, (last_start - t0) * 0.01, seg[0] / n * 0.01, seg[1] / n * 0.01, seg[2] / n * 0.01,
             seg[3] / n * 0.01, (first_done - t0) * 0.01, (tend - t0) * 0.01);
 }
 #endif
@@ -1036,6 +1059,9 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
         if (mode == MASK_NONE) GO(MASK_NONE); else if (mode == MASK_RANGES) GO(MASK_RANGES); else GO(MASK_DENSE);
 #undef GO
         OBTE_CHECK_LAUNCH("obte_attn_bwd(dq)");
+#ifdef OBTE_DEBUG_HOOKS
+        if (p.dbg_times) debug_report_times("dq", p.dbg_times, (int)(p.drop.thresh16 ? grid_d.x : grid.x), st);
+#endif
     }
     {
         const int smem = 2 * (2 * 32 * 2 * D + 384) + 32 * FwdShape<false>::NW * 2 * D + 64;   // >= the dropout variant's
@@ -1055,7 +1081,7 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
 #undef GO
         OBTE_CHECK_LAUNCH("obte_attn_bwd(dkdv)");
 #ifdef OBTE_DEBUG_HOOKS
-        if (p.dbg_times) debug_report_times(p.dbg_times, (int)(p.drop.thresh16 ? grid_d.x : grid.x), st);
+        if (p.dbg_times) debug_report_times("dkdv", p.dbg_times, (int)(p.drop.thresh16 ? grid_d.x : grid.x), st);
 #endif
     }
     return OBTE_OK;
