@@ -53,6 +53,7 @@ struct GemmParams {
     int64_t store_rows;   // = M; 0 in the timing-only 'nostore' diagnostic
     int nt_store;         // non-temporal output stores (outputs that exceed the 256-MiB Infinity Cache)
     int delay_sleeps;     // debug build only: every second workgroup of a CU (odd hardware wave slot) sleeps this many x 3.4 us first
+    unsigned long long* dbg_times;   // debug build only (OBTE_GEMM_TIMES=1): per workgroup, s_memrealtime at entry / first operands landed / loop end / stores issued / stores done
     int64_t a_elems, b_elems;
     int tiles_m, tiles_n, splits, k_per_split;   // k_per_split in K-tiles
     float alpha;
@@ -60,6 +61,11 @@ struct GemmParams {
     const float* rope_cos; const float* rope_sin; int64_t rope_T; int rope_hs;
 };
 
+#ifdef OBTE_DEBUG_HOOKS
+#define OBTE_GSTAMP(p, k) do { if ((p).dbg_times && threadIdx.x == 0) (p).dbg_times[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define OBTE_GSTAMP(p, k) do { } while (0)
+#endif
 __device__ __forceinline__ int kmaj_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int mn_f(int krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
 template <int ROWB>
@@ -323,6 +329,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
     constexpr int NJ = CF::NJ, NPB = CF::NPB, STAGE_BYTES = CF::STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.store_rows < 0) return;   // timing-only diagnostic: launch cost of the empty grid
+    OBTE_GSTAMP(p, 0);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
 
@@ -396,6 +403,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
         else if (CF::NSTAGE == 2 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NPB) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        OBTE_GSTAMP(p, 1);
         load_frags(0, 0, a0, b0);
     }
     for (int t = 0; t + 1 < nk; ++t) {
@@ -421,7 +429,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
         mma(a0, b0);
         mma(a1, b1);
     }
+    OBTE_GSTAMP(p, 2);
     tile_epilogue<EPI, SPLIT, BN>(p, acc, smem, wave, lane, m0, n0, wm, wn, split);
+#ifdef OBTE_DEBUG_HOOKS
+    OBTE_GSTAMP(p, 3);
+    if (p.dbg_times) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); OBTE_GSTAMP(p, 4); }
+#endif
 }
 
 // Explicit instantiations: with implicit instantiation alone hipcc (ROCm 7.2) emitted the host stub of only the
@@ -493,6 +506,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 template <bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPLIT>
 __device__ __forceinline__ void v3_tile(const GemmParams& p, const int wgid, char* smem) {
     constexpr int BN = 256, NJ = 8;
+    OBTE_GSTAMP(p, 0);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int split = wgid % p.splits;
@@ -547,6 +561,7 @@ __device__ __forceinline__ void v3_tile(const GemmParams& p, const int wgid, cha
     issue(0); issue(1); issue(2); issue(3);
     __builtin_amdgcn_s_waitcnt(0x007C);   // vmcnt(12): half-stage 0 landed
     __builtin_amdgcn_s_barrier();
+    OBTE_GSTAMP(p, 1);
     load_frags(0, a0, b0);
     int u = 0;
     // Steady state, hand-interleaved and pinned with sched_barrier: group g of half-step u = {A fragment g and
@@ -603,7 +618,12 @@ __device__ __forceinline__ void v3_tile(const GemmParams& p, const int wgid, cha
     __builtin_amdgcn_sched_barrier(0);
     mma(a0, b0);
     mma(a1, b1);
+    OBTE_GSTAMP(p, 2);
     tile_epilogue<EPI, SPLIT, BN>(p, acc, smem, wave, lane, m0, n0, wm, wn, split);
+#ifdef OBTE_DEBUG_HOOKS
+    OBTE_GSTAMP(p, 3);
+    if (p.dbg_times) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); OBTE_GSTAMP(p, 4); }
+#endif
 }
 
 template <bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPLIT>
@@ -1122,6 +1142,7 @@ static void fill_params(const obte_gemm_args* g, void* workspace, GemmParams& p)
     p.b_elems = (g->b_kmajor ? g->N : g->K) * g->ldb;
     p.store_rows = p.M;
     p.delay_sleeps = 0;
+    p.dbg_times = nullptr;
     p.nt_store = (g->M * g->N * 2 > (256ll << 20)) ? 1 : 0;
     // the GELU epilogue's d (the derivative, 67 MB at the hot-path shape) is read again only in the backward pass: stored
     // non-temporally it does not push the activation d2 — the next GEMM's operand — and the operand panels out of L2 /
@@ -1145,6 +1166,48 @@ static void fill_params(const obte_gemm_args* g, void* workspace, GemmParams& p)
     }
 #endif
 }
+
+#ifdef OBTE_DEBUG_HOOKS
+// OBTE_GEMM_TIMES=1 (debug build): where a GEMM launch spends its time, from s_memrealtime stamps (100 MHz) of every workgroup
+#include <vector>
+static unsigned long long* debug_gemm_times_buffer(int64_t groups) {
+    static int on = -1;
+    static unsigned long long* buf = nullptr;
+    static int64_t cap = 0;
+    if (on < 0) { const char* e = getenv("OBTE_GEMM_TIMES"); on = (e && e[0] == '1') ? 1 : 0; }
+    if (!on) return nullptr;
+    if (cap < groups) {
+        if (buf) (void)hipFree(buf);
+        if (hipMalloc((void**)&buf, (size_t)groups * 64) != hipSuccess) { buf = nullptr; cap = 0; return nullptr; }
+        cap = groups;
+    }
+    (void)hipMemset(buf, 0, (size_t)groups * 64);
+    return buf;
+}
+static void debug_gemm_report(const GemmParams& p, int variant, int epi, hipStream_t st) {
+    const int n = p.tiles_m * p.tiles_n * p.splits;
+    static std::vector<unsigned long long> h;
+    h.resize((size_t)n * 8);
+    if (hipStreamSynchronize(st) != hipSuccess) return;
+    if (hipMemcpy(h.data(), p.dbg_times, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
+    unsigned long long t0 = ~0ull, tend = 0;
+    for (int i = 0; i < n; ++i) { if (h[(size_t)i * 8] && h[(size_t)i * 8] < t0) t0 = h[(size_t)i * 8]; if (h[(size_t)i * 8 + 4] > tend) tend = h[(size_t)i * 8 + 4]; }
+    // workgroups of the first wave of residents (entered within 2 us of the first) and the rest (later rounds)
+    double seg[2][4] = {{0}}, entry[2] = {0, 0}, done[2] = {0, 0}; int cnt[2] = {0, 0};
+    for (int i = 0; i < n; ++i) {
+        const unsigned long long* r = &h[(size_t)i * 8];
+        if (!r[0]) continue;
+        const int c = (r[0] - t0) > 200 ? 1 : 0;
+        cnt[c]++; entry[c] += (double)(r[0] - t0); done[c] += (double)(r[4] - t0);
+        for (int k = 0; k < 4; ++k) seg[c][k] += (double)(r[k + 1] - r[k]);
+    }
+    fprintf(stderr, "[gemm v%d epi %d %lldx%lldx%lld, %d workgroups, us] span %.2f", variant, epi, (long long)p.M, (long long)p.N, (long long)p.K, n, (tend - t0) * 0.01);
+    for (int c = 0; c < 2; ++c)
+        if (cnt[c]) fprintf(stderr, " | %s %d: entry +%.2f, prologue %.2f, loop %.2f, epilogue issue %.2f, drain %.2f, done +%.2f", c ? "later" : "first", cnt[c], entry[c] / cnt[c] * 0.01,
+                            seg[c][0] / cnt[c] * 0.01, seg[c][1] / cnt[c] * 0.01, seg[c][2] / cnt[c] * 0.01, seg[c][3] / cnt[c] * 0.01, done[c] / cnt[c] * 0.01);
+    fprintf(stderr, "\n");
+}
+#endif
 
 extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64_t workspace_bytes, obte_stream s) {
     { const int vrc = validate_args(g); if (vrc != OBTE_OK) return vrc; }
@@ -1179,6 +1242,9 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     p.alpha = g->alpha;
     p.rope_cos = g->rope_cos; p.rope_sin = g->rope_sin; p.rope_T = g->rope_T; p.rope_hs = g->rope_head_dim;
     p.drop = make_drop(g->epilogue == OBTE_EPI_ADD_DROPOUT ? g->dropout_p : 0.f, g->dropout_seed, (uint32_t)g->dropout_site);
+#ifdef OBTE_DEBUG_HOOKS
+    p.dbg_times = debug_gemm_times_buffer((int64_t)p.tiles_m * p.tiles_n * p.splits);
+#endif
     const bool long_enough = p.k_per_split >= 2 && nk - (int64_t)(p.splits - 1) * p.k_per_split >= 2;   // the half-tile rings need >= 4 half-steps
     const bool v3 = use_v3(pl.variant) && pl.bn == 256 && long_enough;
     const bool v4 = !v3 && use_v4(pl.variant) && pl.bn == 128 && long_enough;
@@ -1197,6 +1263,9 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     else if (g->a_kmajor && !g->b_kmajor) rc = dispatch<true, false>(p, g->epilogue, pl.bn, st);
     else if (!g->a_kmajor && g->b_kmajor) rc = dispatch<false, true>(p, g->epilogue, pl.bn, st);
     else rc = dispatch<false, false>(p, g->epilogue, pl.bn, st);
+#ifdef OBTE_DEBUG_HOOKS
+    if (rc == OBTE_OK && p.dbg_times) debug_gemm_report(p, v3 ? 3 : (v4 ? 4 : 2), g->epilogue, st);
+#endif
     if (rc == OBTE_OK && p.splits > 1) {
         const int64_t mn = g->M * g->N;
         int64_t blocks = cdiv64(mn / 4, 256);
