@@ -72,6 +72,18 @@ def candidates(M: int, N: int, K: int, epi: int) -> List[Tuple[int, int, int]]:
     return c
 
 
+def rank_candidates(times: dict) -> list:
+    """{(variant, bn, splits): ms} -> [(ms, variant, bn, splits), ...], the plan to use first.  Candidates within 3 % of the
+    fastest are a tie at this protocol's resolution (cold operands, three repetitions): the structure with the deeper ring
+    goes first — inside the step, with warm operands and neighbours, it is the one that holds its time (the row-compact readout
+    input gradient: 160-195 us on the half-tile ring against 190-215 us when the K-tile ring won the coin toss)."""
+    results = sorted((t, c[0], c[1], c[2]) for c, t in times.items())
+    prefer = {3: 0, 2: 1, 4: 2, 1: 3}
+    tied = [r for r in results if r[0] <= results[0][0] * 1.03]
+    tied.sort(key=lambda r: (prefer.get(r[1], 9), r[0]))
+    return tied[:1] + [r for r in results if r is not tied[0]]
+
+
 def tune_gemm(M: int, N: int, K: int, a_kmajor: bool, b_kmajor: bool, epi: int = L.EPI_NONE, device="cuda", verbose=False):
     key = (M, N, K, a_kmajor, b_kmajor, epi)
     if key in _done:
@@ -97,14 +109,7 @@ def tune_gemm(M: int, N: int, K: int, a_kmajor: bool, b_kmajor: bool, epi: int =
             variant, bn, splits = c
             L.check(lib.obte_gemm_plan_set(int(a_kmajor), int(b_kmajor), epi, M, N, K, variant, bn, splits), "obte_gemm_plan_set")
             best[c] = min(best[c], _time_once(a, b, M, N, K, a_kmajor, b_kmajor, epi, aux, out, reps=3, rope=rope))
-    results = sorted((t, c[0], c[1], c[2]) for c, t in best.items())
-    # candidates within 3 % of the fastest are a tie at this protocol's resolution (cold operands, three repetitions): take the
-    # structure with the deeper ring first — inside the step, with warm operands and neighbours, it is the one that holds its
-    # time (the row-compact readout input gradient: 160-195 us on the half-tile ring against 190-215 us when the K-tile ring won the coin toss)
-    prefer = {3: 0, 2: 1, 4: 2, 1: 3}
-    tied = [r for r in results if r[0] <= results[0][0] * 1.03]
-    tied.sort(key=lambda r: (prefer.get(r[1], 9), r[0]))
-    results = tied[:1] + [r for r in results if r is not tied[0]]
+    results = rank_candidates(best)
     t, variant, bn, splits = results[0]
     L.check(lib.obte_gemm_plan_set(int(a_kmajor), int(b_kmajor), epi, M, N, K, variant, bn, splits), "obte_gemm_plan_set")
     _done[key] = (variant, bn, splits, t)

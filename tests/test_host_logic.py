@@ -237,3 +237,20 @@ def test_grad_policy_is_captured_per_graph_not_per_process():
     with M.embedding_order(box_order):
         assert M._embedding_order.get()[0] is box_order
     assert M._embedding_order.get() is None
+
+
+def test_tuner_ranking_breaks_ties_towards_the_deeper_ring_and_lists_the_masked_readout_shapes():
+    """tune.rank_candidates: candidates within 3 % of the fastest are a tie, taken in the order half-tile ring (3), K-tile
+    ring (2), two-workgroups-per-CU ring (4), first structure (1); outside the band the fastest wins.  tune.model_gemm_shapes
+    lists the three products of the masked-positions readout (about 15 % of the rows) beside the block's shapes."""
+    from omnibiote_amd import tune
+    r = tune.rank_candidates({(2, 256, 12): 0.2174, (3, 256, 12): 0.2196, (2, 128, 8): 0.2500, (1, 128, 1): 0.9})
+    assert r[0][1:] == (3, 256, 12) and [x[1:] for x in r[1:]] == [(2, 256, 12), (2, 128, 8), (1, 128, 1)]
+    r = tune.rank_candidates({(2, 256, 1): 0.100, (3, 256, 1): 0.104, (4, 128, 1): 0.1005})
+    assert r[0][1:] == (2, 256, 1)                       # 4 % slower is not a tie; among the tied, 2 goes before 4
+    r = tune.rank_candidates({(3, 256, 2): 0.1029, (3, 256, 4): 0.1021, (1, 128, 1): 0.1000})
+    assert r[0][1:] == (3, 256, 4)                       # the faster of the preferred structure's own candidates
+    shapes = tune.model_gemm_shapes(8192, 1024, 65536)
+    mm = [s for s in shapes if 1232 in s[:3]]
+    assert sorted((s[0], s[1], s[2], s[3], s[4]) for s in mm) == sorted([(1232, 1024, 65536, True, False), (65536, 1024, 1232, False, False),
+                                                                        (1232, 65536, 1024, True, True)])
