@@ -69,6 +69,9 @@ def parse():
     p.add_argument("--no_variants", action="store_true", help="skip the extra measurements (masked-rows readout, dropout 0.1, dense-mask calling convention)")
     p.add_argument("--pipeline_streams", type=int, default=2, choices=[1, 2],
                    help="2: forward of micro-batch j+1 beside the backward of micro-batch j on a second HIP stream (bitwise the same results)")
+    p.add_argument("--backward_order", default="layer", choices=["layer", "pass"],
+                   help="two streams: order the backward passes per parameter group (the next backward follows one layer behind) or per pass; "
+                        "bitwise the same results")
     p.add_argument("--micro_batches_per_pass", type=int, default=1,
                    help="k > 1: k micro-batches per forward/backward pass (k * mini_batch_size rows per launch), the loss keeping the "
                         "per-micro-batch normalisation; an execution option, 1 in the headline")
@@ -377,7 +380,7 @@ def main():
     total_iters = 1000
     opt, sched = TE.build_optimizer(m, h, total_iters)
     step = TE.TrainStep(model, opt, sched, mini_batch_size=a.mini_batch_size, n_head=cfg["n_head"],
-                        lm_head_impl=a.readout, pipeline_streams=a.pipeline_streams, micro_batches_per_pass=a.micro_batches_per_pass,
+                        lm_head_impl=a.readout, pipeline_streams=a.pipeline_streams, micro_batches_per_pass=a.micro_batches_per_pass, backward_order=a.backward_order,
                         mask_impl="dense" if a.dense_mask else "ranges")
     rng = np.random.default_rng(1234 + rank)
     T = cfg["ctx_len"]

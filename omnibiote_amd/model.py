@@ -131,14 +131,41 @@ class LnPartialStore:
         return buf
 
 
+class BackwardOrder:
+    """Cross-stream ordering of the backward passes of consecutive micro-batches, PER PARAMETER GROUP instead of per pass.
+    Backward passes that run on different HIP streams read-modify-write the same gradient buffers (in-place accumulation, the
+    LayerNorm partial sums); what has to be ordered is each buffer's own sequence of updates, not the passes as wholes.  Every
+    autograd node that owns parameters waits — on the stream it runs on — for the event the SAME node of the previous
+    micro-batch recorded (``wait``), does its work, and records its own (``done``).  The backward of micro-batch j+1 can then
+    follow that of micro-batch j one layer behind instead of starting after its last kernel; every buffer still sees the
+    updates in micro-batch order, so results are bitwise those of one stream.  ``prev_events``: the ``events`` of the previous
+    micro-batch's object (complete on the host by the time this pass's backward is issued: the harness issues backward passes
+    in order); ``fallback``: an event that covers the whole previous backward, for a node the previous pass did not run."""
+    __slots__ = ("prev_events", "fallback", "events")
+
+    def __init__(self, prev_events=None, fallback=None):
+        self.prev_events, self.fallback, self.events = prev_events, fallback, {}
+
+    def wait(self, key):
+        ev = None if self.prev_events is None else self.prev_events.get(key)
+        if ev is None:
+            ev = self.fallback
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def done(self, key):
+        self.events[key] = torch.cuda.current_stream().record_event()
+
+
 class GradPolicy:
     """Immutable snapshot of the switches above; what an autograd node keeps in ``ctx.pol``."""
-    __slots__ = ("accumulate", "ln_mode", "store")
+    __slots__ = ("accumulate", "ln_mode", "store", "order")
 
-    def __init__(self, accumulate: bool = False, ln_mode: int = 0, store: Optional[LnPartialStore] = None):
+    def __init__(self, accumulate: bool = False, ln_mode: int = 0, store: Optional[LnPartialStore] = None, order: Optional[BackwardOrder] = None):
         object.__setattr__(self, "accumulate", bool(accumulate))
         object.__setattr__(self, "ln_mode", int(ln_mode))
         object.__setattr__(self, "store", store)
+        object.__setattr__(self, "order", order)
 
     def __setattr__(self, *a):
         raise AttributeError("GradPolicy is immutable: enter accumulate_grads_inplace(...) for different switches")
@@ -159,8 +186,8 @@ class accumulate_grads_inplace:
     """``with accumulate_grads_inplace(enabled, ln_partial_mode, store=...)``: graphs BUILT inside deliver their gradients
     that way when they run backward (inside the block or later, on whatever thread)."""
 
-    def __init__(self, enabled: bool = True, ln_partial_mode: int = 0, store: Optional[LnPartialStore] = None):
-        self.pol = GradPolicy(enabled, ln_partial_mode, store if store is not None else _default_store)
+    def __init__(self, enabled: bool = True, ln_partial_mode: int = 0, store: Optional[LnPartialStore] = None, order: Optional[BackwardOrder] = None):
+        self.pol = GradPolicy(enabled, ln_partial_mode, store if store is not None else _default_store, order)
 
     def __enter__(self):
         self.token = _policy.set(self.pol)
@@ -205,6 +232,16 @@ def _grad_slot(param, pol: Optional[GradPolicy] = None):
     return g
 
 
+def _ord_wait(pol: Optional[GradPolicy], key) -> None:
+    if pol is not None and pol.order is not None:
+        pol.order.wait(key)
+
+
+def _ord_done(pol: Optional[GradPolicy], key) -> None:
+    if pol is not None and pol.order is not None:
+        pol.order.done(key)
+
+
 # ------------------------------------------------------------------------------------------------- autograd glue
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
@@ -219,11 +256,13 @@ class _LayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, mean, rstd = ctx.saved_tensors
         pol = ctx.pol
+        _ord_wait(pol, id(ctx.w_param))
         if pol.ln_mode:
             dx, dw = ops.layernorm_bwd(dy.contiguous(), x.contiguous(), w, mean, rstd, partials=_ln_partials(ctx.w_param, pol),
                                        partial_mode=pol.ln_mode)
-            return dx, dw
-        dx, dw = ops.layernorm_bwd(dy.contiguous(), x.contiguous(), w, mean, rstd, accumulate_into=_grad_slot(ctx.w_param, pol))
+        else:
+            dx, dw = ops.layernorm_bwd(dy.contiguous(), x.contiguous(), w, mean, rstd, accumulate_into=_grad_slot(ctx.w_param, pol))
+        _ord_done(pol, id(ctx.w_param))
         return dx, dw
 
 
@@ -246,8 +285,10 @@ class _LinearFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         dx = dw = None
+        _ord_wait(ctx.pol, id(ctx.w_param))
         if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             dx, dw = ops.linear_bwd(dy2, x2, w, alpha=ctx.alpha, accumulate_into=_grad_slot(ctx.w_param, ctx.pol))
+            _ord_done(ctx.pol, id(ctx.w_param))
             return dx.view_as(x), dw, None
         if ctx.needs_input_grad[0]:
             dx = ops.linear_dgrad(dy2, w, alpha=ctx.alpha).view_as(x)
@@ -256,6 +297,7 @@ class _LinearFn(torch.autograd.Function):
             dw = ops.linear_wgrad(dy2, x2, alpha=ctx.alpha, accumulate_into=slot)
             if slot is not None:
                 dw = None
+        _ord_done(ctx.pol, id(ctx.w_param))
         return dx, dw, None
 
 
@@ -277,7 +319,9 @@ class _LinearGeluFn(torch.autograd.Function):
         x, w, der = ctx.saved_tensors
         dh = dact.reshape(-1, dact.shape[-1]) * der            # bf16(dact * gelu'(h)), as OBTE_EPI_GELU_BWD forms it
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        _ord_wait(ctx.pol, id(ctx.w_param))
         dx, dw = ops.linear_bwd(dh.contiguous(), x2, w, accumulate_into=_grad_slot(ctx.w_param, ctx.pol))
+        _ord_done(ctx.pol, id(ctx.w_param))
         return dx.view_as(x), dw
 
 
@@ -300,8 +344,10 @@ class _ReadoutRowsGradFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         emb_rows, w, dl = ctx.saved_tensors
+        _ord_wait(ctx.pol, id(ctx.w_param))
         slot = _grad_slot(ctx.w_param, ctx.pol)
         dx, dw = ops.linear_bwd(dl, emb_rows.contiguous(), w, alpha=ctx.alpha, accumulate_into=slot)
+        _ord_done(ctx.pol, id(ctx.w_param))
         return dx, dw, None, None
 
 
@@ -319,8 +365,11 @@ class _EmbeddingFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
-        return None, ops.embedding_bwd(idx.contiguous(), dout.contiguous(), ctx.vocab, accumulate_into=_grad_slot(ctx.w_param, ctx.pol),
-                                       dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1], order=ctx.order), None, None, None
+        _ord_wait(ctx.pol, id(ctx.w_param))
+        dw = ops.embedding_bwd(idx.contiguous(), dout.contiguous(), ctx.vocab, accumulate_into=_grad_slot(ctx.w_param, ctx.pol),
+                               dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1], order=ctx.order)
+        _ord_done(ctx.pol, id(ctx.w_param))
+        return None, dw, None, None, None
 
 
 class _BlockFn(torch.autograd.Function):
@@ -342,11 +391,13 @@ class _BlockFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, act, rope_cos, rope_sin, *params = ctx.saved_tensors
         pol = ctx.pol
+        _ord_wait(pol, id(ctx.w_params[0]))   # one group per block: its six weights are updated by this one call
         slots = [_grad_slot(w, pol) for w in ctx.w_params]
         lnp = (_ln_partials(ctx.w_params[0], pol), _ln_partials(ctx.w_params[3], pol)) if pol.ln_mode else None
         dx, grads = ops.block_bwd(x, dy.contiguous(), act, tuple(params), (rope_cos, rope_sin), ctx.n_head, ctx.mask,
                                   accumulate_into=slots, dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1], ln_partials=lnp,
                                   ln_partial_mode=pol.ln_mode)
+        _ord_done(pol, id(ctx.w_params[0]))
         return (dx, *grads, None, None, None, None, None, None)
 
 

@@ -168,7 +168,7 @@ class TrainStep:
     def __init__(self, model, optimizer, scheduler=None, *, mini_batch_size: int, n_head: int, use_padding: bool = False,
                  loss_impl: str = "fused", mask_impl: str = "ranges", sync_every_micro_step: bool = False,
                  max_grad_norm: float = 1.0, lm_head_impl: str = "masked", pipeline_streams: int = 1,
-                 fused_loss_fn: Optional[Callable] = None, micro_batches_per_pass: int = 1):
+                 fused_loss_fn: Optional[Callable] = None, micro_batches_per_pass: int = 1, backward_order: str = "layer"):
         """fused_loss_fn: ``(logits, targets, mlm_mask, n_accum) -> (loss, dlogits)`` used by loss_impl="fused" instead of
         the HIP kernel (ops.masked_ce) — lets the CPU multi-process tests drive the product scheduling (in-place
         accumulation, no_sync, hand-delivered d(logits)) with a stub model and a torch loss."""
@@ -204,6 +204,15 @@ class TrainStep:
         # the same read-modify-write sequence as on one stream: results are bitwise those of pipeline_streams = 1.
         assert pipeline_streams in (1, 2)
         self.pipeline_streams = pipeline_streams
+        # backward_order (pipeline_streams = 2): "pass" — the backward of micro-batch j+1 starts after the LAST kernel of micro-batch
+        # j's backward (one event per pass); "layer" (default) — every parameter group's update waits for the same group's update
+        # of the previous micro-batch only (model.BackwardOrder: one event per block / LayerNorm / embedding / readout), so the
+        # next backward follows one layer behind and both streams stay busy.  Each gradient buffer sees the same sequence of
+        # read-modify-writes either way: bitwise the same results (tested against pipeline_streams = 1).
+        assert backward_order in ("layer", "pass")
+        self.backward_order = backward_order
+        self._order = None           # the BackwardOrder of the pass being built
+        self._prev_order_events = None
         self._streams = None
         self._slot = 0
         self._prev_bwd_done = None
@@ -218,7 +227,7 @@ class TrainStep:
             ln_partial_mode = 0
         if self._ln_store is None:
             self._ln_store = LnPartialStore()     # this step object's own fp32 LayerNorm partial sums
-        return accumulate_grads_inplace(enabled, ln_partial_mode, store=self._ln_store)
+        return accumulate_grads_inplace(enabled, ln_partial_mode, store=self._ln_store, order=self._order)
 
     def _mask(self, tokens: torch.Tensor, dtype, j: int = -1, k: int = 1):
         from . import masks
@@ -253,6 +262,8 @@ class TrainStep:
 
     def _order_backward(self):
         """Pipelined micro-batches: this backward may start only after the previous micro-batch's backward finished."""
+        if self._order is not None:   # per-group events instead (model.BackwardOrder); _prev_bwd_done is its fallback
+            return
         if self._prev_bwd_done is not None:
             torch.cuda.current_stream().wait_event(self._prev_bwd_done)
 
@@ -415,6 +426,7 @@ class TrainStep:
                 st.wait_stream(main)
         partial = [cum_loss, torch.zeros_like(cum_loss)] if pipelined else [cum_loss]
         self._prev_bwd_done = None
+        self._prev_order_events = None
         for j in range(n_pass):
             self._mb = j
             x = masked_ids[j * span:(j + 1) * span]
@@ -426,6 +438,10 @@ class TrainStep:
                     main.wait_stream(st)
                 self._prev_bwd_done = None
             self._slot = (j % 2) if side else 0
+            self._order = None
+            if side and self.backward_order == "layer" and self.fused_loss_fn is None:
+                from .model import BackwardOrder
+                self._order = BackwardOrder(self._prev_order_events, self._prev_bwd_done)
             with (torch.cuda.stream(self._streams[j % 2]) if side else contextlib.nullcontext()):
                 attn_mask = self._mask(y, dtype, j, k)
                 ctx = contextlib.nullcontext()
@@ -455,6 +471,7 @@ class TrainStep:
                         del logits
                 if side:
                     self._prev_bwd_done = torch.cuda.current_stream().record_event()
+                    self._prev_order_events = self._order.events if self._order is not None else None
         if pipelined:
             cum_loss = partial[0] + partial[1]
         if isinstance(self.optimizer, FusedAdamW):

@@ -328,10 +328,12 @@ def test_readout_paths_match_the_oracle_loss_and_gradients():
             assert rel <= 0.05 and cos >= 0.998, (impl, k, rel, cos)
 
 
+@pytest.mark.parametrize("order", ["layer", "pass"])
 @pytest.mark.parametrize("impl", ["dense", "dense_full", "masked"])
-def test_two_stream_micro_batch_pipeline_is_bitwise_the_single_stream_step(impl):
+def test_two_stream_micro_batch_pipeline_is_bitwise_the_single_stream_step(impl, order):
     """TrainStep(pipeline_streams=2) overlaps the forward of micro-batch j+1 with the backward of micro-batch j on a
-    second stream but keeps the backward passes ordered: loss, gradients and updated weights must equal the
+    second stream and keeps every gradient buffer's updates in micro-batch order — per parameter group (backward_order="layer":
+    the next backward follows one layer behind) or per pass: loss, gradients and updated weights must equal the
     single-stream step bit for bit (any race on a gradient or scratch buffer would show here)."""
     from omnibiote_amd import train_encoder as TE
     from omnibiote_amd.mup_compat import set_base_shapes
@@ -355,7 +357,7 @@ def test_two_stream_micro_batch_pipeline_is_bitwise_the_single_stream_step(impl)
             m.to(BF)
         m.to(DEV)
         opt = TE.FusedAdamW(m.parameters(), lr=1e-3)
-        step = TE.TrainStep(m, opt, None, mini_batch_size=mini, n_head=H, lm_head_impl=impl, pipeline_streams=streams)
+        step = TE.TrainStep(m, opt, None, mini_batch_size=mini, n_head=H, lm_head_impl=impl, pipeline_streams=streams, backward_order=order)
         losses = []
         for it in range(3):
             np.random.seed(7 + it)
