@@ -67,7 +67,7 @@ def parse():
     p.add_argument("--dense_mask", action="store_true",
                    help="pass the reference's dense additive (B,H,T,T) mask (expand view) instead of key ranges")
     p.add_argument("--no_variants", action="store_true", help="skip the extra measurements (masked-rows readout, dropout 0.1, dense-mask calling convention)")
-    p.add_argument("--pipeline_streams", type=int, default=2, choices=[1, 2],
+    p.add_argument("--pipeline_streams", type=int, default=2, choices=[1, 2, 3],
                    help="2: forward of micro-batch j+1 beside the backward of micro-batch j on a second HIP stream (bitwise the same results)")
     p.add_argument("--backward_order", default="layer", choices=["layer", "pass"],
                    help="two streams: order the backward passes per parameter group (the next backward follows one layer behind) or per pass; "

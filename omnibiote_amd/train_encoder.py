@@ -202,7 +202,7 @@ class TrainStep:
         # runs beside the backward of micro-batch j (kernel tails and half-filled grids of one fill with work of the
         # other).  The backward passes stay strictly ordered (an event per micro-batch), so every gradient buffer sees
         # the same read-modify-write sequence as on one stream: results are bitwise those of pipeline_streams = 1.
-        assert pipeline_streams in (1, 2)
+        assert pipeline_streams in (1, 2, 3)
         self.pipeline_streams = pipeline_streams
         # backward_order (pipeline_streams = 2): "pass" — the backward of micro-batch j+1 starts after the LAST kernel of micro-batch
         # j's backward (one event per pass); "layer" (default) — every parameter group's update waits for the same group's update
@@ -412,19 +412,20 @@ class TrainStep:
         cum_loss = torch.zeros((), dtype=torch.float32, device=input_ids.device)
         from . import masks
         self._all_ranges = masks.RangeMask.from_tokens(input_ids, padding=self.use_padding, group=self.mini).key_ranges
-        pipelined = (self.pipeline_streams == 2 and input_ids.is_cuda and self.loss_impl == "fused" and n_pass > 2
+        pipelined = (self.pipeline_streams >= 2 and input_ids.is_cuda and self.loss_impl == "fused" and n_pass > 2
                      and not self.sync_every)
         main = torch.cuda.current_stream() if input_ids.is_cuda else None
         if pipelined:
-            if self._streams is None:
-                self._streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            if self._streams is None or len(self._streams) != self.pipeline_streams:
+                self._streams = [torch.cuda.Stream() for _ in range(self.pipeline_streams)]
                 # gradients are produced on the side streams by design; the engine's cross-stream sync is what we want
                 warn_off = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
                 if warn_off is not None:
                     warn_off(False)
             for st in self._streams:
                 st.wait_stream(main)
-        partial = [cum_loss, torch.zeros_like(cum_loss)] if pipelined else [cum_loss]
+        ns = self.pipeline_streams if pipelined else 1
+        partial = [cum_loss] + [torch.zeros_like(cum_loss) for _ in range(ns - 1)]
         self._prev_bwd_done = None
         self._prev_order_events = None
         for j in range(n_pass):
@@ -437,12 +438,12 @@ class TrainStep:
                 for st in self._streams:
                     main.wait_stream(st)
                 self._prev_bwd_done = None
-            self._slot = (j % 2) if side else 0
+            self._slot = (j % ns) if side else 0
             self._order = None
             if side and self.backward_order == "layer" and self.fused_loss_fn is None:
                 from .model import BackwardOrder
                 self._order = BackwardOrder(self._prev_order_events, self._prev_bwd_done)
-            with (torch.cuda.stream(self._streams[j % 2]) if side else contextlib.nullcontext()):
+            with (torch.cuda.stream(self._streams[j % ns]) if side else contextlib.nullcontext()):
                 attn_mask = self._mask(y, dtype, j, k)
                 ctx = contextlib.nullcontext()
                 if hasattr(self.model, "no_sync") and not last and not self.sync_every:
@@ -474,6 +475,8 @@ class TrainStep:
                     self._prev_order_events = self._order.events if self._order is not None else None
         if pipelined:
             cum_loss = partial[0] + partial[1]
+            for extra in partial[2:]:
+                cum_loss = cum_loss + extra
         if isinstance(self.optimizer, FusedAdamW):
             self.optimizer.step(max_norm=self.max_grad_norm)
         else:
@@ -597,7 +600,7 @@ def parse_args(argv=None):
     # additions
     p.add_argument("--max_steps", type=int, default=0, help="stop after this many optimizer steps (0 = token budget)")
     p.add_argument("--multi_document", action="store_true", default=False, help="synthetic rows with interior EOS")
-    p.add_argument("--pipeline_streams", type=int, default=2, choices=[1, 2],
+    p.add_argument("--pipeline_streams", type=int, default=2, choices=[1, 2, 3],
                    help="2: overlap the forward of micro-batch j+1 with the backward of micro-batch j (same results)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="torch.distributed backend: nccl (= RCCL over xGMI, the production path) or gloo (plumbing runs: "

@@ -342,7 +342,7 @@ def test_two_stream_micro_batch_pipeline_is_bitwise_the_single_stream_step(impl,
     w = R.hash_weights(R.RefConfig(block_size=T, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C))
     ids = torch.from_numpy(TE.synthetic_rows(rows, T, V, np.random.default_rng(0), single_document=False)).to(DEV)
     out = {}
-    for streams in (1, 2):
+    for streams in (1, 2, 3):
         c = OmniBioTAConfig(); c.block_size, c.vocab_size, c.n_layer, c.n_head, c.n_embd, c.dropout, c.flash = T, V, Lyr, H, C, 0.0, True
         m = OmniBioTA(c)
         cb = OmniBioTAConfig(); cb.block_size, cb.vocab_size, cb.n_layer, cb.dropout, cb.flash = T, V, Lyr, 0.0, True
@@ -365,11 +365,12 @@ def test_two_stream_micro_batch_pipeline_is_bitwise_the_single_stream_step(impl,
         torch.cuda.synchronize()
         out[streams] = (losses, {k: p.detach().clone() for k, p in m.named_parameters()},
                         {k: p.grad.clone() for k, p in m.named_parameters()})
-    for a, b in zip(out[1][0], out[2][0]):   # the reported loss is summed per stream first: equal up to fp32 rounding
-        assert abs(a - b) <= 1e-5 * abs(a), (out[1][0], out[2][0])
-    for k in out[1][1]:
-        assert torch.equal(out[1][2][k], out[2][2][k]), "grad " + k
-        assert torch.equal(out[1][1][k], out[2][1][k]), "weight " + k
+    for n in (2, 3):
+        for a, b in zip(out[1][0], out[n][0]):   # the reported loss is summed per stream first: equal up to fp32 rounding
+            assert abs(a - b) <= 1e-5 * abs(a), (n, out[1][0], out[n][0])
+        for k in out[1][1]:
+            assert torch.equal(out[1][2][k], out[n][2][k]), f"{n} streams: grad " + k
+            assert torch.equal(out[1][1][k], out[n][1][k]), f"{n} streams: weight " + k
 
 
 def test_ddp_wrapped_pipelined_step_equals_plain_single_stream_step():
