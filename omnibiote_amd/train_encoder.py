@@ -433,8 +433,11 @@ class TrainStep:
             x = masked_ids[j * span:(j + 1) * span]
             y = input_ids[j * span:(j + 1) * span]
             last = j == n_pass - 1
-            side = pipelined and not last
-            if pipelined and last:   # the last pass (DDP's reducer hooks) runs on the caller's stream, after everything
+            # the last pass of a DDP-wrapped model (the reducer's hooks and bucket all-reduces) runs on the caller's stream, after
+            # everything; without a reducer it is a pass like the others and the caller's stream joins the side streams afterwards
+            isolate_last = last and hasattr(self.model, "no_sync")
+            side = pipelined and not isolate_last
+            if pipelined and isolate_last:
                 for st in self._streams:
                     main.wait_stream(st)
                 self._prev_bwd_done = None
@@ -474,6 +477,8 @@ class TrainStep:
                     self._prev_bwd_done = torch.cuda.current_stream().record_event()
                     self._prev_order_events = self._order.events if self._order is not None else None
         if pipelined:
+            for st in self._streams:   # (a no-op after an isolated last pass: that one already waited for them)
+                main.wait_stream(st)
             cum_loss = partial[0] + partial[1]
             for extra in partial[2:]:
                 cum_loss = cum_loss + extra
