@@ -463,7 +463,8 @@ class TrainStep:
                 ln_mode = 0
                 if n_pass > 2 and not self.sync_every and j >= 1:
                     ln_mode = 1 if j == 1 else (3 if last else 2)
-                with ctx, ctx_order, self._inplace(not last and not self.sync_every, ln_mode):
+                # (the last pass too when no reducer is attached: nothing observes its gradients before the optimizer does)
+                with ctx, ctx_order, self._inplace(not (last and hasattr(self.model, "no_sync")) and not self.sync_every, ln_mode):
                     mk = mask[j * span:(j + 1) * span]
                     if sparse_rows and self.lm_head_impl == "masked":
                         partial[self._slot] += self._masked_rows_loss_backward(x, y, mk, attn_mask, n_accum, k)
