@@ -681,6 +681,33 @@ def _tiny_model(w, C, H, Lyr, V, T):
     return m.to(DEV)
 
 
+def test_pipelined_step_with_dropout_is_bitwise_the_single_stream_step():
+    """Dropout 0.1 at all four sites (counter-based masks, seeds drawn on the host in issue order) under the two-stream
+    pipeline with per-group backward ordering: the masks cannot depend on which stream a micro-batch ran on, so losses,
+    gradients and weights equal the single-stream step's bit for bit."""
+    from omnibiote_amd import train_encoder as TE
+    C, H, Lyr, V, T, rows, mini = 256, 2, 2, 1024, 128, 24, 4     # 6 micro-batches
+    w = R.hash_weights(R.RefConfig(block_size=T, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C))
+    ids = torch.from_numpy(TE.synthetic_rows(rows, T, V, np.random.default_rng(0), single_document=False)).to(DEV)
+    out = {}
+    for streams in (1, 2):
+        m = _tiny_model(w, C, H, Lyr, V, T)
+        TE.set_dropout(m, 0.1)
+        step = TE.TrainStep(m, TE.FusedAdamW(m.parameters(), lr=1e-3), None, mini_batch_size=mini, n_head=H, pipeline_streams=streams)
+        torch.manual_seed(99)
+        losses = []
+        for it in range(2):
+            np.random.seed(11 + it)
+            losses.append(step(ids)["loss"].item())
+        torch.cuda.synchronize()
+        out[streams] = (losses, {k: p.detach().clone() for k, p in m.named_parameters()}, {k: p.grad.clone() for k, p in m.named_parameters()})
+    for a, b in zip(out[1][0], out[2][0]):
+        assert abs(a - b) <= 1e-5 * abs(a), (out[1][0], out[2][0])
+    for k in out[1][1]:
+        assert torch.equal(out[1][2][k], out[2][2][k]), "grad " + k
+        assert torch.equal(out[1][1][k], out[2][1][k]), "weight " + k
+
+
 def test_two_train_steps_on_two_models_in_two_threads_share_no_state():
     """The backward switches (in-place accumulation, fp32 LayerNorm partials, the embedding sort order) belong to the
     TrainStep that built the graph: each autograd node captures them at forward time (model.GradPolicy on ctx), the fp32
