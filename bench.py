@@ -37,7 +37,8 @@ METRIC = "MLM train tokens/sec, small (8L/1024d) ctx=1024 at 1/2/4/8 MI355X"
 READOUT_TEXT = {"dense": "full 65536-way logits for every position in the forward, readout backward over the MLM-masked rows (the other rows of d(logits) are exact zeros)",
                 "dense_full": "full 65536-way logits and dense d(logits)",
                 "masked": "65536-way readout + CE on the MLM-masked positions only (SURVEY §8f rank 1: the loss multiplies every other position by zero, "
-                          "train_encoder.py:304 — same loss, same gradients)"}
+                          "train_encoder.py:304 — same loss, same gradients); the positions are handed to model.forward(rows=...), so the last block's MLP half "
+                          "and ln_f run on them alone as well"}
 CONFIGS = {
     "small": dict(n_layer=8, n_embd=1024, n_head=8, ctx_len=1024),
     "small4k": dict(n_layer=8, n_embd=1024, n_head=8, ctx_len=4096),
@@ -69,6 +70,9 @@ def parse():
     p.add_argument("--no_variants", action="store_true", help="skip the extra measurements (masked-rows readout, dropout 0.1, dense-mask calling convention)")
     p.add_argument("--pipeline_streams", type=int, default=2, choices=[1, 2, 3],
                    help="2: forward of micro-batch j+1 beside the backward of micro-batch j on a second HIP stream (bitwise the same results)")
+    p.add_argument("--full_last_block", action="store_true",
+                   help="readout masked: run the last block's MLP half and ln_f on every position (model.forward(return_embeddings=True), rows "
+                        "gathered afterwards) instead of handing the masked positions to model.forward(rows=...)")
     p.add_argument("--backward_order", default="layer", choices=["layer", "pass"],
                    help="two streams: order the backward passes per parameter group (the next backward follows one layer behind) or per pass; "
                         "bitwise the same results")
@@ -380,7 +384,7 @@ def main():
     total_iters = 1000
     opt, sched = TE.build_optimizer(m, h, total_iters)
     step = TE.TrainStep(model, opt, sched, mini_batch_size=a.mini_batch_size, n_head=cfg["n_head"],
-                        lm_head_impl=a.readout, pipeline_streams=a.pipeline_streams, micro_batches_per_pass=a.micro_batches_per_pass, backward_order=a.backward_order,
+                        lm_head_impl=a.readout, pipeline_streams=a.pipeline_streams, micro_batches_per_pass=a.micro_batches_per_pass, backward_order=a.backward_order, rows_forward=not a.full_last_block,
                         mask_impl="dense" if a.dense_mask else "ranges")
     rng = np.random.default_rng(1234 + rank)
     T = cfg["ctx_len"]
@@ -419,6 +423,8 @@ def main():
     value = tokens_per_step * a.steps / elapsed
     fpt = TE.flops_per_token(n_params, cfg["n_layer"], cfg["n_embd"], T)
     skipped = {"dense": 4.0 * cfg["n_embd"] * 65536 * 0.85, "dense_full": 0.0, "masked": 6.0 * cfg["n_embd"] * 65536 * 0.85}[a.readout]
+    if a.readout == "masked" and not a.full_last_block and a.dropout == 0.0:   # the last block's MLP half (8 C^2 parameters: 6 FLOP each per token) on the masked positions only
+        skipped += 6.0 * 8.0 * cfg["n_embd"] ** 2 * 0.85
     fpt_exec = fpt - skipped   # 15 % of the positions are MLM-masked (train_encoder.py:271); their share of the readout products remains
 
     log(f"timed region done: {value:,.0f} tokens/s")
@@ -499,6 +505,13 @@ def main():
             variants["masked_rows_readout"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
                                                "note": "readout + CE on the MLM-masked rows only, forward included; identical loss and gradients"}
             _step.lm_head_impl = a.readout
+        if a.readout == "masked" and _step.rows_forward:
+            _step.rows_forward = False
+            variants["masked_readout_full_last_block"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
+                                                          "note": "the masked-positions readout on model.forward(return_embeddings=True) of every position: the last "
+                                                                  "block's MLP half and ln_f computed for all positions, rows gathered afterwards (the headline hands "
+                                                                  "the positions to model.forward(rows=...)); identical loss and gradients"}
+            _step.rows_forward = True
         if a.readout != "dense":
             _step.lm_head_impl = "dense"
             variants["dense_logits_forward"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,

@@ -51,7 +51,7 @@ class BlockDesc(C.Structure):
                 ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
                 ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("query_bounds", C.c_void_p),
                 ("ln1_partials", C.c_void_p), ("ln2_partials", C.c_void_p), ("ln_partial_mode", C.c_int32),
-                ("ranges_exact", C.c_void_p)]
+                ("ranges_exact", C.c_void_p), ("out_rows", C.c_void_p), ("n_out_rows", C.c_int64)]
 
 
 LN_PARTIAL_FIRST, LN_PARTIAL_MORE, LN_PARTIAL_LAST = 1, 2, 3
@@ -102,6 +102,8 @@ SYMBOLS = {
     "obte_embedding_bwd_acc": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int64, C.c_int, c_stream]),
     "obte_masked_ce_fwd_bwd": (C.c_int, [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int64, C.c_int64, c_stream]),
     "obte_masked_ce_fwd_bwd_reuse": (C.c_int, [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 2 + [C.c_int64, C.c_int64, c_stream]),
+    "obte_rows_gather_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int64, C.c_int32, c_stream]),
+    "obte_rows_scatter_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int64, C.c_int32, c_stream]),
     "obte_masked_ce_rows": (C.c_int, [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 3 + [C.c_int64, C.c_int64, C.c_int64, c_stream]),
     "obte_adamw_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int64] + [C.c_float] * 5 + [C.c_int32, C.c_void_p, c_stream]),
     "obte_sumsq_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, c_stream]),

@@ -11,7 +11,7 @@ namespace {
 inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 struct ActLayout {
-    int64_t mean1, rstd1, h1, qkv, lse, y, x1, mean2, rstd2, h2, hpre, hact, total;
+    int64_t mean1, rstd1, h1, qkv, lse, y, x1, mean2, rstd2, h2, hpre, hact, x1r, total;
     ActLayout(int64_t B, int64_t T, int C, int H) {
         const int64_t M = B * T;
         int64_t o = 0;
@@ -26,6 +26,7 @@ struct ActLayout {
         h2 = take(M * C * 2);
         hpre = take(M * 4 * C * 2);
         hact = take(M * 4 * C * 2);
+        x1r = take(M * C * 2);      // rows form (obte_block_desc::out_rows): x1 at the wanted positions
         total = o;
     }
 };
@@ -95,6 +96,8 @@ int check_desc(const char* who, const obte_block_desc* d) {
     OBTE_REQUIRE(d->ln1_w && d->attn_w && d->proj_w && d->ln2_w && d->fc_w && d->mlp_w && d->rope_cos && d->rope_sin,
                  "%s: null parameter", who);
     OBTE_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "%s: dropout p must be in [0,1)", who);
+    OBTE_REQUIRE((d->out_rows == nullptr) == (d->n_out_rows == 0) && d->n_out_rows >= 0 && d->n_out_rows <= d->B * d->T, "%s: out_rows / n_out_rows inconsistent", who);
+    OBTE_REQUIRE(!(d->out_rows && d->dropout_p > 0.f), "%s: the rows form (out_rows) is for dropout 0 (its masks are defined on whole activations)", who);
     return OBTE_OK;
 }
 
@@ -138,9 +141,26 @@ extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte
     af.ranges_exact = d->ranges_exact;
     TRY(obte_attn_fwd(&af, s));
     TRY(gemm(yat, d->proj_w, x1, M, C, C, C, C, 1, 1, OBTE_EPI_ADD, x, nullptr, s, nullptr, 0, d->dropout_p, d->dropout_seed, SITE_RESID));
-    TRY(obte_layernorm_fwd(x1, d->ln2_w, h2, mean2, rstd2, M, C, 1e-5f, s));
-    TRY(gemm(h2, d->fc_w, hpre, M, 4 * C, C, C, C, 1, 1, OBTE_EPI_GELU, nullptr, hact, s));
-    TRY(gemm(hact, d->mlp_w, y_out, M, C, 4 * C, 4 * C, 4 * C, 1, 1, OBTE_EPI_ADD, x1, nullptr, s, nullptr, 0, d->dropout_p, d->dropout_seed, SITE_MLP));
+    // the MLP half: on every position, or (rows form) on the n wanted positions only — per-position arithmetic, same results there
+    int64_t Mm = M;
+    const obte_bf16* x1m = x1;
+    if (d->out_rows) {
+        obte_bf16* x1r = (obte_bf16*)(A + L.x1r);
+        TRY(obte_rows_gather_bf16(x1, d->out_rows, x1r, d->n_out_rows, M, C, s));
+        Mm = d->n_out_rows; x1m = x1r;
+    }
+    TRY(obte_layernorm_fwd(x1m, d->ln2_w, h2, mean2, rstd2, Mm, C, 1e-5f, s));
+    TRY(gemm(h2, d->fc_w, hpre, Mm, 4 * C, C, C, C, 1, 1, OBTE_EPI_GELU, nullptr, hact, s));
+    // rows form: [n, C] over K = 4C is a handful of tiles — split-K, with the unused tail of the (M-row) hpre region as its workspace
+    void* fws = nullptr;
+    int64_t fws_bytes = 0;
+    if (d->out_rows) {
+        const int64_t used = align256(Mm * 4 * C * 2);
+        fws = (void*)(A + L.hpre + used);
+        fws_bytes = M * 4 * C * 2 - used;
+        if (fws_bytes < (int64_t)(2 * Mm * C * 4)) { fws = nullptr; fws_bytes = 0; }
+    }
+    TRY(gemm(hact, d->mlp_w, y_out, Mm, C, 4 * C, 4 * C, 4 * C, 1, 1, OBTE_EPI_ADD, x1m, nullptr, s, fws, fws_bytes, d->dropout_p, d->dropout_seed, SITE_MLP));
     return OBTE_OK;
 }
 
@@ -183,16 +203,22 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     obte_bf16* dym2 = (obte_bf16*)(S + W.dym2);
     const bool drop = d->dropout_p > 0.f;
     const bool grouped = use_grouped_wgrad(C, M);
+    // rows form: the MLP half ran on Mm = n_out_rows positions (dy is [Mm, C]); its two weight gradients contract over those rows
+    // and go out as their own launches, the grouped launch keeps the attention half's
+    const bool rows_form = d->out_rows != nullptr;
+    const int64_t Mm = rows_form ? d->n_out_rows : M;
+    const obte_bf16* x1m = rows_form ? (const obte_bf16*)(A + L.x1r) : x1;
+    const bool grouped_mlp = grouped && !rows_form;
     // MLP: out = x1 + dropout(hact W_mlp^T): the projection sees dy masked by the same (seed, site 3) mask
     const obte_bf16* dy_mlp = dy;
     if (drop) {
         TRY(obte_dropout_bf16(dy, dym, M * C, C, d->dropout_p, d->dropout_seed, SITE_MLP, s));
         dy_mlp = dym;
     }
-    TRY(gemm(dy_mlp, d->mlp_w, dhpre, M, 4 * C, C, C, 4 * C, 1, 0, OBTE_EPI_GELU_BWD, hpre, nullptr, s));      // dhpre = (dy W_mlp) * gelu'(h): hpre holds the derivative
-    if (!grouped) TRY(gemm(dy_mlp, hact, dmlp_w, C, 4 * C, M, C, 4 * C, 0, 0, wepi, accumulate_matrices ? dmlp_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_mlp = dy^T hact
-    TRY(gemm(dhpre, d->fc_w, dh, M, C, 4 * C, 4 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh2 = dhpre W_fc
-    if (!grouped) TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, M, 4 * C, C, 0, 0, wepi, accumulate_matrices ? dfc_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_fc = dhpre^T h2
+    TRY(gemm(dy_mlp, d->mlp_w, dhpre, Mm, 4 * C, C, C, 4 * C, 1, 0, OBTE_EPI_GELU_BWD, hpre, nullptr, s));      // dhpre = (dy W_mlp) * gelu'(h): hpre holds the derivative
+    if (!grouped_mlp) TRY(gemm(dy_mlp, hact, dmlp_w, C, 4 * C, Mm, C, 4 * C, 0, 0, wepi, accumulate_matrices ? dmlp_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_mlp = dy^T hact
+    TRY(gemm(dhpre, d->fc_w, dh, Mm, C, 4 * C, 4 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s, rows_form ? gws : nullptr, rows_form ? W.gemmws_bytes : 0));   // dh2 = dhpre W_fc (rows form: few tiles over K = 4C, split-K)
+    if (!grouped_mlp) TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, Mm, 4 * C, C, 0, 0, wepi, accumulate_matrices ? dfc_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_fc = dhpre^T h2
     const int lnp = d->ln_partial_mode;
     if (lnp) OBTE_REQUIRE(d->ln1_partials && d->ln2_partials && lnp >= OBTE_LN_PARTIAL_FIRST && lnp <= OBTE_LN_PARTIAL_LAST,
                           "obte_block_bwd: ln_partial_mode needs both partial buffers and a valid mode");
@@ -203,6 +229,11 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
         TRY(obte_layernorm_bwd_dropout(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dym2, dln2_w, lnp ? d->ln2_partials : lnws, M, C, lnp, acc_ln,
                                        d->dropout_p, d->dropout_seed, SITE_RESID, s));
         dx1_proj = dym2;
+    } else if (rows_form) {   // d x1 at the wanted rows ([Mm, C], staged in dyattn — free until the projection's input gradient), then scattered into zeros
+        obte_bf16* dx1r = dyattn;
+        if (lnp) TRY(obte_layernorm_bwd_partial(dh, x1m, d->ln2_w, mean2, rstd2, dy, dx1r, dln2_w, d->ln2_partials, Mm, C, lnp, s));
+        else TRY(obte_layernorm_bwd_acc(dh, x1m, d->ln2_w, mean2, rstd2, dy, dx1r, dln2_w, lnws, Mm, C, acc_ln, s));
+        TRY(obte_rows_scatter_bf16(dx1r, d->out_rows, dx1, Mm, M, C, s));
     } else if (lnp) {
         TRY(obte_layernorm_bwd_partial(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, d->ln2_partials, M, C, lnp, s));
     } else {
@@ -233,14 +264,20 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
             gs[i].M = m; gs[i].N = n; gs[i].K = M; gs[i].lda = m; gs[i].ldb = n; gs[i].ldd = n;
             gs[i].a_kmajor = 0; gs[i].b_kmajor = 0; gs[i].epilogue = wepi; gs[i].alpha = 1.0f;
         };
-        put(0, dhpre, h2, dfc_w, 4 * C, C);
-        put(1, dy_mlp, hact, dmlp_w, C, 4 * C);
-        put(2, dqkv, h1, dattn_w, 3 * C, C);
-        put(3, dx1_proj, yat, dproj_w, C, C);
-        gs[4].a = dqkv; gs[4].b = d->attn_w; gs[4].d = dh; gs[4].M = M; gs[4].N = C; gs[4].K = 3 * C;
-        gs[4].lda = 3 * C; gs[4].ldb = C; gs[4].ldd = C; gs[4].a_kmajor = 1; gs[4].b_kmajor = 0;
-        gs[4].epilogue = OBTE_EPI_NONE; gs[4].alpha = 1.0f;
-        TRY(obte_gemm_grouped_bf16(gs, group_dgrad ? 5 : 4, s));
+        int np = 0;
+        if (grouped_mlp) {
+            put(np++, dhpre, h2, dfc_w, 4 * C, C);
+            put(np++, dy_mlp, hact, dmlp_w, C, 4 * C);
+        }
+        put(np++, dqkv, h1, dattn_w, 3 * C, C);
+        put(np++, dx1_proj, yat, dproj_w, C, C);
+        if (group_dgrad) {
+            gs[np].a = dqkv; gs[np].b = d->attn_w; gs[np].d = dh; gs[np].M = M; gs[np].N = C; gs[np].K = 3 * C;
+            gs[np].lda = 3 * C; gs[np].ldb = C; gs[np].ldd = C; gs[np].a_kmajor = 1; gs[np].b_kmajor = 0;
+            gs[np].epilogue = OBTE_EPI_NONE; gs[np].alpha = 1.0f;
+            ++np;
+        }
+        TRY(obte_gemm_grouped_bf16(gs, np, s));
     }
     if (lnp) TRY(obte_layernorm_bwd_partial(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, d->ln1_partials, M, C, lnp, s));
     else TRY(obte_layernorm_bwd_acc(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, lnws, M, C, acc_ln, s));                      // dx = dx1 + LN1'(dh1)

@@ -606,6 +606,37 @@ extern "C" int obte_masked_ce_fwd_bwd_reuse(const obte_bf16* logits, const int64
     return OBTE_OK;
 }
 
+// ---- rows by index (the rows form of the block: csrc/block.cpp) ---------------------------------------------------------
+// one wave per row, 16 B per lane and step; gather: dst[i] = src[rows[i]]; scatter: dst[rows[i]] = src[i]
+namespace {
+__global__ __launch_bounds__(256) void rows_copy_kernel(const bf16* __restrict__ src, const int64_t* __restrict__ rows, bf16* __restrict__ dst,
+                                                         int64_t n_rows, int64_t total_rows, int cols, int scatter) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+    if (i >= n_rows) return;
+    int64_t r = rows[i];
+    r = r < 0 ? 0 : (r >= total_rows ? total_rows - 1 : r);
+    const bf16* s = src + (scatter ? i : r) * cols;
+    bf16* d = dst + (scatter ? r : i) * cols;
+    for (int c = lane * 8; c < cols; c += 64 * 8) *reinterpret_cast<bf16x8*>(d + c) = *reinterpret_cast<const bf16x8*>(s + c);
+}
+}  // namespace
+extern "C" int obte_rows_gather_bf16(const obte_bf16* src, const int64_t* rows, obte_bf16* dst, int64_t n_rows, int64_t total_rows, int32_t cols, obte_stream s) {
+    OBTE_REQUIRE(src && rows && dst, "obte_rows_gather_bf16: null pointer");
+    OBTE_REQUIRE(n_rows > 0 && total_rows > 0 && cols > 0 && cols % 8 == 0, "obte_rows_gather_bf16: need n_rows, total_rows > 0 and cols %% 8 == 0");
+    hipLaunchKernelGGL(rows_copy_kernel, dim3((unsigned)cdiv64(n_rows, 4)), dim3(256), 0, (hipStream_t)s, (const bf16*)src, rows, (bf16*)dst, n_rows, total_rows, cols, 0);
+    OBTE_CHECK_LAUNCH("obte_rows_gather_bf16");
+    return OBTE_OK;
+}
+extern "C" int obte_rows_scatter_bf16(const obte_bf16* src, const int64_t* rows, obte_bf16* dst, int64_t n_rows, int64_t total_rows, int32_t cols, obte_stream s) {
+    OBTE_REQUIRE(src && rows && dst, "obte_rows_scatter_bf16: null pointer");
+    OBTE_REQUIRE(n_rows > 0 && n_rows <= total_rows && cols > 0 && cols % 8 == 0, "obte_rows_scatter_bf16: need 0 < n_rows <= total_rows and cols %% 8 == 0");
+    if (hipMemsetAsync(dst, 0, (size_t)total_rows * cols * 2, (hipStream_t)s) != hipSuccess) { obte_set_error("obte_rows_scatter_bf16: memset failed"); return OBTE_ELAUNCH; }
+    hipLaunchKernelGGL(rows_copy_kernel, dim3((unsigned)cdiv64(n_rows, 4)), dim3(256), 0, (hipStream_t)s, (const bf16*)src, rows, (bf16*)dst, n_rows, total_rows, cols, 1);
+    OBTE_CHECK_LAUNCH("obte_rows_scatter_bf16");
+    return OBTE_OK;
+}
+
 extern "C" int obte_masked_ce_rows(const obte_bf16* logits, const int64_t* target, const int64_t* row_index, const float* grad_scale,
                                    float row_scale, const float* row_scale_vec, float* row_loss, obte_bf16* dlogits_rows, int64_t n_rows,
                                    int64_t total_rows, int64_t vocab, obte_stream s) {

@@ -376,12 +376,13 @@ class _BlockFn(torch.autograd.Function):
     """One pre-LN transformer block (model.py:170-181): a single C call per pass."""
 
     @staticmethod
-    def forward(ctx, x, ln1, attn_w, proj_w, ln2, fc_w, mlp_w, rope_cos, rope_sin, n_head, mask, dropout_p, dropout_seed):
+    def forward(ctx, x, ln1, attn_w, proj_w, ln2, fc_w, mlp_w, rope_cos, rope_sin, n_head, mask, dropout_p, dropout_seed, out_rows=None):
         x = x.contiguous()
         params = (ln1, attn_w, proj_w, ln2, fc_w, mlp_w)
-        y, act = ops.block_fwd(x, params, (rope_cos, rope_sin), n_head, mask, dropout_p, dropout_seed)
+        y, act = ops.block_fwd(x, params, (rope_cos, rope_sin), n_head, mask, dropout_p, dropout_seed, out_rows=out_rows)
         ctx.save_for_backward(x, act, rope_cos, rope_sin, *params)
         ctx.n_head, ctx.mask = n_head, mask
+        ctx.out_rows = out_rows   # the rows form: y is [n, C], the positions the caller wants (ops.block_fwd)
         ctx.drop = (dropout_p, dropout_seed)
         ctx.w_params = params
         ctx.pol = current_grad_policy()
@@ -396,9 +397,9 @@ class _BlockFn(torch.autograd.Function):
         lnp = (_ln_partials(ctx.w_params[0], pol), _ln_partials(ctx.w_params[3], pol)) if pol.ln_mode else None
         dx, grads = ops.block_bwd(x, dy.contiguous(), act, tuple(params), (rope_cos, rope_sin), ctx.n_head, ctx.mask,
                                   accumulate_into=slots, dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1], ln_partials=lnp,
-                                  ln_partial_mode=pol.ln_mode)
+                                  ln_partial_mode=pol.ln_mode, out_rows=ctx.out_rows)
         _ord_done(pol, id(ctx.w_params[0]))
-        return (dx, *grads, None, None, None, None, None, None)
+        return (dx, *grads, None, None, None, None, None, None, None)
 
 
 class _AttnCoreFn(torch.autograd.Function):
@@ -544,7 +545,10 @@ class Block(nn.Module):
         if config.bias:
             raise NotImplementedError("bias=True is not used by the reference (model.py:191) and not implemented")
 
-    def forward(self, x, attn_mask=None):
+    def forward(self, x, attn_mask=None, out_rows=None):
+        """out_rows (optional, int64 (n,), ascending rows of the flattened (b*t, n_embd) activation; dropout 0 only): the caller
+        wants the block's output at those positions alone and gets it as (n, n_embd) — the attention half runs on every
+        position, the MLP half on the listed ones (per-position arithmetic: the same values there)."""
         _require_hip(x, "Block")
         _require_hip(self.attn.c_attn.weight, "Block parameters")
         if self.attn.autoregressive:
@@ -555,8 +559,12 @@ class Block(nn.Module):
         # one dropout probability per block, as in the reference (config.dropout feeds all three nn.Dropout modules)
         p = _active_p(self, self.attn.dropout)
         seed = _new_seed() if p > 0 else 0
+        if out_rows is not None and p > 0:   # the dropout masks are defined on whole activations: full block, then the rows
+            y = _BlockFn.apply(x, self.ln_1.weight, self.attn.c_attn.weight, self.attn.c_proj.weight, self.ln_2.weight,
+                               self.mlp.c_fc.weight, self.mlp.c_proj.weight, cos, sin, self.attn.n_head, mask, p, seed)
+            return y.reshape(-1, C).index_select(0, out_rows)
         return _BlockFn.apply(x, self.ln_1.weight, self.attn.c_attn.weight, self.attn.c_proj.weight, self.ln_2.weight,
-                              self.mlp.c_fc.weight, self.mlp.c_proj.weight, cos, sin, self.attn.n_head, mask, p, seed)
+                              self.mlp.c_fc.weight, self.mlp.c_proj.weight, cos, sin, self.attn.n_head, mask, p, seed, out_rows)
 
 
 @dataclass
@@ -604,10 +612,15 @@ class OmniBioTA(nn.Module):
             n_params -= self.transformer.wte.weight.numel()
         return n_params
 
-    def forward(self, idx, attn_mask=None, return_embeddings=False):
+    def forward(self, idx, attn_mask=None, return_embeddings=False, rows=None):
         """idx (b, t) int64 -> logits (b, t, vocab) or, with return_embeddings, emb (b, t, n_embd)
         (model.py:225-254).  ``attn_mask``: None, the reference's additive (b, n_head, t, t) tensor (any strides,
-        expand() views included), or a ``masks.RangeMask`` (per-query key ranges; the fast path)."""
+        expand() views included), or a ``masks.RangeMask`` (per-query key ranges; the fast path).
+        ``rows`` (an extension, not in the reference; int64 (n,), ascending positions of the flattened (b*t) batch): the
+        caller needs the result at those positions only — a masked-LM loss looks at ~15 % of them (train_encoder.py:304) —
+        and gets (n, n_embd) embeddings or (n, vocab) logits.  Nothing after the last block's attention mixes positions, so
+        that block's MLP half, ln_f and the readout run on the listed positions alone; every value returned is the one the full
+        forward computes there (the same arithmetic per position; few-tile projections may sum their K range in split-K order)."""
         _, t = idx.size()
         assert t <= self.config.block_size, f"Cannot forward sequence of length {t}, block size is only {self.config.block_size}"
         wte = self.transformer.wte.weight
@@ -626,11 +639,15 @@ class OmniBioTA(nn.Module):
         if order is not None and (order.numel() != idx.numel() or order.dtype != torch.int32 or order.device != idx.device):
             order = None
         x = _EmbeddingFn.apply(idx, wte, p, _new_seed() if p > 0 else 0, order)
+        n_blocks = len(self.transformer.h)
+        if rows is not None and (rows.numel() == 0 or n_blocks == 0):
+            raise ValueError("OmniBioTA.forward: rows must list at least one position (and the model needs a block)")
         for i, block in enumerate(self.transformer.h):
+            last_rows = rows if (rows is not None and i == n_blocks - 1) else None
             if self.config.checkpoint_freq > 0 and i % self.config.checkpoint_freq == 0:
-                x = checkpoint(block, x, mask, use_reentrant=False)
+                x = checkpoint(block, x, mask, last_rows, use_reentrant=False)
             else:
-                x = block(x, attn_mask=mask)
+                x = block(x, attn_mask=mask, out_rows=last_rows)
         emb = self.transformer.ln_f(x)
         if return_embeddings:
             return emb

@@ -432,31 +432,37 @@ def sumsq_(g, out):
 
 
 # -------------------------------------------------------------------------------------------------------- block
-def _block_desc(B, T, Cc, H, params, rope, mask: MaskSpec, dropout_p=0.0, dropout_seed=0, ln_partials=None, ln_partial_mode=0):
+def _block_desc(B, T, Cc, H, params, rope, mask: MaskSpec, dropout_p=0.0, dropout_seed=0, ln_partials=None, ln_partial_mode=0, out_rows=None):
     ln1, attn_w, proj_w, ln2, fc_w, mlp_w = params
     p1, p2 = ln_partials if ln_partials is not None else (None, None)
+    if out_rows is not None:
+        _need(out_rows, "out_rows", torch.int64)
+        assert 0 < out_rows.numel() <= B * T and dropout_p == 0.0, "the rows form of the block: a non-empty list, dropout 0"
     return L.BlockDesc(B, T, Cc, H, _ptr(ln1), _ptr(attn_w), _ptr(proj_w), _ptr(ln2), _ptr(fc_w), _ptr(mlp_w),
                        _ptr(rope[0]), _ptr(rope[1]), _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq,
-                       float(dropout_p), int(dropout_seed), _ptr(mask.qbounds), _ptr(p1), _ptr(p2), int(ln_partial_mode), _ptr(mask.exact))
+                       float(dropout_p), int(dropout_seed), _ptr(mask.qbounds), _ptr(p1), _ptr(p2), int(ln_partial_mode), _ptr(mask.exact),
+                       _ptr(out_rows), 0 if out_rows is None else out_rows.numel())
 
 
-def block_fwd(x, params, rope, H, mask: MaskSpec, dropout_p=0.0, dropout_seed=0):
-    """One transformer block forward.  Returns (y, act) where act is the opaque saved-activation buffer."""
+def block_fwd(x, params, rope, H, mask: MaskSpec, dropout_p=0.0, dropout_seed=0, out_rows=None):
+    """One transformer block forward.  Returns (y, act) where act is the opaque saved-activation buffer.
+    out_rows (int64 (n,), ascending rows of the [B*T, C] activation; dropout 0): only those positions of the output are
+    wanted — y is [n, C], the MLP half runs on them alone (include/omnibiote_hip.h, obte_block_desc::out_rows)."""
     _need(x, "x")
     B, T, Cc = x.shape
     for i, w in enumerate(params):
         _need(w, f"param{i}")
     _need(rope[0], "rope_cos", torch.float32); _need(rope[1], "rope_sin", torch.float32)
     assert rope[0].shape[0] >= T
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out_rows is None else torch.empty((out_rows.numel(), Cc), dtype=bf16, device=x.device)
     act = torch.empty(int(L.lib().obte_block_act_bytes(B, T, Cc, H)), dtype=torch.uint8, device=x.device)
-    d = _block_desc(B, T, Cc, H, params, rope, mask, dropout_p, dropout_seed)
+    d = _block_desc(B, T, Cc, H, params, rope, mask, dropout_p, dropout_seed, out_rows=out_rows)
     L.check(L.lib().obte_block_fwd(C.byref(d), _ptr(x), _ptr(y), _ptr(act), _stream()), "obte_block_fwd")
     return y, act
 
 
 def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec, accumulate_into=None, dropout_p=0.0, dropout_seed=0, ln_partials=None,
-              ln_partial_mode=0):
+              ln_partial_mode=0, out_rows=None):
     """accumulate_into: optional list of 6 tensors-or-None (same order as params).  When the four matrix entries are all
     given, their gradients are added into those tensors in place and the corresponding returned grads are None; the
     same, independently, for the two LayerNorm weights (entries 0 and 3).
@@ -464,6 +470,7 @@ def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec, accumulate_into=None,
     calls in those fp32 buffers instead (see layernorm_bwd); their returned grads are None except with LN_PARTIAL_LAST."""
     _need(x, "x"); _need(dy, "dy")
     B, T, Cc = x.shape
+    assert dy.numel() == (B * T if out_rows is None else out_rows.numel()) * Cc, "dy: one row per (wanted) position"
     ws = torch.empty(int(L.lib().obte_block_bwd_ws_bytes(B, T, Cc, H)), dtype=torch.uint8, device=x.device)
     dx = torch.empty_like(x)
     acc = accumulate_into is not None and all(accumulate_into[i] is not None for i in (1, 2, 4, 5))
@@ -480,7 +487,7 @@ def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec, accumulate_into=None,
             grads.append(g)
         else:
             grads.append(torch.empty_like(w))
-    d = _block_desc(B, T, Cc, H, params, rope, mask, dropout_p, dropout_seed, ln_partials, ln_partial_mode)
+    d = _block_desc(B, T, Cc, H, params, rope, mask, dropout_p, dropout_seed, ln_partials, ln_partial_mode, out_rows=out_rows)
     L.check(L.lib().obte_block_bwd_acc(C.byref(d), _ptr(x), _ptr(dy), _ptr(act), _ptr(ws), _ptr(dx), *[_ptr(g) for g in grads],
                                         int(acc) + 2 * int(acc_ln), _stream()), "obte_block_bwd")
     ln_none = ln_partial_mode in (L.LN_PARTIAL_FIRST, L.LN_PARTIAL_MORE)

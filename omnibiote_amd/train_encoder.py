@@ -168,7 +168,8 @@ class TrainStep:
     def __init__(self, model, optimizer, scheduler=None, *, mini_batch_size: int, n_head: int, use_padding: bool = False,
                  loss_impl: str = "fused", mask_impl: str = "ranges", sync_every_micro_step: bool = False,
                  max_grad_norm: float = 1.0, lm_head_impl: str = "masked", pipeline_streams: int = 1,
-                 fused_loss_fn: Optional[Callable] = None, micro_batches_per_pass: int = 1, backward_order: str = "layer"):
+                 fused_loss_fn: Optional[Callable] = None, micro_batches_per_pass: int = 1, backward_order: str = "layer",
+                 rows_forward: bool = True):
         """fused_loss_fn: ``(logits, targets, mlm_mask, n_accum) -> (loss, dlogits)`` used by loss_impl="fused" instead of
         the HIP kernel (ops.masked_ce) — lets the CPU multi-process tests drive the product scheduling (in-place
         accumulation, no_sync, hand-delivered d(logits)) with a stub model and a torch loss."""
@@ -211,6 +212,10 @@ class TrainStep:
         # read-modify-writes either way: bitwise the same results (tested against pipeline_streams = 1).
         assert backward_order in ("layer", "pass")
         self.backward_order = backward_order
+        # lm_head_impl="masked": hand the list of masked positions to model.forward(rows=...) so that everything after the last
+        # block's attention (its MLP half, ln_f, the readout) is computed for those positions only; False: forward(return_
+        # embeddings=True) on every position, rows gathered afterwards (the reference's forward contract to the letter)
+        self.rows_forward = bool(rows_forward) and hasattr(model.module if hasattr(model, "module") else model, "transformer")
         self._order = None           # the BackwardOrder of the pass being built
         self._prev_order_events = None
         self._streams = None
@@ -309,16 +314,21 @@ class TrainStep:
         the CE kernel turns them into d(logits) rows, and the two backward products are those of the "dense" path."""
         from . import ops
         from .model import _ReadoutRowsGradFn
-        emb = self.model(x, attn_mask=attn_mask, return_embeddings=True)
         core = self.model.module if hasattr(self.model, "module") else self.model
         rows, weights = self._pass_rows(self._mb, k, self.mini * x.shape[1])
         if rows.numel() == 0:
             # nothing masked in this pass: still hand EVERY parameter a (zero) gradient — lm_head included — or
             # DDP's reducer would wait for it forever when this is the synchronising micro-batch
+            emb = self.model(x, attn_mask=attn_mask, return_embeddings=True)
             self._order_backward()
             (emb.sum() * 0 + core.lm_head.weight.sum() * 0).backward()
             return torch.zeros((), dtype=torch.float32, device=x.device)
-        emb_rows = emb.reshape(-1, emb.shape[-1]).index_select(0, rows)
+        if self.rows_forward:
+            # the model is told which positions are wanted: the last block's MLP half and ln_f run on them alone (model.forward(rows=))
+            emb_rows = self.model(x, attn_mask=attn_mask, return_embeddings=True, rows=rows)
+        else:
+            emb = self.model(x, attn_mask=attn_mask, return_embeddings=True)
+            emb_rows = emb.reshape(-1, emb.shape[-1]).index_select(0, rows)
         with torch.no_grad():
             logits = core.lm_head(emb_rows)                # (n_masked, V): model.py:253 on the rows the loss keeps (:304)
             loss, dl = ops.masked_ce_rows(logits, y.reshape(-1).index_select(0, rows), None, n_accum, row_weights=weights)

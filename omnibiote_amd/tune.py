@@ -60,7 +60,7 @@ def candidates(M: int, N: int, K: int, epi: int) -> List[Tuple[int, int, int]]:
         if K >= 128:
             c.append((3, 256, 1))
     nk = (K + 63) // 64
-    if epi == L.EPI_NONE and M * N * 4 * 8 <= (1 << 28):   # split-K only for small outputs (weight gradients)
+    if epi in (L.EPI_NONE, L.EPI_ADD) and M * N * 4 * 8 <= (1 << 28):   # split-K only for small outputs (weight gradients, the rows form's projections)
         for bn in (128, 256):
             if bn == 256 and N < 256:
                 continue
@@ -136,6 +136,10 @@ def model_gemm_shapes(rows: int, n_embd: int, vocab: int):
         # the readout over the MLM-masked rows (about 15 % of M; the library applies these plans to counts within 20 %): its
         # two backward products, and the forward of the readout that computes the masked rows only
         (Mm, C, V, True, False, E.EPI_NONE), (V, C, Mm, False, False, E.EPI_NONE), (Mm, V, C, True, True, E.EPI_NONE),
+        # the last block's MLP half on those positions (model.forward(rows=...)): forward, input gradients, weight gradients
+        (Mm, 4 * C, C, True, True, E.EPI_GELU), (Mm, C, 4 * C, True, True, E.EPI_ADD),
+        (Mm, 4 * C, C, True, False, E.EPI_GELU_BWD), (Mm, C, 4 * C, True, False, E.EPI_NONE),
+        (C, 4 * C, Mm, False, False, E.EPI_NONE), (4 * C, C, Mm, False, False, E.EPI_NONE),
     ]
 
 

@@ -53,7 +53,7 @@ def test_bench_two_ranks_prints_one_line(tmp_path):
     assert "mfma_fraction_whole_step" not in line and line["mfma_fraction_whole_step_executed"] >= 0 and line["flops_per_token_executed"] > 0
     assert len(line["gemm_plans"]["table"]) >= 15 and len(line["gemm_plans"]["sha16"]) == 16
     assert line["roofline"]["bound"] == "mfma" and line["roofline"]["frac"] > 0
-    assert set(line["variants"]) >= {"dense_logits_forward", "dense_dlogits_full_backward", "dropout_0.1", "dense_mask_calling_convention"}
+    assert set(line["variants"]) >= {"dense_logits_forward", "masked_readout_full_last_block", "dense_dlogits_full_backward", "dropout_0.1", "dense_mask_calling_convention"}
     assert ("REHEARSAL" in line["data"]) == (not rccl)
     assert "first all-reduce ok" in se
 

@@ -681,6 +681,55 @@ def _tiny_model(w, C, H, Lyr, V, T):
     return m.to(DEV)
 
 
+def test_forward_rows_returns_the_listed_positions_of_the_full_forward():
+    """OmniBioTA.forward(rows=...): embeddings / logits at the listed positions only (the last block's MLP half, ln_f and the
+    readout run on them alone).  The values are those of the full forward at those positions (to a bf16 rounding: the small
+    projections are split-K); the gradients of a
+    loss on them equal, within bf16 accumulation differences, the full forward's with zeros elsewhere; with dropout on the model
+    falls back to the full block (same API); activation checkpointing passes the list through."""
+    from omnibiote_amd import train_encoder as TE
+    from omnibiote_amd.masks import RangeMask
+    C, H, Lyr, V, T, B = 256, 2, 3, 1024, 128, 4
+    w = R.hash_weights(R.RefConfig(block_size=T, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C))
+    ids = torch.from_numpy(TE.synthetic_rows(B, T, V, np.random.default_rng(2), single_document=False)).to(DEV)
+    rows = torch.sort(torch.randperm(B * T, generator=torch.Generator().manual_seed(1))[:70]).values.to(DEV)
+    mask = RangeMask.from_tokens(ids)
+    m = _tiny_model(w, C, H, Lyr, V, T)
+    full = m(ids, attn_mask=mask, return_embeddings=True)
+    part = m(ids, attn_mask=mask, return_embeddings=True, rows=rows)
+    assert tuple(part.shape) == (70, C)
+    def near(a, b, atol, rtol):   # (split-K summation order: a bf16 rounding, not bit identity)
+        a, b = a.float(), b.float()
+        assert ((a - b).abs() <= atol + rtol * b.abs()).all(), (a - b).abs().max().item()
+    near(part, full.reshape(-1, C)[rows], 4e-3, 2.0 ** -7)
+    near(m(ids, attn_mask=mask, rows=rows), m(ids, attn_mask=mask).reshape(-1, V)[rows], 2e-2, 2.0 ** -6)
+    gsel = torch.randn(70, C, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)).to(BF) * 0.1
+    grads = {}
+    for tag in ("rows", "full"):
+        m.zero_grad(set_to_none=True)
+        out = m(ids, attn_mask=mask, return_embeddings=True, rows=rows) if tag == "rows" else m(ids, attn_mask=mask, return_embeddings=True).reshape(-1, C)[rows]
+        out.backward(gsel)
+        grads[tag] = {k: p.grad.float().clone() for k, p in m.named_parameters() if p.grad is not None}
+    assert grads["rows"].keys() == grads["full"].keys()
+    for k in grads["full"]:
+        a, b = grads["rows"][k], grads["full"][k]
+        assert (a - b).norm().item() <= 0.02 * b.norm().item() + 1e-6, k
+    m.config.checkpoint_freq = 1   # every block recomputed in the backward: the list travels through checkpoint()
+    m.zero_grad(set_to_none=True)
+    out = m(ids, attn_mask=mask, return_embeddings=True, rows=rows)
+    assert torch.equal(out, part)      # the same launches as without checkpointing
+    out.backward(gsel)
+    for k, p in m.named_parameters():
+        if k in grads["rows"]:   # (lm_head takes no part in an embeddings-only graph)
+            assert torch.equal(p.grad.float(), grads["rows"][k]), "checkpointed " + k
+    m.config.checkpoint_freq = 0
+    TE.set_dropout(m, 0.1)             # dropout on: full block, then the rows (same call, same shapes)
+    torch.manual_seed(5)
+    assert tuple(m(ids, attn_mask=mask, return_embeddings=True, rows=rows).shape) == (70, C)
+    with pytest.raises(ValueError):
+        m(ids, attn_mask=mask, rows=rows[:0])
+
+
 def test_pipelined_step_with_dropout_is_bitwise_the_single_stream_step():
     """Dropout 0.1 at all four sites (counter-based masks, seeds drawn on the host in issue order) under the two-stream
     pipeline with per-group backward ordering: the masks cannot depend on which stream a micro-batch ran on, so losses,

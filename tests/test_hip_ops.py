@@ -518,6 +518,65 @@ def test_block_fwd_bwd_vs_oracle(monkeypatch, C, H, T, mode, grouped):
         close(g, gr, atol=tol, rtol=2.0 ** -5, what="block d" + n)
 
 
+@pytest.mark.parametrize("C,H,T,n_rows", [(128, 2, 64, 1), (256, 2, 77, 23), (1024, 8, 128, 40), (1024, 8, 1024, 300)])
+@pytest.mark.parametrize("grouped", ["0", "1"])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_block_rows_form_vs_oracle_and_vs_the_full_block(monkeypatch, C, H, T, n_rows, grouped, accumulate):
+    """obte_block_desc::out_rows (the last block of a masked-LM step): the block's output at the listed positions only, its
+    MLP half computed on those positions alone.  Against the oracle — the full block, output rows picked, gradient fed at those
+    rows and zero elsewhere (what a loss that multiplies the other positions by zero produces) — and against the HIP full
+    block run the same way: the same forward rows (to one bf16 rounding: the few-tile projections of the rows form are split-K),
+    gradients within the bar; with in-place accumulation as the harness uses it."""
+    monkeypatch.setenv("OBTE_GROUPED_WGRAD", grouped)
+    B = 2
+    hs = C // H
+    cfg = R.RefConfig(block_size=T, vocab_size=256, n_layer=1, n_head=H, n_embd=C)
+    w = {k: v.to(BF) for k, v in R.hash_weights(cfg).items()}
+    pre = "transformer.h.0."
+    names = ["ln_1.weight", "attn.c_attn.weight", "attn.c_proj.weight", "ln_2.weight", "mlp.c_fc.weight", "mlp.c_proj.weight"]
+    g = torch.Generator().manual_seed(5)
+    rows = torch.sort(torch.randperm(B * T, generator=g)[:n_rows]).values
+    x, dy_r = rnd(B, T, C, seed=1), rnd(n_rows, C, seed=2, scale=0.1)
+    tokens = np.random.default_rng(3).integers(20, 100, size=(B, T))
+    tokens[0, T // 2] = R.EOS_TOKEN
+    dense, ranges = _blocks_to_masks(tokens, T)
+    tab = R.cast_rope_table(R.rope_table(hs, T), BF)
+    wf = {k: v.float().requires_grad_(True) for k, v in w.items()}
+    xf = x.float().requires_grad_(True)
+    ref = R.block_forward(xf, wf, pre, cfg, tab, dense.unsqueeze(1)).reshape(-1, C)[rows]
+    ref.backward(dy_r.float())
+    from omnibiote_amd.model import rope_tables
+    o = ops()
+    params = tuple(w[pre + n].to(DEV) for n in names)
+    rope = rope_tables(tab.to(DEV))
+    spec = o.MaskSpec(ranges=ranges.to(DEV))
+    rows_d = rows.to(DEV)
+    y_r, act = o.block_fwd(x.to(DEV), params, rope, H, spec, out_rows=rows_d)
+    assert tuple(y_r.shape) == (n_rows, C)
+    y_full, act_full = o.block_fwd(x.to(DEV), params, rope, H, spec)
+    # the listed rows of the full block: the same arithmetic per position, up to the summation order of a split-K projection
+    close(y_r, y_full.reshape(-1, C)[rows_d], atol=2e-3, rtol=2.0 ** -7, what="block rows vs full block")
+    close(y_r, ref, atol=3e-2, rtol=2.0 ** -6, what="block rows fwd")
+    acc = None
+    old = None
+    if accumulate:   # gradients added into existing buffers by the epilogues, LayerNorm weights included
+        old = [rnd(*p.shape, seed=30 + i, scale=0.05).to(DEV) for i, p in enumerate(params)]
+        acc = [t.clone() for t in old]
+    dx, grads = o.block_bwd(x.to(DEV), dy_r.to(DEV), act, params, rope, H, spec, accumulate_into=acc, out_rows=rows_d)
+    close(dx, xf.grad, atol=2e-2, rtol=2.0 ** -5, what="block rows dx")
+    dy_full = torch.zeros(B * T, C, dtype=BF, device=DEV)
+    dy_full[rows_d] = dy_r.to(DEV)
+    dx_full, grads_full = o.block_bwd(x.to(DEV), dy_full.reshape(B, T, C), act_full, params, rope, H, spec)
+    assert (dx.float() - dx_full.float()).norm().item() <= 0.01 * dx_full.float().norm().item() + 1e-6
+    for i, (n, gr_) in enumerate(zip(names, grads)):
+        want = wf[pre + n].grad
+        got = (acc[i].float() - old[i].float()) if accumulate else gr_.float()
+        tol = 0.03 * want.abs().max().item() + 1e-3 + (2.0 ** -7 * old[i].float().abs().max().item() if accumulate else 0.0)
+        close(got, want, atol=tol, rtol=2.0 ** -5, what="block rows d" + n)
+        if not accumulate:
+            assert (gr_.float() - grads_full[i].float()).norm().item() <= 0.02 * grads_full[i].float().norm().item() + 1e-5, n
+
+
 # ------------------------------------------------------------------------------ GEMM: split-K and big-tile paths
 @pytest.mark.parametrize("M,N,K", [(1024, 1024, 2048), (384, 256, 4096), (256, 128, 8192), (3072, 1024, 1100)])
 def test_gemm_wgrad_split_k(M, N, K):
