@@ -216,9 +216,22 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
         dy_mlp = dym;
     }
     TRY(gemm(dy_mlp, d->mlp_w, dhpre, Mm, 4 * C, C, C, 4 * C, 1, 0, OBTE_EPI_GELU_BWD, hpre, nullptr, s));      // dhpre = (dy W_mlp) * gelu'(h): hpre holds the derivative
-    if (!grouped_mlp) TRY(gemm(dy_mlp, hact, dmlp_w, C, 4 * C, Mm, C, 4 * C, 0, 0, wepi, accumulate_matrices ? dmlp_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_mlp = dy^T hact
+    // rows form with enough rows for the grouped kernel's K: the MLP half's two weight gradients (K = Mm) share one launch below
+    const bool pair_mlp = rows_form && grouped && Mm >= 256;
+    if (!grouped_mlp && !pair_mlp) TRY(gemm(dy_mlp, hact, dmlp_w, C, 4 * C, Mm, C, 4 * C, 0, 0, wepi, accumulate_matrices ? dmlp_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_mlp = dy^T hact
     TRY(gemm(dhpre, d->fc_w, dh, Mm, C, 4 * C, 4 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s, rows_form ? gws : nullptr, rows_form ? W.gemmws_bytes : 0));   // dh2 = dhpre W_fc (rows form: few tiles over K = 4C, split-K)
-    if (!grouped_mlp) TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, Mm, 4 * C, C, 0, 0, wepi, accumulate_matrices ? dfc_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_fc = dhpre^T h2
+    if (!grouped_mlp && !pair_mlp) TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, Mm, 4 * C, C, 0, 0, wepi, accumulate_matrices ? dfc_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_fc = dhpre^T h2
+    if (pair_mlp) {
+        obte_gemm_args gp[2] = {};
+        auto putp = [&](int i, const obte_bf16* a, const obte_bf16* b, obte_bf16* dw, int64_t m, int64_t n) {
+            gp[i].a = a; gp[i].b = b; gp[i].d = dw; gp[i].aux = accumulate_matrices ? dw : nullptr;
+            gp[i].M = m; gp[i].N = n; gp[i].K = Mm; gp[i].lda = m; gp[i].ldb = n; gp[i].ldd = n;
+            gp[i].a_kmajor = 0; gp[i].b_kmajor = 0; gp[i].epilogue = wepi; gp[i].alpha = 1.0f;
+        };
+        putp(0, dhpre, h2, dfc_w, 4 * C, C);
+        putp(1, dy_mlp, hact, dmlp_w, C, 4 * C);
+        TRY(obte_gemm_grouped_bf16(gp, 2, s));
+    }
     const int lnp = d->ln_partial_mode;
     if (lnp) OBTE_REQUIRE(d->ln1_partials && d->ln2_partials && lnp >= OBTE_LN_PARTIAL_FIRST && lnp <= OBTE_LN_PARTIAL_LAST,
                           "obte_block_bwd: ln_partial_mode needs both partial buffers and a valid mode");
