@@ -423,7 +423,7 @@ def main():
     value = tokens_per_step * a.steps / elapsed
     fpt = TE.flops_per_token(n_params, cfg["n_layer"], cfg["n_embd"], T)
     skipped = {"dense": 4.0 * cfg["n_embd"] * 65536 * 0.85, "dense_full": 0.0, "masked": 6.0 * cfg["n_embd"] * 65536 * 0.85}[a.readout]
-    if a.readout == "masked" and not a.full_last_block and a.dropout == 0.0:   # the last block's MLP half (8 C^2 parameters: 6 FLOP each per token) on the masked positions only
+    if a.readout == "masked" and not a.full_last_block:   # the last block's MLP half (8 C^2 parameters: 6 FLOP each per token) on the masked positions only
         skipped += 6.0 * 8.0 * cfg["n_embd"] ** 2 * 0.85
     fpt_exec = fpt - skipped   # 15 % of the positions are MLM-masked (train_encoder.py:271); their share of the readout products remains
 

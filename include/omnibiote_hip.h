@@ -307,13 +307,14 @@ typedef struct {
      * dln1_w / dln2_w are not written. */
     float *ln1_partials, *ln2_partials; int32_t ln_partial_mode;
     const int32_t* ranges_exact;              /* nullable: obte_mask_bounds' flag for a dense mask (see obte_mask_bounds) */
-    /* optional (the LAST block of a masked-LM step, dropout 0): only these positions of the block's output are wanted — the
+    /* optional (the LAST block of a masked-LM step): only these positions of the block's output are wanted — the
      * loss multiplies every other position by zero (train_encoder.py:304) and nothing after the last block mixes positions.
      * out_rows: int64 [n_out_rows], ascending rows of the [B*T, C] activation.  The attention half runs on every position
      * (keys and values of all of them are needed); x1 is gathered at out_rows and ln_2, c_fc + GELU, mlp.c_proj run on those
      * rows only: y is [n_out_rows, C].  Backward: dy is [n_out_rows, C]; the MLP half's gradients are contracted over those
      * rows (the rows left out would contribute exact zeros), d x1 is scattered back into a zeroed [B*T, C] and the attention
-     * half's backward runs as usual.  NULL / 0: the whole block on every position. */
+     * half's backward runs as usual.  With dropout, site 3 (the MLP projection) masks element (i, c) of the [n_out_rows, C]
+     * output, forward and backward alike; sites 1 and 2 are unchanged.  NULL / 0: the whole block on every position. */
     const int64_t* out_rows; int64_t n_out_rows;
 } obte_block_desc;
 int64_t obte_block_act_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head);

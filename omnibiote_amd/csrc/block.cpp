@@ -97,7 +97,6 @@ int check_desc(const char* who, const obte_block_desc* d) {
                  "%s: null parameter", who);
     OBTE_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "%s: dropout p must be in [0,1)", who);
     OBTE_REQUIRE((d->out_rows == nullptr) == (d->n_out_rows == 0) && d->n_out_rows >= 0 && d->n_out_rows <= d->B * d->T, "%s: out_rows / n_out_rows inconsistent", who);
-    OBTE_REQUIRE(!(d->out_rows && d->dropout_p > 0.f), "%s: the rows form (out_rows) is for dropout 0 (its masks are defined on whole activations)", who);
     return OBTE_OK;
 }
 
@@ -211,8 +210,8 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     const bool grouped_mlp = grouped && !rows_form;
     // MLP: out = x1 + dropout(hact W_mlp^T): the projection sees dy masked by the same (seed, site 3) mask
     const obte_bf16* dy_mlp = dy;
-    if (drop) {
-        TRY(obte_dropout_bf16(dy, dym, M * C, C, d->dropout_p, d->dropout_seed, SITE_MLP, s));
+    if (drop) {   // (rows form: dy and the mask of site 3 are [Mm, C] — element (i, c) of the compact output, as in the forward)
+        TRY(obte_dropout_bf16(dy, dym, Mm * C, C, d->dropout_p, d->dropout_seed, SITE_MLP, s));
         dy_mlp = dym;
     }
     TRY(gemm(dy_mlp, d->mlp_w, dhpre, Mm, 4 * C, C, C, 4 * C, 1, 0, OBTE_EPI_GELU_BWD, hpre, nullptr, s));      // dhpre = (dy W_mlp) * gelu'(h): hpre holds the derivative
@@ -238,7 +237,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     // dx1 = dy + LN2'(dh2); attention: x1 = x + dropout(y W_proj^T), so its projection sees dx1 under the (seed, site 2) mask:
     // with dropout on, the LayerNorm backward writes that masked copy beside dx1 (it used to be a pass of its own)
     const obte_bf16* dx1_proj = dx1;
-    if (drop) {
+    if (drop && !rows_form) {
         TRY(obte_layernorm_bwd_dropout(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dym2, dln2_w, lnp ? d->ln2_partials : lnws, M, C, lnp, acc_ln,
                                        d->dropout_p, d->dropout_seed, SITE_RESID, s));
         dx1_proj = dym2;
@@ -247,6 +246,10 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
         if (lnp) TRY(obte_layernorm_bwd_partial(dh, x1m, d->ln2_w, mean2, rstd2, dy, dx1r, dln2_w, d->ln2_partials, Mm, C, lnp, s));
         else TRY(obte_layernorm_bwd_acc(dh, x1m, d->ln2_w, mean2, rstd2, dy, dx1r, dln2_w, lnws, Mm, C, acc_ln, s));
         TRY(obte_rows_scatter_bf16(dx1r, d->out_rows, dx1, Mm, M, C, s));
+        if (drop) {   // the attention projection sees d x1 under the (seed, site 2) mask, which is defined on whole activations
+            TRY(obte_dropout_bf16(dx1, dym2, M * C, C, d->dropout_p, d->dropout_seed, SITE_RESID, s));
+            dx1_proj = dym2;
+        }
     } else if (lnp) {
         TRY(obte_layernorm_bwd_partial(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, d->ln2_partials, M, C, lnp, s));
     } else {

@@ -546,9 +546,10 @@ class Block(nn.Module):
             raise NotImplementedError("bias=True is not used by the reference (model.py:191) and not implemented")
 
     def forward(self, x, attn_mask=None, out_rows=None):
-        """out_rows (optional, int64 (n,), ascending rows of the flattened (b*t, n_embd) activation; dropout 0 only): the caller
+        """out_rows (optional, int64 (n,), ascending distinct rows of the flattened (b*t, n_embd) activation): the caller
         wants the block's output at those positions alone and gets it as (n, n_embd) — the attention half runs on every
-        position, the MLP half on the listed ones (per-position arithmetic: the same values there)."""
+        position, the MLP half on the listed ones (per-position arithmetic: the same values there; in training mode the
+        dropout mask of the MLP projection is drawn for the (n, n_embd) output)."""
         _require_hip(x, "Block")
         _require_hip(self.attn.c_attn.weight, "Block parameters")
         if self.attn.autoregressive:
@@ -559,10 +560,6 @@ class Block(nn.Module):
         # one dropout probability per block, as in the reference (config.dropout feeds all three nn.Dropout modules)
         p = _active_p(self, self.attn.dropout)
         seed = _new_seed() if p > 0 else 0
-        if out_rows is not None and p > 0:   # the dropout masks are defined on whole activations: full block, then the rows
-            y = _BlockFn.apply(x, self.ln_1.weight, self.attn.c_attn.weight, self.attn.c_proj.weight, self.ln_2.weight,
-                               self.mlp.c_fc.weight, self.mlp.c_proj.weight, cos, sin, self.attn.n_head, mask, p, seed)
-            return y.reshape(-1, C).index_select(0, out_rows)
         return _BlockFn.apply(x, self.ln_1.weight, self.attn.c_attn.weight, self.attn.c_proj.weight, self.ln_2.weight,
                               self.mlp.c_fc.weight, self.mlp.c_proj.weight, cos, sin, self.attn.n_head, mask, p, seed, out_rows)
 

@@ -437,7 +437,7 @@ def _block_desc(B, T, Cc, H, params, rope, mask: MaskSpec, dropout_p=0.0, dropou
     p1, p2 = ln_partials if ln_partials is not None else (None, None)
     if out_rows is not None:
         _need(out_rows, "out_rows", torch.int64)
-        assert 0 < out_rows.numel() <= B * T and dropout_p == 0.0, "the rows form of the block: a non-empty list, dropout 0"
+        assert 0 < out_rows.numel() <= B * T, "the rows form of the block: a non-empty list of positions"
     return L.BlockDesc(B, T, Cc, H, _ptr(ln1), _ptr(attn_w), _ptr(proj_w), _ptr(ln2), _ptr(fc_w), _ptr(mlp_w),
                        _ptr(rope[0]), _ptr(rope[1]), _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq,
                        float(dropout_p), int(dropout_seed), _ptr(mask.qbounds), _ptr(p1), _ptr(p2), int(ln_partial_mode), _ptr(mask.exact),
@@ -446,8 +446,9 @@ def _block_desc(B, T, Cc, H, params, rope, mask: MaskSpec, dropout_p=0.0, dropou
 
 def block_fwd(x, params, rope, H, mask: MaskSpec, dropout_p=0.0, dropout_seed=0, out_rows=None):
     """One transformer block forward.  Returns (y, act) where act is the opaque saved-activation buffer.
-    out_rows (int64 (n,), ascending rows of the [B*T, C] activation; dropout 0): only those positions of the output are
-    wanted — y is [n, C], the MLP half runs on them alone (include/omnibiote_hip.h, obte_block_desc::out_rows)."""
+    out_rows (int64 (n,), ascending distinct rows of the [B*T, C] activation): only those positions of the output are
+    wanted — y is [n, C], the MLP half runs on them alone (include/omnibiote_hip.h, obte_block_desc::out_rows).  With dropout
+    the mask of the MLP projection (site 3) is that of the [n, C] output — element (i, c) — in forward and backward alike."""
     _need(x, "x")
     B, T, Cc = x.shape
     for i, w in enumerate(params):

@@ -723,9 +723,11 @@ def test_forward_rows_returns_the_listed_positions_of_the_full_forward():
         if k in grads["rows"]:   # (lm_head takes no part in an embeddings-only graph)
             assert torch.equal(p.grad.float(), grads["rows"][k]), "checkpointed " + k
     m.config.checkpoint_freq = 0
-    TE.set_dropout(m, 0.1)             # dropout on: full block, then the rows (same call, same shapes)
+    TE.set_dropout(m, 0.1)             # dropout on: the same call and shapes (the MLP projection's mask is drawn for the rows)
     torch.manual_seed(5)
-    assert tuple(m(ids, attn_mask=mask, return_embeddings=True, rows=rows).shape) == (70, C)
+    outd = m(ids, attn_mask=mask, return_embeddings=True, rows=rows)
+    assert tuple(outd.shape) == (70, C) and torch.isfinite(outd.float()).all()
+    outd.backward(gsel)
     with pytest.raises(ValueError):
         m(ids, attn_mask=mask, rows=rows[:0])
 

@@ -919,6 +919,54 @@ def test_block_dropout_fwd_bwd_vs_oracle(monkeypatch, grouped):
         close(gg, gr, atol=0.03 * gr.abs().max().item() + 1e-3, rtol=2.0 ** -5, what="block dropout d" + n)
 
 
+@pytest.mark.parametrize("grouped", ["0", "1"])
+def test_block_rows_form_with_dropout_vs_oracle(monkeypatch, grouped):
+    """The rows form of the block (obte_block_desc::out_rows) with all three dropout sites on: sites 1 and 2 (attention
+    probabilities, attention projection) as in the full block, site 3 (MLP projection) on the [n, C] output — against the oracle
+    fed the restated masks, forward and every gradient."""
+    monkeypatch.setenv("OBTE_GROUPED_WGRAD", grouped)
+    B, T, C, H, p, n_rows = 2, 64, 128, 2, 0.15, 29
+    hs = C // H
+    cfg = R.RefConfig(block_size=T, vocab_size=256, n_layer=1, n_head=H, n_embd=C)
+    w = {k: v.to(BF) for k, v in R.hash_weights(cfg).items()}
+    pre = "transformer.h.0."
+    names = ["ln_1.weight", "attn.c_attn.weight", "attn.c_proj.weight", "ln_2.weight", "mlp.c_fc.weight", "mlp.c_proj.weight"]
+    rows = torch.sort(torch.randperm(B * T, generator=torch.Generator().manual_seed(8))[:n_rows]).values
+    x, dy = rnd(B, T, C, seed=1), rnd(n_rows, C, seed=2, scale=0.1)
+    tab = R.cast_rope_table(R.rope_table(hs, T), BF)
+    m_attn = R.dropout_scale_mask((B, H, T, T), p, SEED, 1)
+    m_res = R.dropout_scale_mask((B, T, C), p, SEED, 2)
+    m_mlp = R.dropout_scale_mask((n_rows, C), p, SEED, 3)
+    wf = {k: v.float().requires_grad_(True) for k, v in w.items()}
+    xf = x.float().requires_grad_(True)
+    import torch.nn.functional as F
+    h1 = R.layer_norm(xf, wf[pre + "ln_1.weight"])
+    qkv = F.linear(h1, wf[pre + "attn.c_attn.weight"])
+    q, k, v = qkv.split(C, dim=2)
+    q = R.apply_rope(q.reshape(B, T, H, hs), tab).transpose(1, 2)
+    k = R.apply_rope(k.reshape(B, T, H, hs), tab).transpose(1, 2)
+    v = v.reshape(B, T, H, hs).transpose(1, 2)
+    y = (torch.softmax((q @ k.transpose(-2, -1)) * (8.0 / C), dim=-1) * m_attn) @ v
+    y = y.transpose(1, 2).contiguous().view(B, T, C)
+    x1 = (xf + F.linear(y, wf[pre + "attn.c_proj.weight"]) * m_res).reshape(-1, C)[rows]
+    a = R.gelu_erf(F.linear(R.layer_norm(x1, wf[pre + "ln_2.weight"]), wf[pre + "mlp.c_fc.weight"]))
+    ref = x1 + F.linear(a, wf[pre + "mlp.c_proj.weight"]) * m_mlp
+    ref.backward(dy.float())
+    from omnibiote_amd.model import rope_tables
+    o = ops()
+    params = tuple(w[pre + n].to(DEV) for n in names)
+    rope = rope_tables(tab.to(DEV))
+    spec = o.MaskSpec()
+    rows_d = rows.to(DEV)
+    yg, act = o.block_fwd(x.to(DEV), params, rope, H, spec, p, SEED, out_rows=rows_d)
+    close(yg, ref, atol=4e-2, rtol=2.0 ** -6, what="block rows dropout fwd")
+    dx, grads = o.block_bwd(x.to(DEV), dy.to(DEV), act, params, rope, H, spec, dropout_p=p, dropout_seed=SEED, out_rows=rows_d)
+    close(dx, xf.grad, atol=2e-2, rtol=2.0 ** -5, what="block rows dropout dx")
+    for n, gg in zip(names, grads):
+        gr = wf[pre + n].grad
+        close(gg, gr, atol=0.03 * gr.abs().max().item() + 1e-3, rtol=2.0 ** -5, what="block rows dropout d" + n)
+
+
 @pytest.mark.parametrize("hs,mode", [(64, "complex"), (128, "cos_only")])
 def test_gemm_rope_epilogue_equals_projection_then_rope(hs, mode):
     """c_attn with RoPE fused in its epilogue == plain projection followed by the stand-alone RoPE kernel."""
