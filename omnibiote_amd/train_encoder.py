@@ -248,6 +248,8 @@ class TrainStep:
     def _loss_backward(self, logits, targets, mask, n_accum):
         if self.loss_impl == "fused" and self.fused_loss_fn is not None:
             loss, dlogits = self.fused_loss_fn(logits, targets, mask, n_accum)
+            if logits.is_cuda:
+                self._order_backward()
             logits.backward(dlogits)
             return loss.detach()
         if self.loss_impl == "fused":
@@ -267,6 +269,11 @@ class TrainStep:
 
     def _order_backward(self):
         """Pipelined micro-batches: this backward may start only after the previous micro-batch's backward finished."""
+        if getattr(self, "_join_side_streams", False):   # the isolated last pass of a DDP-wrapped model: everything before it is done
+            self._join_side_streams = False
+            for st in self._streams:
+                torch.cuda.current_stream().wait_stream(st)
+            return
         if self._order is not None:   # per-group events instead (model.BackwardOrder); _prev_bwd_done is its fallback
             return
         if self._prev_bwd_done is not None:
@@ -448,8 +455,9 @@ class TrainStep:
             isolate_last = last and hasattr(self.model, "no_sync")
             side = pipelined and not isolate_last
             if pipelined and isolate_last:
-                for st in self._streams:
-                    main.wait_stream(st)
+                # its forward still runs beside the previous backward passes (it only reads weights); the caller's stream joins
+                # the side streams right before its backward (_order_backward)
+                self._join_side_streams = True
                 self._prev_bwd_done = None
             self._slot = (j % ns) if side else 0
             self._order = None
