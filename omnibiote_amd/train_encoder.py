@@ -279,6 +279,17 @@ class TrainStep:
         if self._prev_bwd_done is not None:
             torch.cuda.current_stream().wait_event(self._prev_bwd_done)
 
+    def _pass_targets(self, j: int, k: int):
+        """The labels of the masked positions of pass j in _pass_rows' order, when the host prelude shipped them; else None."""
+        lists = getattr(self, "_mask_targets_host", None)
+        if lists is None:
+            return None
+        lists = lists[j * k:(j + 1) * k]
+        if k == 1:
+            return lists[0]
+        keep = [t for t in lists if t.numel() > 0]
+        return torch.cat(keep) if keep else lists[0]
+
     def _pass_rows(self, j: int, k: int, rows_per_mb: int):
         """Masked positions of pass j (micro-batches j*k .. j*k + k-1) as row indices into the pass's k * mini rows, and —
         for k > 1 — the weight 1 / (masked tokens of its own micro-batch) of each."""
@@ -338,7 +349,8 @@ class TrainStep:
             emb_rows = emb.reshape(-1, emb.shape[-1]).index_select(0, rows)
         with torch.no_grad():
             logits = core.lm_head(emb_rows)                # (n_masked, V): model.py:253 on the rows the loss keeps (:304)
-            loss, dl = ops.masked_ce_rows(logits, y.reshape(-1).index_select(0, rows), None, n_accum, row_weights=weights)
+            tg = self._pass_targets(self._mb, k)
+            loss, dl = ops.masked_ce_rows(logits, tg if tg is not None else y.reshape(-1).index_select(0, rows), None, n_accum, row_weights=weights)
         del logits
         self._order_backward()
         wm = float(core.lm_head.output_mult) / float(core.lm_head.width_mult())
@@ -360,6 +372,7 @@ class TrainStep:
         if st is None:
             st = dict(mask_pin=torch.empty((rows, T), dtype=torch.bool).pin_memory(), rows_pin=torch.empty(rows * T, dtype=torch.int64).pin_memory(),
                       mask_dev=torch.empty((rows, T), dtype=torch.bool, device=dev), rows_dev=torch.empty(rows * T, dtype=torch.int64, device=dev),
+                      tgt_pin=torch.empty(rows * T, dtype=torch.int64).pin_memory(), tgt_dev=torch.empty(rows * T, dtype=torch.int64, device=dev),
                       done=None)
             if len(self._host_bufs) >= 4:          # --batch_ramp walks through many row counts: keep a few
                 self._host_bufs.pop(next(iter(self._host_bufs)))
@@ -377,8 +390,13 @@ class TrainStep:
             if total:
                 st["rows_pin"].numpy()[:total] = np.concatenate(idx)
                 st["rows_dev"][:total].copy_(st["rows_pin"][:total], non_blocking=True)
+                # the labels of those positions (the uncorrupted ids), in the same order: the compact CE needs no device-side gather
+                per_ids = ids_h.reshape(n_accum, -1)
+                st["tgt_pin"].numpy()[:total] = np.concatenate([per_ids[j][idx[j]] for j in range(n_accum)])
+                st["tgt_dev"][:total].copy_(st["tgt_pin"][:total], non_blocking=True)
             off = np.concatenate([[0], np.cumsum(sizes)])
             lists = [st["rows_dev"][int(off[j]):int(off[j + 1])] for j in range(n_accum)]
+            self._mask_targets_host = [st["tgt_dev"][int(off[j]):int(off[j + 1])] for j in range(n_accum)]
         st["done"] = torch.cuda.current_stream().record_event()
         mask = st["mask_dev"]
         return input_ids.masked_fill(mask, MASK_TOKEN), mask, lists
@@ -397,6 +415,7 @@ class TrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         # the two row-compact readouts need the HIP kernels; a stub model / torch loss (CPU tests) takes the generic graph
         sparse_rows = self.lm_head_impl in ("dense", "masked") and self.loss_impl == "fused" and self.fused_loss_fn is None
+        self._mask_targets_host = None   # set by the host prelude when it runs (labels of the masked positions)
         if mlm_mask is None and input_ids_host is not None and input_ids.is_cuda:
             masked_ids, mask, lists = self._host_prelude(input_ids, input_ids_host, rows, n_accum, sparse_rows)
             if sparse_rows:
