@@ -4,9 +4,13 @@
 
 A *step* is one optimizer step of the reference's training loop (training/train_encoder.py:241-323) on this rank's
 128 rows of 1024 synthetic tokens: 16 accumulated micro-batches of mini_batch_size 8 through the drop-in
-``OmniBioTA`` (small: 8L/1024d/8h, bf16, dropout 0), masked-LM loss over the full 65 536-way logits, backward,
-global-norm clip, MuAdamW-grouped AdamW, LinearLR — BASELINE.json configs[1] at N=1 and configs[2]
-(batch_size 1024 over 8 ranks) at N=8.  Per-rank work is fixed as N grows (weak scaling).  Inputs are resident in
+``OmniBioTA`` (small: 8L/1024d/8h, bf16, dropout 0), the 65 536-way readout and masked-LM cross entropy evaluated on the
+MLM-masked positions only (``--readout masked``, the default since round 3: the loss multiplies every other position by
+zero, train_encoder.py:304, so loss and gradients are the reference's; the last block's MLP half and ln_f run on those
+positions too — ``model.forward(rows=...)``; ``--readout dense`` / ``dense_full`` compute every position's logits as
+rounds 1-2 did and are reported as variants), backward, global-norm clip, MuAdamW-grouped AdamW, LinearLR — BASELINE.json
+configs[1] at N=1 and configs[2] (batch_size 1024 over 8 ranks) at N=8.  At N=1 the line also carries ``other_configs``:
+driver-timed steps of BASELINE configs 4 (small, ctx 4096) and 5 (large 24L/2048d/16h, its single-GPU leg).  Per-rank work is fixed as N grows (weak scaling).  Inputs are resident in
 HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects: ``roofline`` for the dominant kernel family (bf16 MFMA GEMM; per-launch durations from HIP events
@@ -39,6 +43,9 @@ READOUT_TEXT = {"dense": "full 65536-way logits for every position in the forwar
                 "masked": "65536-way readout + CE on the MLM-masked positions only (SURVEY §8f rank 1: the loss multiplies every other position by zero, "
                           "train_encoder.py:304 — same loss, same gradients); the positions are handed to model.forward(rows=...), so the last block's MLP half "
                           "and ln_f run on them alone as well"}
+# leads config.workload (the driver keeps the first 128 characters of it): which readout ran
+READOUT_LEAD = {"masked": "masked-positions readout+CE, rows-form last block", "masked_full": "masked-positions readout+CE, full last block",
+                "dense": "every-position logits fwd, masked-rows readout bwd", "dense_full": "reference-literal dense logits + dense dlogits"}
 CONFIGS = {
     "small": dict(n_layer=8, n_embd=1024, n_head=8, ctx_len=1024),
     "small4k": dict(n_layer=8, n_embd=1024, n_head=8, ctx_len=4096),
@@ -67,6 +74,7 @@ def parse():
     p.add_argument("--no_roofline", action="store_true")
     p.add_argument("--dense_mask", action="store_true",
                    help="pass the reference's dense additive (B,H,T,T) mask (expand view) instead of key ranges")
+    p.add_argument("--no_other_configs", action="store_true", help="skip the driver-timed steps of BASELINE configs 4 (small4k) and 5 (large)")
     p.add_argument("--no_variants", action="store_true", help="skip the extra measurements (masked-rows readout, dropout 0.1, dense-mask calling convention)")
     p.add_argument("--pipeline_streams", type=int, default=2, choices=[1, 2, 3],
                    help="2: forward of micro-batch j+1 beside the backward of micro-batch j on a second HIP stream (bitwise the same results)")
@@ -265,6 +273,77 @@ def cpu_baseline(cfg, mini_rows=8, steps=5, warmup=2, device="cpu", rows=None):
                       f"fp32: median of {n32} steps, each after {warmup} warm-ups"}
 
 
+def measure_other_config(name: str, rows: int, a, dev, steps: int = 2, warmup: int = 1):
+    """One more BASELINE config on this GPU, driver-timed inside the same run (N = 1 only; never the headline): its own model,
+    its own tuned plans, `warmup` + `steps` optimizer steps of `rows` rows through the same TrainStep as the headline, then one
+    single-stream step under the library's launch profiler for the kernel-family fractions."""
+    from omnibiote_amd import _lib, tune
+    from omnibiote_amd import train_encoder as TE
+    import contextlib
+    import io
+    cfg = CONFIGS[name]
+    T = cfg["ctx_len"]
+    t_begin = time.perf_counter()
+    saved = (a.rows_per_rank,)
+    a.rows_per_rank = rows
+    try:
+        h = harness_args(cfg, a, 1)
+    finally:
+        (a.rows_per_rank,) = saved
+    torch.manual_seed(1234)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = TE.build_model(h, dev)
+    n_params = m.get_num_params()
+    tune.tune_model_shapes(a.mini_batch_size * T, cfg["n_embd"], 2 ** 16, device=dev)
+    opt, sched = TE.build_optimizer(m, h, 1000)
+    ts = TE.TrainStep(m, opt, sched, mini_batch_size=a.mini_batch_size, n_head=cfg["n_head"], lm_head_impl=a.readout,
+                      pipeline_streams=a.pipeline_streams, backward_order=a.backward_order, rows_forward=not a.full_last_block)
+    rng = np.random.default_rng(4321)
+    host = [TE.synthetic_rows(rows, T, 2 ** 16, rng, single_document=True) for _ in range(2)]
+    batches = [torch.from_numpy(hb).to(dev) for hb in host]
+    set_up_s = time.perf_counter() - t_begin
+    loss = None
+    for i in range(warmup):
+        loss = ts(batches[i % 2], input_ids_host=host[i % 2])["loss"]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = ts(batches[i % 2], input_ids_host=host[i % 2])["loss"]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    value = rows * T * steps / el
+    fpt = TE.flops_per_token(n_params, cfg["n_layer"], cfg["n_embd"], T)
+    fpt_exec = TE.flops_per_token_executed(n_params, cfg["n_layer"], cfg["n_embd"], T, a.readout, not a.full_last_block)
+    out = {"workload": f"{READOUT_LEAD['masked_full' if (a.readout == 'masked' and a.full_last_block) else a.readout]}; OmniBioTA {name} "
+                       f"({cfg['n_layer']}L/{cfg['n_embd']}d/{cfg['n_head']}h) ctx={T}, {rows} rows = {rows // a.mini_batch_size} micro-batches of "
+                       f"{a.mini_batch_size}, dropout {a.dropout:g}, single-document rows, one GPU",
+           "value": round(value, 1), "unit": "tokens/s", "steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 2),
+           "flops_per_token_executed": fpt_exec, "mfma_fraction_whole_step_executed": round(value * fpt_exec / (PEAK_BF16_TFLOPS * 1e12), 4),
+           "reference_formula": {"flops_per_token": fpt, "model_flops_fraction": round(value * fpt / (PEAK_BF16_TFLOPS * 1e12), 4)},
+           "final_loss": round(float(loss.item()), 4), "set_up_s": round(set_up_s, 1)}
+    if not bool(torch.isfinite(loss).item()):
+        raise SystemExit(f"bench.py: other_configs[{name}]: non-finite loss")
+    if not a.no_roofline:
+        ts.pipeline_streams = 1
+        _lib.lib().obte_profile_enable(1)
+        ts(batches[0], input_ids_host=host[0])
+        torch.cuda.synchronize()
+        ms, dims, kind = collect_profile()
+        _lib.lib().obte_profile_enable(0)
+        if len(ms):
+            r = roofline_from_profile(ms, dims, kind, 1)
+            fam = {"gemm_family": {k: r[k] for k in ("achieved", "frac", "launches_per_step", "avg_launch_ms", "share_of_profiled_time")}}
+            for k in ("attn_fwd", "attn_bwd"):
+                if k in r["breakdown"]:
+                    fam[k] = r["breakdown"][k]
+            fam["gemm_family"]["unit"] = "TFLOP/s"
+            out["families_single_stream_profiled_step"] = fam
+    del ts, opt, sched, m, batches
+    torch.cuda.empty_cache()
+    out["wall_s"] = round(time.perf_counter() - t_begin, 1)
+    return out
+
+
 class Watchdog:
     """Fail loudly instead of hanging: if the guarded phase (process-group set-up, the first collective, the timed steps)
     has not finished after ``seconds`` of wall time, say where on stderr and end THIS process with a non-zero code —
@@ -422,10 +501,8 @@ def main():
     tokens_per_step = a.rows_per_rank * T * world   # no PAD in the synthetic rows: all tokens count (train_encoder.py:350)
     value = tokens_per_step * a.steps / elapsed
     fpt = TE.flops_per_token(n_params, cfg["n_layer"], cfg["n_embd"], T)
-    skipped = {"dense": 4.0 * cfg["n_embd"] * 65536 * 0.85, "dense_full": 0.0, "masked": 6.0 * cfg["n_embd"] * 65536 * 0.85}[a.readout]
-    if a.readout == "masked" and not a.full_last_block:   # the last block's MLP half (8 C^2 parameters: 6 FLOP each per token) on the masked positions only
-        skipped += 6.0 * 8.0 * cfg["n_embd"] ** 2 * 0.85
-    fpt_exec = fpt - skipped   # 15 % of the positions are MLM-masked (train_encoder.py:271); their share of the readout products remains
+    # 15 % of the positions are MLM-masked (train_encoder.py:271); their share of the readout products (and of the last block's MLP half) remains
+    fpt_exec = TE.flops_per_token_executed(n_params, cfg["n_layer"], cfg["n_embd"], T, a.readout, not a.full_last_block)
 
     log(f"timed region done: {value:,.0f} tokens/s")
     tail_guard = Watchdog(900.0, "profiled step + variants (they contain collectives at N > 1)")
@@ -471,7 +548,7 @@ def main():
                     for (name, d0, d1, d2, code), (n, tt) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
                         fl = launch_flops(code, d0, d1, d2)
                         f.write(f"{name:62s} {d0:7d} {d1:7d} {d2:7d} {n:6d} {tt / n * 1e3:9.1f} {fl * n / (tt * 1e-3) / 1e12:8.1f} {tt:8.2f}\n")
-    # Not the headline — the same step in the other regimes a user of the reference meets, each timed over 3 steps after
+    # Not the headline — the same step in the other regimes a user of the reference meets, each timed over 10 steps after
     # 2 warm-ups and reported beside `value`:
     #   dense_logits_forward / dense_dlogits_full_backward   the readout computed for every position in the forward, and also
     #                        with the dense d(logits) backward (the reference's literal graph) — same loss and gradients as the
@@ -482,7 +559,7 @@ def main():
     #                        (train_encoder.py:290-292) instead of key ranges.
     variants = None
 
-    def timed_variant(n=3, w=2):
+    def timed_variant(n=10, w=2):
         for i in range(w):
             step(batches[i % len(batches)])
         sync()
@@ -502,25 +579,25 @@ def main():
         variants = {}
         if a.readout != "masked":
             _step.lm_head_impl = "masked"
-            variants["masked_rows_readout"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
+            variants["masked_rows_readout"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 10,
                                                "note": "readout + CE on the MLM-masked rows only, forward included; identical loss and gradients"}
             _step.lm_head_impl = a.readout
         if a.readout == "masked" and _step.rows_forward:
             _step.rows_forward = False
-            variants["masked_readout_full_last_block"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
+            variants["masked_readout_full_last_block"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 10,
                                                           "note": "the masked-positions readout on model.forward(return_embeddings=True) of every position: the last "
                                                                   "block's MLP half and ln_f computed for all positions, rows gathered afterwards (the headline hands "
                                                                   "the positions to model.forward(rows=...)); identical loss and gradients"}
             _step.rows_forward = True
         if a.readout != "dense":
             _step.lm_head_impl = "dense"
-            variants["dense_logits_forward"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
+            variants["dense_logits_forward"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 10,
                                                 "note": "logits of EVERY position in the forward (model.py:253 as the reference calls it), readout backward over "
                                                         "the masked rows; identical loss and gradients (rounds 1-2 quoted this form)"}
             _step.lm_head_impl = a.readout
         if a.readout != "dense_full":
             _step.lm_head_impl = "dense_full"
-            variants["dense_dlogits_full_backward"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
+            variants["dense_dlogits_full_backward"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 10,
                                                        "note": "the reference's literal graph: dense [M,V] d(logits) and full-size readout backward products "
                                                                "(85 % of those rows are exact zeros); identical loss and gradients"}
             _step.lm_head_impl = a.readout
@@ -532,21 +609,35 @@ def main():
                 dist.broadcast_object_list(box, src=0)
                 if rank != 0:
                     tune.import_plans(box[0])
-            variants["two_micro_batches_per_pass"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
+            variants["two_micro_batches_per_pass"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 10,
                                                       "note": "an execution option, off in the headline: two micro-batches of 8 rows go through the model in one "
                                                               "16-row pass, every masked row weighted by its own micro-batch's count, so loss and gradients are those of "
                                                               "separate passes (tested); every kernel sees twice the rows per launch"}
             _step.per_pass = 1
         if a.dropout == 0.0:
             TE.set_dropout(m, 0.1)
-            variants["dropout_0.1"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
+            variants["dropout_0.1"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 10,
                                        "note": "the reference's default --dropout 0.1 (fused counter-based masks at all four sites)"}
             TE.set_dropout(m, 0.0)
         if not a.dense_mask:
             _step.mask_impl = "dense"
-            variants["dense_mask_calling_convention"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 3,
+            variants["dense_mask_calling_convention"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 10,
                                                          "note": "attn_mask passed as the reference's dense additive (B,H,T,T) expand() view"}
             _step.mask_impl = "ranges"
+    # the headline's plan table, before other configs add their shapes to the library's
+    plans = tune.export_plans()
+    other_configs = None
+    if world == 1 and not a.no_other_configs and a.config == "small":
+        # BASELINE configs 4 and 5 (their single-GPU legs), driver-timed in this same run: never the headline
+        other_configs = {}
+        for oname, orows in (("small4k", 32), ("large", 32)):
+            log(f"other config {oname}")
+            try:
+                other_configs[oname] = measure_other_config(oname, orows, a, dev)
+            except SystemExit:
+                raise
+            except Exception as e:   # noqa: BLE001 — the headline does not depend on it; say what happened
+                other_configs[oname] = {"value": None, "note": repr(e)[:300]}
     if world > 1:
         dist.barrier()
     tail_guard.__exit__()
@@ -556,7 +647,6 @@ def main():
             raise SystemExit(f"bench.py: rank {rank}: non-finite loss {float(x.item())}")
     if rank == 0:
         import hashlib
-        plans = tune.export_plans()
         plan_rows = [f"{'k' if r['a_kmajor'] else 'm'}{'k' if r['b_kmajor'] else 'n'} epi{r['epilogue']} {r['M']}x{r['N']}x{r['K']}: "
                      f"{STRUCT_NAMES.get(r['variant'], r['variant'])} bn{r['bn']} split{r['splits']}" for r in plans]
         plan_hash = hashlib.sha256("\n".join(plan_rows).encode()).hexdigest()[:16]
@@ -577,7 +667,8 @@ def main():
             "metric": METRIC if a.config == "small" else f"MLM train tokens/sec, {a.config} ctx={T}", "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU over gloo; not a measurement)",
-            "config": {"workload": f"OmniBioTA {a.config} ({cfg['n_layer']}L/{cfg['n_embd']}d/{cfg['n_head']}h) ctx={T} MLM train step: "
+            "config": {"workload": f"{READOUT_LEAD['masked_full' if (a.readout == 'masked' and a.full_last_block) else a.readout]}; "
+                                   f"OmniBioTA {a.config} ({cfg['n_layer']}L/{cfg['n_embd']}d/{cfg['n_head']}h) ctx={T} MLM train step: "
                                    f"{a.rows_per_rank} rows/rank = {a.rows_per_rank // a.mini_batch_size} micro-batches of {a.mini_batch_size}, "
                                    f"{READOUT_TEXT[a.readout]}, dropout {a.dropout:g}, {'multi' if a.multi_document else 'single'}-document rows",
                        "global_batch_rows": a.rows_per_rank * world, "mini_batch_size": a.mini_batch_size, "seq_len": T,
@@ -598,6 +689,8 @@ def main():
         }
         if variants:
             out["variants"] = variants
+        if other_configs:
+            out["other_configs"] = other_configs
         if world == 1 and not a.no_cpu_baseline:
             log(f"cpu_baseline on {usable_cores()} cores")
             out["cpu_baseline"] = cpu_baseline(cfg)

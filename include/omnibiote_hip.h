@@ -9,7 +9,10 @@
  *     caller's stream (a hipStream_t passed as void*; NULL = the null stream).
  *   - bf16 tensors are passed as uint16_t* (bit pattern of bfloat16), dense row-major unless a stride
  *     argument says otherwise.  "rows" always means tokens (B*T).
- *   - re-entrant: no global mutable state besides the thread-local error string.
+ *   - re-entrant: callable from any thread (autograd's backward workers call in without the GIL).  Process-wide state is
+ *     the thread-local error string plus two mutex-protected tables: the tuned GEMM plan table (obte_gemm_plan_set /
+ *     _clear; read by every GEMM launch) and the opt-in launch profiler's records (obte_profile_*).  Nothing else persists
+ *     between calls.
  */
 #ifndef OMNIBIOTE_HIP_H
 #define OMNIBIOTE_HIP_H
@@ -135,10 +138,14 @@ int obte_gemm_plan_set(int a_kmajor, int b_kmajor, int epilogue, int64_t M, int6
 int obte_gemm_plan_clear(void);
 int64_t obte_gemm_workspace_bytes_max(int64_t M, int64_t N, int64_t K);
 
-/* Grouped launch: `count` (1..4) independent GEMMs of ONE layout and epilogue (OBTE_EPI_NONE or OBTE_EPI_ADD) in a
- * single grid of 256x256 tiles, each tile running its full K (>= 128) — no split-K workspace, no reduce launches.
- * Replaces, in one call, the four weight-gradient products autograd issues for the nn.Linear layers of one block
- * (training/model.py:102,151,163,166 under loss.backward(), train_encoder.py:462): dW_mlp, dW_fc, dW_proj, dW_attn. */
+/* Grouped launch: `count` (1..OBTE_GROUP_MAX) independent GEMMs in a single grid of 256x256 tiles, each tile running its
+ * full K (>= 128) — no split-K workspace, no reduce launches.  The problems may MIX layouts (a_kmajor / b_kmajor per
+ * problem), alpha and the two admissible epilogues (OBTE_EPI_NONE overwrite, OBTE_EPI_ADD accumulate into aux == d): tiles
+ * are dealt so that every XCD gets its share of the long-K problems first.  Replaces, in one call, the four weight-gradient
+ * products autograd issues for the nn.Linear layers of one block (training/model.py:102,151,163,166 under loss.backward(),
+ * train_encoder.py:462: dW_mlp, dW_fc, dW_proj, dW_attn, K = tokens) together with the c_attn input gradient (K = 3C) on
+ * the CUs those leave idle; and the readout's input gradient beside its weight gradient (model.py:253). */
+#define OBTE_GROUP_MAX 6
 int obte_gemm_grouped_bf16(const obte_gemm_args* gs, int count, obte_stream s);
 
 /* ---- dropout (training/model.py:83-84,160,204) -------------------------------------------------------------------
@@ -233,7 +240,8 @@ int obte_embedding_bwd_dropout(const int64_t* idx, const int32_t* order, const o
 /* ---- masked-LM cross entropy, forward + backward in one pass (training/train_encoder.py:301-305) -------------
  * loss_sum[0] += sum over rows with mlm_mask!=0 of (logsumexp(logits[r]) - logits[r,target[r]]) * row_scale
  * dlogits[r,:] = (softmax(logits[r]) - onehot(target[r])) * row_scale * grad_scale[0]  for masked rows, else 0,
- * where row_scale = 1/n_accum and grad_scale points at a device fp32 (1/mask_count), so no host sync is needed.
+ * where row_scale = 1/n_accum and grad_scale points at a device fp32 (1/mask_count), so no host sync is needed
+ * (obte_masked_ce_rows also accepts grad_scale = NULL, meaning 1: its caller knows the count and folds it into row_scale).
  * vocab % 8 == 0, vocab <= 65536*2. */
 int obte_masked_ce_fwd_bwd(const obte_bf16* logits, const int64_t* target, const uint8_t* mlm_mask,
                            const float* grad_scale, float row_scale, float* loss_sum, float* row_loss,

@@ -598,7 +598,6 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
     const float scale2 = p.scale * LOG2E;
 
-    if (t_begin < t_end) issue_kv(t_begin, 0);
     dma_wait_all();
     prologue_wait_all();
     __syncthreads();

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void masked_ce_kernel(const bf16* __restrict__
     const float rsc = row_scale_vec ? row_scale * row_scale_vec[r] : row_scale;   // per-row weight (compact form, several micro-batches in one call)
     if (threadIdx.x == 0 && row_loss) row_loss[r] = (lse - bf2f(lrow[tgt])) * rsc;
     // pass 2 (row is L2-resident): gradient
-    const float gs = rsc * grad_scale[0];
+    const float gs = grad_scale ? rsc * grad_scale[0] : rsc;   // nullable device-side scale: NULL = 1
     for (int64_t c = (int64_t)threadIdx.x * 8; c < vocab; c += 256 * 8) {
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(lrow + c);
         bf16x8 o;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void masked_ce_regs_kernel(const bf16* __re
     tgt = tgt < 0 ? 0 : (tgt >= vocab ? vocab - 1 : tgt);
     const float rsc = row_scale_vec ? row_scale * row_scale_vec[r] : row_scale;
     if (threadIdx.x == 0 && row_loss) row_loss[r] = (lse - bf2f(lrow[tgt])) * rsc;
-    const float gs = rsc * grad_scale[0];
+    const float gs = grad_scale ? rsc * grad_scale[0] : rsc;   // nullable device-side scale: NULL = 1
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int64_t c = ((int64_t)i * 256 + threadIdx.x) * 8;
@@ -640,7 +640,7 @@ extern "C" int obte_rows_scatter_bf16(const obte_bf16* src, const int64_t* rows,
 extern "C" int obte_masked_ce_rows(const obte_bf16* logits, const int64_t* target, const int64_t* row_index, const float* grad_scale,
                                    float row_scale, const float* row_scale_vec, float* row_loss, obte_bf16* dlogits_rows, int64_t n_rows,
                                    int64_t total_rows, int64_t vocab, obte_stream s) {
-    OBTE_REQUIRE(logits && target && grad_scale && dlogits_rows && row_loss, "obte_masked_ce_rows: null pointer");
+    OBTE_REQUIRE(logits && target && dlogits_rows && row_loss, "obte_masked_ce_rows: null pointer");
     OBTE_REQUIRE(n_rows > 0 && n_rows <= total_rows && total_rows < (1ll << 31) && vocab > 0 && vocab % 8 == 0,
                  "obte_masked_ce_rows: need 0 < n_rows <= total_rows and vocab %% 8 == 0");
     OBTE_REQUIRE(row_index || n_rows == total_rows, "obte_masked_ce_rows: without a row list, logits and target hold exactly the n_rows listed rows");

@@ -642,7 +642,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v3_kernel(GemmParams p) {
 // class 1 = the rest — and when both class sizes divide by 8 every XCD receives its share of class 0 first, then
 // its share of class 1, so the short tiles start on the CUs that got no long one and behind the first finishers.
 // Layout and accumulate/overwrite are per problem (uniform branches; aux == null means overwrite).
-constexpr int GROUP_MAX = 6;
+constexpr int GROUP_MAX = OBTE_GROUP_MAX;   // include/omnibiote_hip.h
 struct GroupParams {
     GemmParams g[GROUP_MAX];
     int first_wg[GROUP_MAX + 1];

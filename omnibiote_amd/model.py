@@ -110,6 +110,7 @@ def _require_hip(t: torch.Tensor, what: str) -> None:
 #   store: who owns those fp32 buffers (one ``LnPartialStore`` per TrainStep; a process-wide default for bare uses of the
 #       context manager).
 import contextvars
+import os
 
 
 class LnPartialStore:
@@ -555,6 +556,8 @@ class Block(nn.Module):
         if self.attn.autoregressive:
             raise NotImplementedError("autoregressive=True is not used by the encoder and not implemented")
         B, T, C = x.shape
+        if out_rows is not None:
+            _check_rows(out_rows, B * T, 1)
         mask = ops.MaskSpec.from_user(attn_mask, B, T, self.attn.n_head, x.device)
         cos, sin = self.attn.rope()
         # one dropout probability per block, as in the reference (config.dropout feeds all three nn.Dropout modules)
@@ -562,6 +565,24 @@ class Block(nn.Module):
         seed = _new_seed() if p > 0 else 0
         return _BlockFn.apply(x, self.ln_1.weight, self.attn.c_attn.weight, self.attn.c_proj.weight, self.ln_2.weight,
                               self.mlp.c_fc.weight, self.mlp.c_proj.weight, cos, sin, self.attn.n_head, mask, p, seed, out_rows)
+
+
+def _check_rows(rows, total: int, n_blocks: int) -> None:
+    """The contract of ``OmniBioTA.forward(rows=)`` / ``Block.forward(out_rows=)``: a non-empty int64 vector on the GPU of
+    ASCENDING, DISTINCT positions in [0, total).  Shape, dtype and device are checked on every call (no device read).  The
+    values are the caller's responsibility — duplicates are unsupported (the scatter of the block backward would keep one of
+    the contributions instead of their sum) and the gather clamps an out-of-range index instead of faulting — unless
+    OBTE_CHECK_ROWS=1, which verifies bounds and strict monotonicity at the price of a device round trip per call."""
+    if not torch.is_tensor(rows) or rows.dtype != torch.int64 or rows.dim() != 1 or not rows.is_cuda:
+        raise ValueError("OmniBioTA.forward: rows must be a 1-D int64 tensor on the GPU")
+    if rows.numel() == 0 or n_blocks == 0:
+        raise ValueError("OmniBioTA.forward: rows must list at least one position (and the model needs a block)")
+    if rows.numel() > total:
+        raise ValueError(f"OmniBioTA.forward: {rows.numel()} rows listed, the batch has {total} positions")
+    if os.environ.get("OBTE_CHECK_ROWS") == "1":
+        r = rows.detach().cpu()
+        if int(r[0]) < 0 or int(r[-1]) >= total or (r.numel() > 1 and not bool((r[1:] > r[:-1]).all())):
+            raise ValueError(f"OmniBioTA.forward: rows must be strictly ascending positions in [0, {total})")
 
 
 @dataclass
@@ -637,8 +658,8 @@ class OmniBioTA(nn.Module):
             order = None
         x = _EmbeddingFn.apply(idx, wte, p, _new_seed() if p > 0 else 0, order)
         n_blocks = len(self.transformer.h)
-        if rows is not None and (rows.numel() == 0 or n_blocks == 0):
-            raise ValueError("OmniBioTA.forward: rows must list at least one position (and the model needs a block)")
+        if rows is not None:
+            _check_rows(rows, b * t, n_blocks)
         for i, block in enumerate(self.transformer.h):
             last_rows = rows if (rows is not None and i == n_blocks - 1) else None
             if self.config.checkpoint_freq > 0 and i % self.config.checkpoint_freq == 0:

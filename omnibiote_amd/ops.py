@@ -411,27 +411,14 @@ def masked_ce_rows(logits, targets, rows, n_accum: int, row_weights: Optional[to
     if row_weights is not None:
         _need(row_weights, "row_weights", torch.float32); assert row_weights.numel() == n
     # the 1 / n of the mean is known on the host here (the list's length): it travels in the by-value row scale, and the device-side
-    # gradient scale is a constant 1 — no fill launch per call, and the loss is the plain sum of the row losses
-    one = _ones1(logits.device)
+    # gradient scale is a constant 1 (a NULL grad_scale: no persistent [1.0] tensor whose fill another stream would have to be
+    # ordered after) — no fill launch per call, and the loss is the plain sum of the row losses
     row_scale = (1.0 if row_weights is not None else 1.0 / n) / n_accum
     row_loss = torch.empty(n, dtype=torch.float32, device=logits.device)
     dl = torch.empty((n, V), dtype=bf16, device=logits.device)
-    L.check(L.lib().obte_masked_ce_rows(_ptr(logits), _ptr(targets), _ptr(rows), _ptr(one), row_scale, _ptr(row_weights),
+    L.check(L.lib().obte_masked_ce_rows(_ptr(logits), _ptr(targets), _ptr(rows), None, row_scale, _ptr(row_weights),
                                         _ptr(row_loss), _ptr(dl), n, M, V, _stream()), "obte_masked_ce_rows")
     return row_loss.sum(), dl
-
-
-_ONES = {}
-
-
-def _ones1(device) -> torch.Tensor:
-    """A persistent fp32 [1.0] per device (read-only operand of entry points that take a device-side scale)."""
-    key = str(device)
-    t = _ONES.get(key)
-    if t is None:
-        t = torch.ones(1, dtype=torch.float32, device=device)
-        _ONES[key] = t
-    return t
 
 
 def adamw_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, clip_coef=None):

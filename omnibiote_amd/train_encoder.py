@@ -224,8 +224,15 @@ class TrainStep:
         self._host_bufs = {}
         self._ln_store = None
 
+    @staticmethod
+    def _no_inplace() -> bool:
+        """OBTE_NO_INPLACE_ACCUM=1 (A/B switch): every gradient is delivered through autograd's AccumulateGrad (`grad += new`,
+        issued by the engine AFTER a node's backward returned), so no per-group event a node records can cover it: pipelined
+        passes are then ordered as wholes (backward_order="pass": one event after the entire backward)."""
+        return os.environ.get("OBTE_NO_INPLACE_ACCUM") == "1"
+
     def _inplace(self, enabled: bool, ln_partial_mode: int = 0):
-        if self.loss_impl != "fused" or os.environ.get("OBTE_NO_INPLACE_ACCUM") == "1":   # CPU-oracle tests / A-B switch
+        if self.loss_impl != "fused" or self._no_inplace():   # CPU-oracle tests / A-B switch (whole-pass ordering then: __call__)
             return contextlib.nullcontext()
         from .model import LnPartialStore, accumulate_grads_inplace
         if self.fused_loss_fn is not None or os.environ.get("OBTE_NO_LN_PARTIALS") == "1":   # stub models / A-B switch
@@ -267,14 +274,17 @@ class TrainStep:
         loss.backward()
         return loss.detach().float()
 
-    def _order_backward(self):
-        """Pipelined micro-batches: this backward may start only after the previous micro-batch's backward finished."""
+    def _order_backward(self, whole_pass: bool = False):
+        """Pipelined micro-batches: this backward may start only after the previous micro-batch's backward finished.
+        whole_pass: wait for the previous backward as a whole even under per-group ordering — for a graph whose gradients
+        reach the readout weight through AccumulateGrad instead of a node that carries the BackwardOrder (the zero
+        gradients of a pass with nothing masked)."""
         if getattr(self, "_join_side_streams", False):   # the isolated last pass of a DDP-wrapped model: everything before it is done
             self._join_side_streams = False
             for st in self._streams:
                 torch.cuda.current_stream().wait_stream(st)
             return
-        if self._order is not None:   # per-group events instead (model.BackwardOrder); _prev_bwd_done is its fallback
+        if self._order is not None and not whole_pass:   # per-group events instead (model.BackwardOrder); _prev_bwd_done is its fallback
             return
         if self._prev_bwd_done is not None:
             torch.cuda.current_stream().wait_event(self._prev_bwd_done)
@@ -317,7 +327,7 @@ class TrainStep:
             else:
                 loss, dl = ops.masked_ce_rows(logits, y.reshape(-1), rows, n_accum, row_weights=weights)
         del logits
-        self._order_backward()
+        self._order_backward(whole_pass=dl is None)
         if dl is None:    # nothing masked: zero gradients for every parameter (the reference would produce 0/0 = NaN here)
             (emb.sum() * 0 + core.lm_head.weight.sum() * 0).backward()
             return torch.zeros((), dtype=torch.float32, device=x.device)
@@ -338,7 +348,7 @@ class TrainStep:
             # nothing masked in this pass: still hand EVERY parameter a (zero) gradient — lm_head included — or
             # DDP's reducer would wait for it forever when this is the synchronising micro-batch
             emb = self.model(x, attn_mask=attn_mask, return_embeddings=True)
-            self._order_backward()
+            self._order_backward(whole_pass=True)
             (emb.sum() * 0 + core.lm_head.weight.sum() * 0).backward()
             return torch.zeros((), dtype=torch.float32, device=x.device)
         if self.rows_forward:
@@ -480,7 +490,7 @@ class TrainStep:
                 self._prev_bwd_done = None
             self._slot = (j % ns) if side else 0
             self._order = None
-            if side and self.backward_order == "layer" and self.fused_loss_fn is None:
+            if side and self.backward_order == "layer" and self.fused_loss_fn is None and not self._no_inplace():
                 from .model import BackwardOrder
                 self._order = BackwardOrder(self._prev_order_events, self._prev_bwd_done)
             with (torch.cuda.stream(self._streams[j % ns]) if side else contextlib.nullcontext()):
@@ -597,6 +607,18 @@ def build_optimizer(model, args, total_iters: int, fused: bool = True):
 
 def flops_per_token(num_model_params: int, n_layer: int, n_embd: int, ctx_len: int) -> float:
     return 6.0 * num_model_params + 12.0 * n_layer * n_embd * ctx_len   # train_encoder.py:360
+
+
+def flops_per_token_executed(num_model_params: int, n_layer: int, n_embd: int, ctx_len: int, lm_head_impl: str = "masked",
+                             rows_forward: bool = True, vocab: int = 2 ** 16, masked_fraction: float = 0.15) -> float:
+    """FLOP per token the step actually EXECUTES: the reference's 6N + 12LCT minus the products the readout form leaves out on
+    the (1 - masked_fraction) of the positions the loss multiplies by zero (train_encoder.py:304) — "dense": the two backward
+    products of the readout; "masked": all three, and with rows_forward the last block's MLP half (8 C^2 parameters) as well."""
+    skip = 1.0 - masked_fraction
+    skipped = {"dense": 4.0 * n_embd * vocab * skip, "dense_full": 0.0, "masked": 6.0 * n_embd * vocab * skip}[lm_head_impl]
+    if lm_head_impl == "masked" and rows_forward:
+        skipped += 6.0 * 8.0 * n_embd ** 2 * skip
+    return flops_per_token(num_model_params, n_layer, n_embd, ctx_len) - skipped
 
 
 def wrap_ddp(model, device_index: Optional[int], bucket_cap_mb: int = 100):
@@ -842,7 +864,9 @@ def run(args):
         start = int(total_iters * (trained / args.token_budget))
         st = torch.load(f"{args.save_name}_optimizer_{args.resume_from}.pt", map_location=device, weights_only=False)
         opt.load_state_dict(st["optimizer"]); sched.load_state_dict(st["scheduler"])
-    fpt = flops_per_token(n_params, args.n_layer, args.n_embd, args.ctx_len)
+    fpt = flops_per_token(n_params, args.n_layer, args.n_embd, args.ctx_len)   # the reference's MFU formula (:360)
+    # what this step executes: its default readout runs on the ~15 % MLM-masked positions only (fewer FLOP, same gradients)
+    fpt_exec = flops_per_token_executed(n_params, args.n_layer, args.n_embd, args.ctx_len, step.lm_head_impl, step.rows_forward)
     n_steps = total_iters if args.max_steps <= 0 else min(total_iters, start + args.max_steps)
 
     def save(tag):
@@ -869,7 +893,8 @@ def run(args):
             if rank == 0:
                 lrs = [g["lr"] for g in opt.param_groups]
                 print(f"step {i} loss {loss:.4f} lr {lrs[0]:.5f}|{lrs[-1]:.5f} tokens/s {toks / dt:,.0f} "
-                      f"MFMA-frac {toks / dt * fpt / (2.5e15 * world) * 100:.1f}% trained {trained / 1e6:.2f}M", flush=True)
+                      f"MFMA-frac(executed FLOP) {toks / dt * fpt_exec / (2.5e15 * world) * 100:.1f}% "
+                      f"[reference formula 6N+12LCT: {toks / dt * fpt / (2.5e15 * world) * 100:.1f}%] trained {trained / 1e6:.2f}M", flush=True)
             if trained - last_test > args.test_freq:            # train_encoder.py:371-410
                 for name, v in evaluate(model, test_sources, args, world, device).items():
                     if rank == 0:

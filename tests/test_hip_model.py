@@ -328,16 +328,20 @@ def test_readout_paths_match_the_oracle_loss_and_gradients():
             assert rel <= 0.05 and cos >= 0.998, (impl, k, rel, cos)
 
 
-@pytest.mark.parametrize("order", ["layer", "pass"])
-@pytest.mark.parametrize("impl", ["dense", "dense_full", "masked"])
-def test_two_stream_micro_batch_pipeline_is_bitwise_the_single_stream_step(impl, order):
+@pytest.mark.parametrize("order,impl,no_inplace", [(o, i, False) for i in ("dense", "dense_full", "masked") for o in ("layer", "pass")]
+                         + [("layer", "masked", True)])
+def test_two_stream_micro_batch_pipeline_is_bitwise_the_single_stream_step(impl, order, no_inplace, monkeypatch):
     """TrainStep(pipeline_streams=2) overlaps the forward of micro-batch j+1 with the backward of micro-batch j on a
     second stream and keeps every gradient buffer's updates in micro-batch order — per parameter group (backward_order="layer":
     the next backward follows one layer behind) or per pass: loss, gradients and updated weights must equal the
-    single-stream step bit for bit (any race on a gradient or scratch buffer would show here)."""
+    single-stream step bit for bit (any race on a gradient or scratch buffer would show here).
+    no_inplace: the A/B switch OBTE_NO_INPLACE_ACCUM=1 — every gradient delivered through autograd's `grad += new`, which no
+    per-group event can cover: the pipelined passes must then be ordered as wholes (and still reproduce one stream)."""
     from omnibiote_amd import train_encoder as TE
     from omnibiote_amd.mup_compat import set_base_shapes
     from omnibiote_amd.model import OmniBioTA, OmniBioTAConfig
+    if no_inplace:
+        monkeypatch.setenv("OBTE_NO_INPLACE_ACCUM", "1")
     C, H, Lyr, V, T, rows, mini = 256, 2, 2, 1024, 128, 24, 4     # 6 micro-batches
     w = R.hash_weights(R.RefConfig(block_size=T, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C))
     ids = torch.from_numpy(TE.synthetic_rows(rows, T, V, np.random.default_rng(0), single_document=False)).to(DEV)

@@ -256,3 +256,15 @@ def test_tuner_ranking_breaks_ties_towards_the_deeper_ring_and_lists_the_masked_
         (1232, 1024, 65536, True, False), (65536, 1024, 1232, False, False), (1232, 65536, 1024, True, True),      # the readout
         (1232, 4096, 1024, True, True), (1232, 1024, 4096, True, True), (1232, 4096, 1024, True, False), (1232, 1024, 4096, True, False),
         (1024, 4096, 1232, False, False), (4096, 1024, 1232, False, False)])                                         # the last block's MLP half
+
+
+def test_forward_rows_contract_is_checked_on_the_host():
+    """OmniBioTA.forward(rows=) / Block.forward(out_rows=): shape, dtype, device and count of the list are refused on the host
+    before anything is launched (the values — ascending, distinct, in range — are the caller's contract, verified only under
+    OBTE_CHECK_ROWS=1, which needs the device)."""
+    import pytest
+    import torch
+    from omnibiote_amd.model import _check_rows
+    for bad in (torch.zeros(3, dtype=torch.int32), torch.zeros((2, 2), dtype=torch.int64), [0, 1], torch.zeros(3, dtype=torch.int64)):
+        with pytest.raises(ValueError):
+            _check_rows(bad, 16, 1)   # the last one: a CPU tensor (the model lives on the GPU)

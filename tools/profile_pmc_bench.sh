@@ -6,7 +6,7 @@ set -u
 OUT=${1:-gpurun_out/pmc}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-CMD="python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_roofline --no_variants --pipeline_streams 1 --plan_cache $OUT/plans.json"
+CMD="python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_other_configs --no_roofline --no_variants --pipeline_streams 1 --plan_cache $OUT/plans.json"
 [ -f $OUT/plans.json ] || $CMD > /dev/null 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o x -- $CMD > $OUT/pmc_$c.log 2>&1
