@@ -78,14 +78,17 @@ def test_forward_matches_reference_golden(golden_dir, name, rope_mode, mask_kind
     idx = torch.from_numpy(g["masked_ids"]).to(DEV)
     mask = masks_for(g, mask_kind, H)
     emb = m(idx, attn_mask=mask, return_embeddings=True)
+    # measured on MI355X (tools/measure_bars.py, round 4): emb max 0.026-0.031 / mean 1.1e-3-3.8e-3, logits max 1.0e-3-2.8e-3 /
+    # mean 1.4e-4-4.8e-4 over the seven cases and both mask forms; bars = those with ~1.5x margin
     mx, mean = stats(emb, g["emb"])
-    assert mx <= 0.10 and mean <= 5e-3, (mx, mean)
+    assert mx <= 0.05 and mean <= 5e-3, (mx, mean)
     logits = m(idx, attn_mask=mask)
     mx, mean = stats(logits, g["logits"])
-    assert mx <= 0.05 and mean <= 3e-3, (mx, mean)
+    assert mx <= 5e-3 and mean <= 1e-3, (mx, mean)
     from omnibiote_amd import ops
     loss, _ = ops.masked_ce(logits, torch.from_numpy(g["tokens"]).to(DEV), torch.from_numpy(g["mlm_mask"]).to(DEV), int(g["n_accum"]))
-    assert abs(loss.item() - float(g["loss"])) <= 0.02, (loss.item(), float(g["loss"]))
+    # the bf16 reference quantises its loss to 2^-6 (bf16 cross_entropy): measured <= 0.013 there, <= 2e-4 against the fp32 runs
+    assert abs(loss.item() - float(g["loss"])) <= (0.02 if "bf16" in name else 2e-3), (loss.item(), float(g["loss"]))
 
 
 def test_cos_only_and_complex_modes_are_distinguished(golden_dir):
@@ -118,8 +121,10 @@ def test_backward_matches_reference_golden(golden_dir, name, rope_mode):
         denom = want.norm().item() + 1e-12
         rel = (got - want).norm().item() / denom
         cos = torch.dot(got, want).item() / (got.norm().item() * denom + 1e-30)
-        # bf16 golden grads are themselves rounded at every step; fp32 ones are exact: same bar for both
-        assert rel <= 0.08 and cos >= 0.996, (k, rel, cos)
+        # bf16 golden grads are themselves rounded at every step; fp32 ones are exact: same bar for both.  Measured (round 4,
+        # tools/measure_bars.py): worst parameter rel 0.008-0.013, cos 0.99993-0.99997 — the bar of the full-size tests
+        # (tests/test_hip_headline.py: cos >= 0.9995, rel <= 0.04) holds here too
+        assert rel <= 0.04 and cos >= 0.9995, (k, rel, cos)
 
 
 def test_dense_mask_and_range_mask_paths_agree(golden_dir):
