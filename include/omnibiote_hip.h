@@ -194,8 +194,17 @@ typedef struct {
     float dropout_p; uint64_t dropout_seed;     /* must equal the forward call's */
     const int32_t* query_bounds;                /* nullable; with a dense mask: int32 [B,T,2] per KEY, see obte_mask_bounds */
     const int32_t* ranges_exact;                /* nullable; with mask + key_ranges + query_bounds: obte_mask_bounds' flag */
+    /* optional scratch of obte_attn_bwd_ws_bytes() bytes: with it, head_dim 128, no dense mask and dropout_p = 0 the backward
+     * runs as ONE kernel that forms each score tile once (five MFMA products per tile instead of the seven of the
+     * dQ + dK/dV kernel pair): per-key-block fp32 contributions to dQ land in the scratch and are summed in key-block order
+     * (no atomics: bitwise reproducible).  NULL / too small: the two-kernel form. */
+    void* ws; int64_t ws_bytes;
 } obte_attn_bwd_args;
 int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s);
+int64_t obte_attn_bwd_ws_bytes(int64_t B, int64_t T, int32_t n_head, int32_t head_dim);
+/* A/B switch (process-wide, measurement only): 0 = automatic (the one-kernel form wherever it applies), 1 = always the
+ * two-kernel form.  Returns the previous value.  The environment variable OBTE_ATTN_BWD=two sets 1 at load time. */
+int obte_attn_bwd_select(int mode);
 
 /* Conservative bounds of a dense additive mask, so that the dense-mask kernels can skip key tiles without changing a
  * single value (the arithmetic still reads the mask element by element).  An entry counts as "masking" when it is

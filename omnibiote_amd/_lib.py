@@ -39,7 +39,8 @@ class AttnBwdArgs(C.Structure):
                 ("key_ranges", C.c_void_p), ("mask", C.c_void_p),
                 ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
                 ("B", C.c_int64), ("T", C.c_int64), ("n_head", C.c_int32), ("head_dim", C.c_int32), ("scale", C.c_float),
-                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("query_bounds", C.c_void_p), ("ranges_exact", C.c_void_p)]
+                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("query_bounds", C.c_void_p), ("ranges_exact", C.c_void_p),
+                ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
 
 
 class BlockDesc(C.Structure):
@@ -93,6 +94,8 @@ SYMBOLS = {
     "obte_mask_bounds": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
     "obte_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), c_stream]),
+    "obte_attn_bwd_ws_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "obte_attn_bwd_select": (C.c_int, [C.c_int]),
     "obte_embedding_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int64, c_stream]),
     "obte_embedding_fwd_dropout": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int64, C.c_float, C.c_uint64, c_stream]),
     "obte_embedding_bwd_dropout": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_uint64, c_stream]),

@@ -872,7 +872,7 @@ static int debug_max_tiles() {
 }
 static int debug_skip() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("OBTE_ATTN_SKIP"); v = e ? atoi(e) : 0; if (v) debug_warn_once("OBTE_ATTN_SKIP"); }
+    { const char* e = getenv("OBTE_ATTN_SKIP"); v = e ? atoi(e) : 0; if (v) debug_warn_once("OBTE_ATTN_SKIP"); }
     return v;
 }
 static unsigned long long* debug_times_buffer(int64_t max_groups) {
@@ -981,6 +981,18 @@ extern "C" int obte_attn_fwd(const obte_attn_fwd_args* a, obte_stream s) {
     return rc;
 }
 
+#include <atomic>
+static std::atomic<int>& attn_bwd_mode_ref() {
+    static std::atomic<int> m{[] { const char* e = getenv("OBTE_ATTN_BWD"); return (e && !strcmp(e, "two")) ? 1 : 0; }()};
+    return m;
+}
+static int attn_bwd_mode() { return attn_bwd_mode_ref().load(std::memory_order_relaxed); }
+extern "C" int obte_attn_bwd_select(int mode) { return attn_bwd_mode_ref().exchange(mode == 1 ? 1 : 0); }
+extern "C" int64_t obte_attn_bwd_ws_bytes(int64_t B, int64_t T, int32_t n_head, int32_t head_dim) {
+    if (B <= 0 || T <= 0 || n_head <= 0 || head_dim != 128) return 0;
+    return fused_bwd_ws_bytes(B, T, n_head);
+}
+
 extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
     OBTE_REQUIRE(a, "obte_attn_bwd: null args");
     int rc = check_common("obte_attn_bwd", a->qkv, a->B, a->T, a->n_head, a->head_dim, a->key_ranges, a->mask);
@@ -998,7 +1010,11 @@ extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
     p.dbg_times = debug_times_buffer(a->B * a->n_head * ((a->T + 127) / 128));
     const int mode = mask_mode(a->key_ranges, a->mask);
     const int prof = obte_prof_begin((hipStream_t)s, 101, a->B * a->n_head, a->T, a->head_dim);
-    if (mode == MASK_DENSE && a->key_ranges && a->query_bounds && a->ranges_exact)
+    if (mode != MASK_DENSE && a->head_dim == 128 && p.drop.thresh16 == 0 && a->ws && attn_bwd_mode() == 0 &&
+        a->ws_bytes >= fused_bwd_ws_bytes(a->B, a->T, a->n_head) && a->T * 3 * a->n_head * 128 * 2 < (1ll << 31)) {   // (its per-lane byte offsets are 32-bit)
+        if (mode == MASK_RANGES) p.query_bounds = nullptr;   // a range mask without a dense tensor: symmetric (the key's own range)
+        rc = launch_bwd_fused(p, mode, a->ws, (hipStream_t)s);
+    } else if (mode == MASK_DENSE && a->key_ranges && a->query_bounds && a->ranges_exact)
         rc = a->head_dim == 128 ? launch_bwd_gated<128>(p, a->ranges_exact, (hipStream_t)s) : launch_bwd_gated<64>(p, a->ranges_exact, (hipStream_t)s);
     else
         rc = a->head_dim == 128 ? launch_bwd<128>(p, mode, (hipStream_t)s) : launch_bwd<64>(p, mode, (hipStream_t)s);

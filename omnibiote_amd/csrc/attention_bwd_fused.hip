@@ -1,0 +1,664 @@
+// One-kernel attention backward for head_dim 128 (training/model.py:115-146 under loss.backward()): dQ, dK and dV from FIVE
+// MFMA products per tile — S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS, dQ^T += K^T dS^T — where the two-kernel
+// form of attention.hip recomputes S and dP in both kernels (seven products).  Structure (cdna_hip_programming.md, Appendix B
+// "Attention backward"): a workgroup = 4 waves (one per SIMD, the whole 512-register file each) = 256 keys of one
+// (batch, head); each wave keeps dK^T and dV^T of its 64 keys in 256 ACCUMULATOR registers (a[0:255], asm MFMAs with "+a"
+// operands) while the workgroup sweeps the 32-row query slices; S and dP are formed with the KEY on the MFMA lane, so their
+// accumulators, converted in place, already are the B operands of the dV^T / dK^T products; only dS crosses LDS, once, as
+// the B operand of the dQ product, for which wave w owns the 32 head-dim columns 32 w .. 32 w + 31 over all 256 keys.
+//
+// Built with -mllvm -amdgpu-mfma-vgpr-form (csrc/Makefile): with a 512-register budget hipcc otherwise selects the
+// AGPR-destination form for EVERY builtin MFMA and moves the S / dP tiles to the vector ALU through v_accvgpr_read, one
+// instruction per element (measured in round 2: 350 copies per tile).  With the flag the builtin products (S, dP, dQ) live in
+// architectural VGPRs and the resident dK / dV accumulators, only ever touched by the asm statements, in the AGPR half.
+//
+// dQ sums over the key blocks of a (batch, head), i.e. over T/256 workgroups.  Each workgroup writes its fp32 contribution
+// tile (32 queries x 128) to its own slab; attn_dq_reduce_kernel adds the slabs in key-block order, applies the softmax
+// scale and the inverse RoPE and rounds once to bf16 — no atomics, bitwise reproducible.  A key block whose keys no query of
+// a slice may see (block-diagonal document masks) skips the slice; the reduce kernel re-derives who took part from the
+// per-key-block query bounds the fused kernel publishes.
+#include "attn_common.h"
+
+namespace {
+using namespace obte_attn;
+
+constexpr int FB_NW = 4;       // waves per workgroup (one per SIMD)
+constexpr int FB_KEYS = 256;   // keys per workgroup: 64 per wave, two 32-key MFMA tiles
+#ifndef FB_RA
+#define FB_RA 4
+#define FB_RD 4
+#define FB_RC 3
+#endif
+
+template <int D>
+struct FusedShape {
+    static constexpr int QB = 32 * 2 * D;            // one 32-row tile of Q or dO
+    static constexpr int STAGE = 2 * QB + 384;       // Q tile, dO tile, three row constants of the 32 queries (-lse / scale, -delta, -lse log2 e)
+    static constexpr int KBYTES = FB_KEYS * 2 * D;   // the workgroup's K rows (row reads for S, transposed reads for dQ)
+    static constexpr int DSG = FB_KEYS * 8 + 32;     // dS image: one group of 4 queries = [256 keys][4 q] bf16 (+ 32 B: bank spread)
+    static constexpr int DSB = 8 * DSG;              // one dS buffer (8 groups = 32 queries)
+    static constexpr int NSTG = 3;
+    static constexpr int SMEM = NSTG * STAGE + KBYTES + 2 * DSB + 64;
+};
+
+struct FusedParams {
+    AttnParams a;
+    float* dq_part;        // fp32 [B*H][nkb][nsl][4 waves][4][64 lanes][4]: per-key-block contributions to dQ^T tiles
+    int32_t* kb_bounds;    // int32 [B*H][nkb][2]: query range [lo, hi) each key block swept (what the reduce kernel sums)
+    int nkb, nsl;
+};
+
+// one MFMA into a RESIDENT accumulator (AGPRs).  s_nop 1: the A / B operands may have been written by the vector ALU just
+// before (cdna_hip_programming.md §5.7 item 2: hipcc pads nothing for an asm statement).
+__device__ __forceinline__ void mfma_acc(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+// B fragment of the dQ product from the dS image: MFMA column = query (lane & 31), k element j = key row
+// krow0 + 8 (j >> 2) + 4 (lane >> 5) + (j & 3) — the order tr_frag<D>() delivers the K^T A operand in.
+// Image: group g (queries 4 g .. 4 g + 3) at g * DSG, key row r at + 8 r (4 bf16).  Lane 4 q' + p of a 16-lane group supplies
+// row q', query group p of its 16 queries; the transposing read hands lane i query i of the four rows.
+template <int D>
+__device__ __forceinline__ bf16x8 ds_frag(const char* img, int krow0, int lane) {
+    const int li = lane & 15, hh = lane >> 5, qhalf = (lane >> 4) & 1;
+    const int g = 4 * qhalf + (li & 3);
+    const char* t = img + g * FusedShape<D>::DSG + (krow0 + 4 * hh + (li >> 2)) * 8;
+    return join8(lds_read_tr16(t), lds_read_tr16(t + 64));
+}
+
+// LDS reads as  <one VGPR base> + <immediate>: the bases of a slice (stage and dS-image parity are run-time values) are formed once
+// per iteration and made opaque, so every fragment read of the loop is a bare ds_read with an offset field — left to itself hipcc
+// re-derives stage + constant in scalar registers and adds the lane part per read (two VALU + two SALU instructions per read pair).
+typedef __attribute__((address_space(3))) const bf16x8* lds_b128_t;
+typedef __attribute__((address_space(3))) const f32x4* lds_f128_t;
+__device__ __forceinline__ bf16x8 lds_row(uint32_t base, int imm) { return *(lds_b128_t)(uintptr_t)(base + (uint32_t)imm); }
+__device__ __forceinline__ f32x4 lds_f4(uint32_t base, int imm) { return *(lds_f128_t)(uintptr_t)(base + (uint32_t)imm); }
+__device__ __forceinline__ bf16x4 lds_tr(uint32_t base, int imm) {
+    s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)(base + (uint32_t)imm));
+    return __builtin_bit_cast(bf16x4, t);
+}
+__device__ __forceinline__ uint32_t opaque(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
+
+// delta[b,h,q] = sum_d O[b,q,h,d] dO[b,q,h,d] (the softmax backward's row constant).  One wave per (b, q) row of the [M, C]
+// activations: 16 lanes hold one head's 128 values.
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ d_o, float* __restrict__ delta,
+                                                         int64_t B, int64_t T, int H) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= B * T) return;
+    const int64_t b = row / T, q = row % T;
+    const int C = H * 128;
+    for (int c0 = 0; c0 < C; c0 += 512) {   // 64 lanes x 8 elements
+        const int c = c0 + lane * 8;
+        float s = 0.f;
+        if (c < C) {
+            const bf16x8 x = *reinterpret_cast<const bf16x8*>(o + row * C + c);
+            const bf16x8 y = *reinterpret_cast<const bf16x8*>(d_o + row * C + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += bf2f(x[j]) * bf2f(y[j]);
+        }
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
+        if (c < C && (lane & 15) == 0) delta[(b * H + c / 128) * T + q] = s;
+    }
+}
+
+template <int D, int MODE, int SK = 0>   // SK: timing-only skip bits (debug library), compile-time so that the variants cost no branches
+__global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedParams fp) {
+    static_assert(D == 128, "the one-kernel backward is written for head_dim 128");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using S = FusedShape<D>;
+    constexpr int NS = D / 16, ND = D / 32;
+    const AttnParams& p = fp.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const BlockId bid_ = block_id(fp.nkb, p.H);
+    const int kb = bid_.blk, hd = bid_.hd;
+    const int64_t b = bid_.b;
+    const int T = (int)p.T;
+    const int C = p.H * D;
+    const int64_t ld = 3 * (int64_t)C;
+    const int64_t bh = b * p.H + hd;
+
+    char* Kblk = smem + S::NSTG * S::STAGE;
+    char* dsimg = Kblk + S::KBYTES;
+    int* scratch = reinterpret_cast<int*>(dsimg + 2 * S::DSB);
+
+    // ---- this wave's 64 keys: two MFMA tiles of 32, key on the lane ----------------------------------------------
+    int key[2], qs[2], qe[2];
+    bool k_ok[2];
+    bf16x8 vf[2][NS];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        key[kt] = kb * FB_KEYS + wave * 64 + 32 * kt + (lane & 31);
+        k_ok[kt] = key[kt] < T;
+        const int key_c = k_ok[kt] ? key[kt] : T - 1;
+        qs[kt] = 0; qe[kt] = T;
+        if (MODE == MASK_RANGES) {   // the queries that may see this key: the per-key table, or (symmetric masks) the key's own range
+            const int32_t* src = p.query_bounds ? p.query_bounds : p.key_ranges;
+            qs[kt] = max(src[(b * T + key_c) * 2], 0);
+            qe[kt] = min(src[(b * T + key_c) * 2 + 1], T);
+        }
+        if (!k_ok[kt]) { qs[kt] = 0; qe[kt] = 0; }
+        const bf16* vptr = p.qkv + (b * T + key_c) * ld + 2 * C + hd * D;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) vf[kt][s] = *reinterpret_cast<const bf16x8*>(vptr + 16 * s + 8 * h);
+    }
+    {   // the K rows of the block: LDS-DMA, zero-filled past T
+        TileDma<D, FB_KEYS, FB_NW> dmk;
+        dmk.init(wave, lane, ld);
+        const int64_t row0 = (int64_t)kb * FB_KEYS;
+        dmk.issue(p.qkv + (b * T + row0) * ld + C + hd * D, (((int64_t)T - row0) * ld - (C + hd * D)) * 2, Kblk, wave);
+    }
+    int lo = T, hi = 0;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+        if (k_ok[kt] && qe[kt] > qs[kt]) { lo = min(lo, qs[kt]); hi = max(hi, qe[kt]); }
+    block_minmax<FB_NW>(lo, hi, scratch, wave, lane);
+    const int t_begin = hi > lo ? lo / 32 : 0;
+    const int t_end = hi > lo ? (hi + 31) / 32 : 0;
+    if (tid == 0) {   // what this key block sweeps: the reduce kernel sums exactly these slices of its slab
+        fp.kb_bounds[(bh * fp.nkb + kb) * 2] = t_begin;
+        fp.kb_bounds[(bh * fp.nkb + kb) * 2 + 1] = t_end;
+    }
+
+    const bf16* qbase = p.qkv + b * T * ld + hd * D;
+    const bf16* dobase = p.d_o + b * T * C + hd * D;
+    const float* lse_b = p.lse_in + bh * T;
+    const float* del_b = p.delta + bh * T;
+    const float scale2 = p.scale * LOG2E;
+    const float inv_scale = 1.0f / p.scale;
+
+    f32x16 dk[2][ND], dv[2][ND];   // resident: 256 accumulator registers
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[kt][i][r] = 0.f; dv[kt][i][r] = 0.f; }
+
+    // Q / dO tiles by LDS-DMA into a ring of three stages.  ONE buffer descriptor per tensor for the whole kernel (this batch
+    // element's rows of this head: reads past row T return zeros); the slice enters through the per-lane byte offset, so issuing a
+    // slice is four { v_add, s_mov m0, buffer_load ... lds } — the per-tile descriptors of attention.hip cost ~45 scalar
+    // instructions per slice, in front of the first MFMA.
+    TileDma<D, 32, FB_NW> dmq, dmd;
+    dmq.init(wave, lane, ld);
+    dmd.init(wave, lane, C);
+    const i32x4_t rs_q = make_rsrc_words(qbase, ((int64_t)T * ld - hd * D) * 2);
+    const i32x4_t rs_d = make_rsrc_words(dobase, ((int64_t)T * C - hd * D) * 2);
+    const int q_step = (int)(32 * ld * 2), d_step = 32 * C * 2;   // bytes per slice
+    static_assert(TileDma<D, 32, FB_NW>::NP == 2, "two pieces per wave and tile");
+    auto stage_of = [&](int t) { return smem + ((t - t_begin) % S::NSTG) * S::STAGE; };
+    auto issue_piece = [&](int t, int j) {   // j = 0, 1: Q pieces; 2, 3: dO pieces of this wave
+        const uint32_t base = lds_addr_of(stage_of(t)) + wave * 1024;
+        if (j < 2) lds_dma16(rs_q, base + FB_NW * j * 1024, dmq.voff[j] + t * q_step);
+        else lds_dma16(rs_d, base + S::QB + FB_NW * (j - 2) * 1024, dmd.voff[j - 2] + t * d_step);
+    };
+    // lse (threads 0..31) / delta (32..63) of the next slice: ONE load per thread, issued with the tile's LDS-DMA and not touched
+    // until the end of the iteration (vmcnt retires in issue order: a use right after the load would also drain the DMA just issued)
+    float st_l = 0.f;
+    auto load_stats = [&](int q0) {
+        if (tid < 96) {
+            const int q = min(q0 + (tid & 31), T - 1);
+            st_l = ((tid >> 5) == 1 ? del_b : lse_b)[q];
+        }
+    };
+    // row constants of a slice: -lse / scale and -delta are the INITIAL ACCUMULATORS of key tile 0's two chains (S - lse / scale,
+    // dP - delta come out of the MFMAs ready); key tile 1 starts from zero and adds -lse log2(e), -delta in its arithmetic (its
+    // chains would otherwise hold 32 more registers while tile 0's are still being consumed)
+    auto store_stats = [&](char* stage, int q0) {
+        if (tid < 96) {
+            const int row = tid >> 5;
+            float v = row == 0 ? -st_l * inv_scale : (row == 1 ? -st_l : -st_l * LOG2E);
+            if (q0 + (tid & 31) >= T) v = row == 1 ? 0.f : -INFINITY;   // rows past T: p = exp2(-inf) = 0
+            reinterpret_cast<float*>(stage + 2 * S::QB)[tid] = v;
+        }
+    };
+    if (t_begin < t_end) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) issue_piece(t_begin, j);
+        load_stats(t_begin * 32);
+        store_stats(stage_of(t_begin), t_begin * 32);
+    }
+    dma_wait_all();
+    prologue_wait_all();
+    __syncthreads();
+
+    // dQ^T tile of one slice: this wave's 32 head-dim columns over all 256 keys, from the dS image the four waves wrote
+    // (the last slice's; the others are formed inside the loop)
+    float* const dq_dummy = fp.dq_part + (int64_t)p.B * p.H * fp.nkb * fp.nsl * 4096;   // where the first iteration's (meaningless) tile goes
+    auto dq_dst = [&](int t) { return fp.dq_part + ((((bh * fp.nkb + kb) * fp.nsl + t) * FB_NW + wave) * 4) * 256 + lane * 4; };
+    auto dq_tile = [&](int t, const char* img) {
+        f32x16 dq;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < FB_KEYS / 16; ++ks)
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Kblk, 16 * ks, wave, lane), ds_frag<D>(img, 16 * ks, lane), dq, 0, 0, 0);
+        float* dst = dq_dst(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst + i * 256) = f32x4{dq[4 * i], dq[4 * i + 1], dq[4 * i + 2], dq[4 * i + 3]};
+    };
+
+    // ---- the slice loop, scheduled by hand ---------------------------------------------------------------------------------
+    // One wave per SIMD: nothing hides a wave's vector-ALU or LDS latency except its own MFMAs, and hipcc left to itself runs
+    // the phases one after the other (products, then all of the softmax arithmetic, then products: 3.1 us per slice against
+    // 1.3 us of matrix-pipe time).  The iteration is therefore written as 80 SLOTS of one MFMA each, pinned in this order by
+    // sched_barrier(0), every slot carrying the fragment reads of a later slot and its share of everything else:
+    //   A0  16 slots  S0 / dP0 alternating (key tile 0)            beside: LDS-DMA of the next slice (one piece per slot pair), its lse / delta load
+    //   D   16 slots  dQ^T tile of the PREVIOUS slice (its dS image was completed by that iteration's barrier)
+    //                                                             beside: P0, dS0 of key tile 0, one element per slot
+    //   A1  16 slots  S1 / dP1                                     beside: the previous slice's dQ contribution leaves
+    //   C0  16 slots  dV0, dK0 per (query k-step, head-dim tile): resident accumulators, asm
+    //                                                             beside: P1, dS1 of key tile 1, one element per slot; dS0 into the image
+    //   C1   8 slots  dV1, dK1                                     beside: dS1 into the image
+    //   ---- counted vmcnt (the next slice's tiles have landed) + the iteration's ONE barrier ----
+    //   C1   8 slots                                               beside: the first fragments and row constants of the NEXT slice
+    // (this order, not A0 A1 D C, because it keeps one key tile's S / dP pair live at a time: with both the loop needs ~30 more
+    // registers than there are and hipcc spills the V fragments, reloading them behind vmcnt(0) in every slot)
+    // The barrier sits where the matrix pipe has eight MFMAs with operands in hand, so nothing drains at the loop edge; that is
+    // what the third stage is for (a wave ahead issues the DMA of slice t + 2 while a wave behind still reads stage t).
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define OBTE_SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef OBTE_DEBUG_HOOKS
+    // OBTE_ATTN_TIMES=1 (debug library): s_memtime at the phase boundaries of every slice, summed per workgroup (wave 0) — the SHARES
+    // of the phases, not their lengths (each stamp drains the LDS reads in flight across it)
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    const bool stamping = p.dbg_times != nullptr;
+#define OBTE_PHASE(k) do { if (stamping) { __builtin_amdgcn_sched_barrier(0); unsigned long long now_; \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); tsum[k] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+    // timing-only (OBTE_ATTN_SKIP picks an instantiation, debug library): 1 D-phase reads, 2 A-phase reads, 4 softmax arithmetic,
+    // 8 barrier, 16 DMA wait, 32 C-phase reads, 64 dS image + dQ stores, 128 DMA issue (results are wrong)
+#define OBTE_SKIP(b) ((SK & (b)) != 0)
+#else
+#define OBTE_SKIP(b) false
+#define OBTE_PHASE(k) do { } while (0)
+#endif
+    // state carried over the loop edge: the A-phase fragment ring (k-step n = 8 kt + s in slot n % 3, read two k-steps ahead),
+    // key tile 0's two chains holding their row constants, and whether the slice needs the range test
+    constexpr int RA = FB_RA, RD = FB_RD, RC = FB_RC;   // fragment rings: a fragment is read RING - 1 steps ahead of its MFMA
+    bf16x8 fq[RA], fd[RA], fk[RA];
+    f32x16 sc0, dp0;
+    bool inside = true;
+    // lane parts of the fragment addresses (attn_common.h: row_frag, tr_frag; ds_frag above), formed once
+    const int r31 = lane & 31, li = lane & 15;
+    const uint32_t lrow0 = (16 * D) * (r31 >> 3) + 64 * (r31 & 7) + 16 * ((h ^ (r31 >> 2)) & 3);   // row reads, k-step even; odd: ^ 32
+    const uint32_t ltr0 = 64 * (4 * h + (li >> 2)) + 16 * ((2 * ((lane >> 4) & 1) + ((li & 3) >> 1)) ^ h) + (li & 1) * 8;   // transposed reads, rows 0..7 of a group; 8..15: ^ 32, + 16 D
+    const uint32_t lds0 = (4 * ((lane >> 4) & 1) + (li & 3)) * S::DSG + (4 * h + (li >> 2)) * 8;   // dS image
+    const uint32_t a_smem = lds_addr_of(smem), a_k = lds_addr_of(Kblk), a_ds = lds_addr_of(dsimg);
+    const uint32_t k_row[2] = {opaque(a_k + lrow0 + (16 * D) * (8 * wave)), opaque(a_k + (lrow0 ^ 32) + (16 * D) * (8 * wave))};   // this wave's 64 K rows
+    const uint32_t k_tr[2] = {opaque(a_k + ltr0 + 512 * wave), opaque(a_k + (ltr0 ^ 32) + 16 * D + 512 * wave)};                   // K^T, head-dim tile = wave
+    struct SliceBases { uint32_t row[2], tr[2], st; };   // of one stage: Q tile at +0, dO tile at +QB, row constants at +2 QB
+    auto bases_of = [&](int t) {
+        const uint32_t a = a_smem + ((t - t_begin) % S::NSTG) * S::STAGE;
+        SliceBases b;
+        b.row[0] = opaque(a + lrow0); b.row[1] = opaque(a + (lrow0 ^ 32));
+        b.tr[0] = opaque(a + ltr0); b.tr[1] = opaque(a + (ltr0 ^ 32) + 16 * D);
+        b.st = opaque(a + 2 * S::QB + 16 * h);
+        return b;
+    };
+    auto rdA = [&](const SliceBases& sb, int n) {
+        const int s = n & 7, kt = n >> 3, i = n % RA;
+        if (OBTE_SKIP(2) && n > 2) return;
+        fq[i] = lds_row(sb.row[s & 1], 512 * (s >> 1));
+        fd[i] = lds_row(sb.row[s & 1], S::QB + 512 * (s >> 1));
+        fk[i] = lds_row(k_row[s & 1], (16 * D) * (4 * kt) + 512 * (s >> 1));
+    };
+    // the row constants of the 16 query rows this lane's accumulator registers stand for, read straight into the accumulators
+    auto row_init = [&](const SliceBases& sb, int which) {
+        f32x16 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 x = lds_f4(sb.st, 128 * which + 32 * i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * i + j] = x[j];
+        }
+        return v;
+    };
+    // A slice some key of the wave is NOT seen by in full (a document boundary, keys past T): the score chain of a masked
+    // (query, key) pair starts from -inf instead, so its P and dS come out as exact zeros with no test in the arithmetic.
+    // query q0 + acc_row(r, h) inside [qs, qe)  <=>  (unsigned)(c_r - (qs - q0 - 4 h)) < qe - qs
+    auto mask_init = [&](f32x16& sc, int kt, int q0) {
+        const int m_lo = qs[kt] - q0 - 4 * h;
+        const unsigned m_len = (unsigned)(qe[kt] - qs[kt]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = ((unsigned)((r & 3) + 8 * (r >> 2) - m_lo) < m_len) ? sc[r] : -INFINITY;
+    };
+    SliceBases sb_next = bases_of(t_begin);
+    auto preload = [&](int t, int part) {   // part 0: first fragments; 1: row constants (two slots' worth of LDS reads each)
+        const int q0 = t * 32;
+        if (part == 0) {
+            sb_next = bases_of(t);
+#pragma unroll
+            for (int n = 0; n < RA - 1; ++n) rdA(sb_next, n);
+            return;
+        }
+        inside = __all(q0 >= qs[0] && q0 + 32 <= qe[0] && q0 >= qs[1] && q0 + 32 <= qe[1]);
+        sc0 = row_init(sb_next, 0);
+        dp0 = row_init(sb_next, 1);
+        if (!inside) mask_init(sc0, 0, q0);
+    };
+    if (t_begin < t_end) { preload(t_begin, 0); preload(t_begin, 1); }
+
+#ifdef OBTE_DEBUG_HOOKS
+    if (stamping) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory"); }
+#endif
+    for (int t = t_begin; t < t_end; ++t) {
+        const bool more = t + 1 < t_end;
+        const int cur = (t - t_begin) & 1;
+        const SliceBases sb = sb_next;
+        const uint32_t ds_rd = opaque(a_ds + (cur ^ 1) * S::DSB + lds0);   // the previous slice's dS image (reads)
+        char* img_cur = dsimg + cur * S::DSB;
+        const int q0 = t * 32;
+
+        bf16x8 ka[RD], db[RD];          // D phase: K^T and dS^T fragments of key step ks in ring slot ks % RD
+        auto rdD = [&](int ks) {
+            if (OBTE_SKIP(1) && ks > 2) return;
+            ka[ks % RD] = join8(lds_tr(k_tr[0], (16 * D) * (2 * ks)), lds_tr(k_tr[1], (16 * D) * (2 * ks)));
+            db[ks % RD] = join8(lds_tr(ds_rd, 128 * ks), lds_tr(ds_rd, 128 * ks + 64));
+        };
+        bf16x8 cdo[RC], cq[RC];         // C phases: dO^T and Q^T fragments; step gg = 0..15 (C0 then C1) uses group gg % 8 = 4 kk + dt, ring slot gg % RC
+        auto rdC = [&](int gg) {
+            if (OBTE_SKIP(32) && gg > 1) return;
+            const int g = gg & 7, off = (16 * D) * (2 * (g >> 2)) + 512 * (g & 3);
+            cdo[gg % RC] = join8(lds_tr(sb.tr[0], S::QB + off), lds_tr(sb.tr[1], S::QB + off));
+            cq[gg % RC] = join8(lds_tr(sb.tr[0], off), lds_tr(sb.tr[1], off));
+        };
+        f32x16 sc1, dp1, dq;
+        uint32_t pw0[8], dw0[8], pw1[8], dw1[8];   // P and dS of the two key tiles as bf16 pairs (register pair 2 i, 2 i + 1 -> word i)
+        // One element of P = exp2(S' scale2) and dS = P dP' (both chains started from their row constant), computed IN THE SLOT IT
+        // IS WRITTEN IN: the empty asm statements make the results opaque there — without them hipcc sinks the arithmetic to its first
+        // use, phase C, and the slots meant to hide it run empty (sched_barrier orders instructions, it does not stop IR-level sinking).
+        // Two steps, one slot apart: a lone wave has nobody to cover the latency of v_exp_f32, so element r + 1's exponential is
+        // issued in the slot that finishes element r.
+        auto sm_exp = [&](f32x16& sc, int r) {
+            if (OBTE_SKIP(4)) return;
+            float pv = fast_exp2(sc[r] * scale2);   // the chain started from -lse / scale: nothing to subtract
+            asm volatile("" : "+v"(pv));
+            sc[r] = pv;
+        };
+        auto sm_fin = [&](f32x16& sc, f32x16& dp, uint32_t (&pw)[8], uint32_t (&dw)[8], int r) {
+            if (OBTE_SKIP(4)) { if (r & 1) { pw[r >> 1] = __float_as_uint(sc[r]); dw[r >> 1] = __float_as_uint(dp[r]); } return; }
+            float ds = sc[r] * dp[r];
+            if (r & 1) {
+                bf16x2 a = {f2bf(sc[r - 1]), f2bf(sc[r])}, c = {f2bf(dp[r - 1]), f2bf(ds)};
+                uint32_t aw = __builtin_bit_cast(uint32_t, a), cw = __builtin_bit_cast(uint32_t, c);
+                asm volatile("" : "+v"(aw), "+v"(cw));
+                pw[r >> 1] = aw; dw[r >> 1] = cw;
+            } else {
+                asm volatile("" : "+v"(ds));
+                dp[r] = ds;
+            }
+        };
+        // key tile 1: the score chain starts from zero (-inf where the range mask excludes the pair); its row constants -lse log2(e) and -delta
+        // arrive four query rows at a time, one chunk ahead of the arithmetic (c4 / d4 [i & 1] = rows 8 i + 4 h .. + 3 = registers 4 i .. 4 i + 3)
+        f32x4 c4[2], d4[2];
+        auto rd_const1 = [&](int i) {
+            c4[i & 1] = lds_f4(sb.st, 256 + 32 * i);
+            d4[i & 1] = lds_f4(sb.st, 128 + 32 * i);
+        };
+        auto sm1_exp = [&](int r) {
+            if (OBTE_SKIP(4)) return;
+            float pv = fast_exp2(__builtin_fmaf(sc1[r], scale2, c4[(r >> 2) & 1][r & 3]));
+            asm volatile("" : "+v"(pv));
+            sc1[r] = pv;
+        };
+        auto sm1_fin = [&](int r) {
+            if (OBTE_SKIP(4)) { if (r & 1) { pw1[r >> 1] = __float_as_uint(sc1[r]); dw1[r >> 1] = __float_as_uint(dp1[r]); } return; }
+            float ds = sc1[r] * (dp1[r] + d4[(r >> 2) & 1][r & 3]);
+            if (r & 1) {
+                bf16x2 a = {f2bf(sc1[r - 1]), f2bf(sc1[r])}, c = {f2bf(dp1[r - 1]), f2bf(ds)};
+                uint32_t aw = __builtin_bit_cast(uint32_t, a), cw = __builtin_bit_cast(uint32_t, c);
+                asm volatile("" : "+v"(aw), "+v"(cw));
+                pw1[r >> 1] = aw; dw1[r >> 1] = cw;
+            } else {
+                asm volatile("" : "+v"(ds));
+                dp1[r] = ds;
+            }
+        };
+        auto frag_of = [](const uint32_t (&w)[8], int kk) {
+            const u32x4 v = {w[4 * kk], w[4 * kk + 1], w[4 * kk + 2], w[4 * kk + 3]};
+            return __builtin_bit_cast(bf16x8, v);
+        };
+
+        OBTE_PHASE(7);
+        OBTE_SB();
+        // ---- A0 (its first fragments and row constants were read behind the previous iteration's barrier) ----
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            if (n + RA - 1 < 8) rdA(sb, n + RA - 1);
+            if (n >= 8 - (RD - 1)) rdD(n - (8 - (RD - 1)));   // D's first fragments
+            if (more && !OBTE_SKIP(128)) {
+                if (n < 4) issue_piece(t + 1, n);
+                if (n == 4) load_stats((t + 1) * 32);
+            }
+            sc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % RA], fk[n % RA], sc0, 0, 0, 0);
+            OBTE_SB();
+            dp0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[n % RA], vf[0][n], dp0, 0, 0, 0);
+            OBTE_SB();
+        }
+        OBTE_PHASE(0);
+        // ---- D (previous slice) beside the softmax arithmetic of key tile 0 ----
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            if (ks + RD - 1 < 16) rdD(ks + RD - 1);
+            if (ks >= 16 - (RA - 1)) rdA(sb, 8 + ks - (16 - (RA - 1)));   // A1's first fragments
+            if (ks == 0) sm_exp(sc0, 0);
+            if (ks + 1 < 16) sm_exp(sc0, ks + 1);
+            sm_fin(sc0, dp0, pw0, dw0, ks);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks % RD], db[ks % RD], ks == 0 ? zero16 : dq, 0, 0, 0);
+            OBTE_SB();
+        }
+        OBTE_PHASE(1);
+        // ---- A1; beside it the previous slice's dQ contribution leaves ----
+        {
+            float* dst = t > t_begin ? dq_dst(t - 1) : dq_dummy + (wave * 4) * 256 + lane * 4;
+#pragma unroll
+            for (int n = 8; n < 16; ++n) {
+                if (n + RA - 1 < 16) rdA(sb, n + RA - 1);
+                if (n >= 16 - (RC - 1)) rdC(n - (16 - (RC - 1)));   // C0's first fragments
+                if (n < 12 && !OBTE_SKIP(64)) *reinterpret_cast<f32x4*>(dst + (n - 8) * 256) = f32x4{dq[4 * (n - 8)], dq[4 * (n - 8) + 1], dq[4 * (n - 8) + 2], dq[4 * (n - 8) + 3]};
+                if (n == 15) rd_const1(0);
+                if (n == 8) { sc1 = zero16; if (!inside) mask_init(sc1, 1, q0); }
+                sc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % RA], fk[n % RA], sc1, 0, 0, 0);
+                OBTE_SB();
+                dp1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[n % RA], vf[1][n - 8], n == 8 ? zero16 : dp1, 0, 0, 0);
+                OBTE_SB();
+            }
+        }
+        OBTE_PHASE(2);
+        // ---- C0: key tile 0's resident accumulators beside the softmax arithmetic of key tile 1; then C1 beside the dS image, the
+        //      barrier and the next slice's first reads.  Group g = 4 kk + dt; fragment ring slot g & 1, read two groups ahead.
+        char* rowp0 = img_cur + (64 * wave + (lane & 31)) * 8 + h * S::DSG;
+        auto ds_words = [&](const uint32_t (&w)[8], int kt, int j) {   // j = 0..3: words 2 j, 2 j + 1 = registers 4 j .. 4 j + 3 = query group 2 j + h
+            if (!OBTE_SKIP(64)) *reinterpret_cast<u32x2*>(rowp0 + kt * (32 * 8) + (2 * j) * S::DSG) = u32x2{w[2 * j], w[2 * j + 1]};
+        };
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int kk = g >> 2, dt = g & 3;
+            rdC(g + RC - 1);   // (the last ones: C1's first steps, the same fragments again)
+            if (g >= 4) ds_words(dw0, 0, g - 4);
+            if ((g & 1) == 0 && g / 2 + 1 < 4) rd_const1(g / 2 + 1);
+            if (g == 0) sm1_exp(0);
+            sm1_exp(2 * g + 1);
+            sm1_fin(2 * g);
+            mfma_acc(dv[0][dt], cdo[g % RC], frag_of(pw0, kk)); OBTE_SB();
+            if (2 * g + 2 < 16) sm1_exp(2 * g + 2);
+            sm1_fin(2 * g + 1);
+            mfma_acc(dk[0][dt], cq[g % RC], frag_of(dw0, kk)); OBTE_SB();
+        }
+        OBTE_PHASE(3);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int kk = g >> 2, dt = g & 3;
+            if (8 + g + RC - 1 < 16) rdC(8 + g + RC - 1);
+            if (g < 4) ds_words(dw1, 1, g);
+            if (g == 3 && more) store_stats(stage_of(t + 1), (t + 1) * 32);
+            if (g == 4) {
+                OBTE_PHASE(4);
+                // the next slice's tiles (four LDS-DMA + one load, all issued before this iteration's four stores) have landed;
+                // the stores may still be in flight
+                if (!OBTE_SKIP(16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                if (!OBTE_SKIP(8)) __syncthreads();
+                OBTE_PHASE(5);
+                preload(t + 1, 0);   // (unconditional: past the last slice it reads a stage nobody wrote, and nobody uses what it read)
+            }
+            if (g == 6) preload(t + 1, 1);
+            mfma_acc(dv[1][dt], cdo[(8 + g) % RC], frag_of(pw1, kk)); OBTE_SB();
+            mfma_acc(dk[1][dt], cq[(8 + g) % RC], frag_of(dw1, kk)); OBTE_SB();
+        }
+        OBTE_PHASE(6);
+    }
+#ifdef OBTE_DEBUG_HOOKS
+    if (stamping && tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p.dbg_times[(size_t)blockIdx.x * 8 + k] = tsum[k];
+    }
+#endif
+#undef OBTE_PHASE
+#undef OBTE_SB
+#undef OBTE_SKIP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t_end > t_begin) dq_tile(t_end - 1, dsimg + ((t_end - 1 - t_begin) & 1) * S::DSB);
+    __syncthreads();   // every wave is done with the K rows (all 256 of them feed each wave's dQ tiles): they now carry rows out
+
+    {   // dV and dK rows leave through the wave's own K rows in LDS as whole 256-byte rows (wave_rows_out); dK rotated back
+        char* wl = Kblk + wave * (64 * 2 * D);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int64_t key0 = (int64_t)key[kt] - (lane & 31);
+            const int rows_ok = (int)max((int64_t)0, min((int64_t)32, (int64_t)T - key0));
+            bf16* dk0 = p.dqkv + (b * T + key0) * ld + C + hd * D;
+            RopeRow<D> rr;
+            rr.load(p.rope_cos, p.rope_sin, k_ok[kt] ? key[kt] : T - 1, h);
+            bf16x4 gb[ND * 4];
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gb[4 * dt + i][j] = f2bf(dv[kt][dt][4 * i + j]);
+            wave_rows_out<D>(wl, gb, dk0 + C, ld, rows_ok, lane);
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float g[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] = dk[kt][dt][4 * i + j] * p.scale;
+                    rr.apply(g, dt, i);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gb[4 * dt + i][j] = f2bf(g[j]);
+                }
+            wave_rows_out<D>(wl + 32 * 2 * D, gb, dk0, ld, rows_ok, lane);
+        }
+    }
+}
+
+// dQ = scale * sum over key blocks (in key-block order) of their fp32 contribution tiles, inverse RoPE, one rounding to bf16.
+// One workgroup per (batch, head, slice); thread (wave w, lane) owns the same 16 values it owned in the fused kernel: head-dim
+// columns 32 w + 8 i + 4 h .. + 3 (i = 0..3) of query 32 t + (lane & 31).
+template <int D>
+__global__ __launch_bounds__(256) void attn_dq_reduce_kernel(FusedParams fp) {
+    const AttnParams& p = fp.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int t = blockIdx.x % fp.nsl;
+    const int64_t bh = blockIdx.x / fp.nsl;
+    const int64_t b = bh / p.H;
+    const int hd = (int)(bh % p.H);
+    const int T = (int)p.T, C = p.H * D;
+    const int q = t * 32 + (lane & 31);
+    f32x4 acc[4] = {};
+    for (int kb = 0; kb < fp.nkb; ++kb) {
+        const int tb = fp.kb_bounds[(bh * fp.nkb + kb) * 2], te = fp.kb_bounds[(bh * fp.nkb + kb) * 2 + 1];
+        if (t < tb || t >= te) continue;   // uniform over the workgroup
+        const float* src = fp.dq_part + ((((bh * fp.nkb + kb) * fp.nsl + t) * FB_NW + wave) * 4) * 256 + lane * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += *reinterpret_cast<const f32x4*>(src + i * 256);
+    }
+    if (q >= T) return;
+    bf16* out = p.dqkv + (b * T + q) * 3 * (int64_t)C + hd * D + 32 * wave + 4 * h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float g[4] = {acc[i][0] * p.scale, acc[i][1] * p.scale, acc[i][2] * p.scale, acc[i][3] * p.scale};
+        if (p.rope_cos) {
+            const int64_t at = (int64_t)q * (D / 2) + (32 * wave + 8 * i + 4 * h) / 2;
+            const float2 cc = *reinterpret_cast<const float2*>(p.rope_cos + at), ss = *reinterpret_cast<const float2*>(p.rope_sin + at);
+            const float e0 = g[0] * cc.x + g[1] * ss.x, o0 = -g[0] * ss.x + g[1] * cc.x;
+            const float e1 = g[2] * cc.y + g[3] * ss.y, o1 = -g[2] * ss.y + g[3] * cc.y;
+            g[0] = e0; g[1] = o0; g[2] = e1; g[3] = o1;
+        }
+        *reinterpret_cast<bf16x4*>(out + 8 * i) = bf16x4{f2bf(g[0]), f2bf(g[1]), f2bf(g[2]), f2bf(g[3])};
+    }
+}
+
+template __global__ void attn_bwd_fused_kernel<128, MASK_NONE>(FusedParams);
+template __global__ void attn_bwd_fused_kernel<128, MASK_RANGES>(FusedParams);
+#ifdef OBTE_DEBUG_HOOKS
+#define OBTE_FUSED_SKIPS(X) X(4) X(35) X(39) X(64) X(103) X(128) X(231) X(255)
+#define X(m) template __global__ void attn_bwd_fused_kernel<128, MASK_RANGES, m>(FusedParams);
+OBTE_FUSED_SKIPS(X)
+#undef X
+#endif
+template __global__ void attn_dq_reduce_kernel<128>(FusedParams);
+
+}  // namespace
+
+namespace obte_attn {
+
+int64_t fused_bwd_ws_bytes(int64_t B, int64_t T, int H) {
+    const int64_t nkb = (T + FB_KEYS - 1) / FB_KEYS, nsl = (T + 31) / 32;
+    return B * H * nkb * nsl * (32 * 128 * 4) + (32 * 128 * 4) + B * H * nkb * 2 * 4 + 256;   // contributions, one scratch tile, bounds
+}
+
+// mode: MASK_NONE or MASK_RANGES.  ws: fused_bwd_ws_bytes() bytes.
+int launch_bwd_fused(const AttnParams& p, int mode, void* ws, hipStream_t st) {
+    FusedParams fp;
+    fp.a = p;
+    fp.nkb = (int)((p.T + FB_KEYS - 1) / FB_KEYS);
+    fp.nsl = (int)((p.T + 31) / 32);
+    fp.dq_part = reinterpret_cast<float*>(ws);
+    fp.kb_bounds = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + (p.B * p.H * (int64_t)fp.nkb * fp.nsl + 1) * (32 * 128 * 4));
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv64(p.B * p.T, 4)), dim3(256), 0, st, p.o_in, p.d_o, p.delta, p.B, p.T, p.H);
+    OBTE_CHECK_LAUNCH("obte_attn_bwd(delta)");
+    const int smem = FusedShape<128>::SMEM;
+    const dim3 grid((unsigned)(fp.nkb * p.H * p.B)), block(FB_NW * 64);
+    if (mode == MASK_NONE) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<128, MASK_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipLaunchKernelGGL((attn_bwd_fused_kernel<128, MASK_NONE>), grid, block, smem, st, fp);
+    } else {
+        bool done = false;
+#ifdef OBTE_DEBUG_HOOKS
+#define X(m) if (p.dbg_skip == m) { (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<128, MASK_RANGES, m>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+                                    hipLaunchKernelGGL((attn_bwd_fused_kernel<128, MASK_RANGES, m>), grid, block, smem, st, fp); done = true; }
+        OBTE_FUSED_SKIPS(X)
+#undef X
+#endif
+        if (!done) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<128, MASK_RANGES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<128, MASK_RANGES>), grid, block, smem, st, fp);
+        }
+    }
+    OBTE_CHECK_LAUNCH("obte_attn_bwd(fused)");
+#ifdef OBTE_DEBUG_HOOKS
+    if (p.dbg_times) {
+        const int n = (int)grid.x;
+        std::vector<unsigned long long> hbuf((size_t)n * 8);
+        if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hbuf.data(), p.dbg_times, hbuf.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < n; ++i) for (int k = 0; k < 8; ++k) sum[k] += (double)hbuf[(size_t)i * 8 + k];
+            const char* names[8] = {"A0", "D+SM0", "A1", "C0+SM1", "C1a", "wait+barrier", "C1b+preload", "loop edge"};
+            double tot = 0; for (int k = 0; k < 8; ++k) tot += sum[k];
+            fprintf(stderr, "[attn fused phases, cycles per slice per workgroup (%d slices)]", fp.nsl);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.0f (%.0f%%)", names[k], sum[k] / n / fp.nsl, 100.0 * sum[k] / tot);
+            fprintf(stderr, " | total %.0f\n", tot / n / fp.nsl);
+        }
+    }
+#endif
+    hipLaunchKernelGGL((attn_dq_reduce_kernel<128>), dim3((unsigned)(p.B * p.H * fp.nsl)), dim3(256), 0, st, fp);
+    OBTE_CHECK_LAUNCH("obte_attn_bwd(dq reduce)");
+    return OBTE_OK;
+}
+
+}  // namespace obte_attn

@@ -250,4 +250,8 @@ struct RopeRow {
 };
 
 
+// attention_bwd_fused.hip: the one-kernel backward (head_dim 128, MASK_NONE / MASK_RANGES, no dropout)
+int64_t fused_bwd_ws_bytes(int64_t B, int64_t T, int H);
+int launch_bwd_fused(const AttnParams& p, int mode, void* ws, hipStream_t st);
+
 }  // namespace obte_attn

@@ -32,7 +32,7 @@ struct ActLayout {
 };
 
 struct WsLayout {
-    int64_t dhpre, dh, dx1, dyattn, dqkv, delta, lnws, dym, dym2, gemmws, gemmws_bytes, total;
+    int64_t dhpre, dh, dx1, dyattn, dqkv, delta, lnws, dym, dym2, gemmws, gemmws_bytes, attnws, attnws_bytes, total;
     WsLayout(int64_t B, int64_t T, int C, int H) {
         const int64_t M = B * T;
         int64_t o = 0;
@@ -53,6 +53,8 @@ struct WsLayout {
             if (b > gemmws_bytes) gemmws_bytes = b;
         }
         gemmws = take(gemmws_bytes > 0 ? gemmws_bytes : 256);
+        attnws_bytes = obte_attn_bwd_ws_bytes(B, T, H, C / H);   // the one-kernel attention backward's dQ contributions (0: not applicable)
+        attnws = take(attnws_bytes > 0 ? attnws_bytes : 256);
         total = o;
     }
 };
@@ -265,6 +267,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     ab.ranges_exact = d->ranges_exact;
     ab.B = d->B; ab.T = d->T; ab.n_head = H; ab.head_dim = hs; ab.scale = 8.0f / (float)C;
     ab.dropout_p = d->dropout_p; ab.dropout_seed = d->dropout_seed;
+    if (W.attnws_bytes > 0) { ab.ws = (void*)(S + W.attnws); ab.ws_bytes = W.attnws_bytes; }
     TRY(obte_attn_bwd(&ab, s));
     // OBTE_GROUPED_DGRAD=0 keeps dh1 = dqkv W_attn as its own launch (A/B timing)
     const char* gd = getenv("OBTE_GROUPED_DGRAD");

@@ -266,6 +266,44 @@ def test_attention_fwd_bwd(hs, T, mode):
     close(dqkv, dref, atol=1.5e-2, rtol=2.0 ** -6, what=f"attn bwd {mode}")
 
 
+@pytest.mark.parametrize("T,mode", [(600, "ranges"), (600, "none"), (1024, "ranges"), (333, "ranges")])
+def test_attention_backward_one_kernel_form(T, mode):
+    """The one-kernel backward (head size 128, key ranges or no mask, no dropout; csrc/attention_bwd_fused.hip) over several
+    256-key blocks, ragged lengths and multi-document rows — against the oracle (model.py:115-146 differentiated by autograd),
+    against the dQ + dK/dV kernel pair (the two forms sum in different orders: equal to rounding, not bitwise), and against
+    itself run twice (no atomics anywhere: bitwise)."""
+    B, H, hs = 2, 3, 128
+    C = H * hs
+    scale = 8.0 / C
+    qkv, q, k, v = _attn_case(B, T, H, hs, seed=T)
+    rng = np.random.default_rng(T)
+    tokens = rng.integers(20, 100, size=(B, T))
+    tokens[0, [T // 5, T // 2, T // 2 + 40]] = R.EOS_TOKEN      # documents that start and end inside / across key blocks
+    tokens[1, [3, T - 7]] = R.EOS_TOKEN
+    dense, ranges = _blocks_to_masks(tokens, T)
+    o = ops()
+    mask_add, spec = (dense.unsqueeze(1), o.MaskSpec(ranges=ranges.to(DEV))) if mode == "ranges" else (None, None)
+    qf, kf, vf = q.requires_grad_(True), k.requires_grad_(True), v.requires_grad_(True)
+    ref = R.attention(qf, kf, vf, scale, mask_add)
+    d_o = rnd(B, T, C, seed=5)
+    ref.backward(d_o.reshape(B, T, H, hs).transpose(1, 2).float())
+    dref = torch.cat([g.transpose(1, 2).reshape(B, T, C) for g in (qf.grad, kf.grad, vf.grad)], dim=2)
+    got, lse = o.attn_fwd(qkv.to(DEV), B, T, H, hs, scale, spec)
+    cos, sin = None, None
+    one = o.attn_bwd(qkv.to(DEV), got, d_o.to(DEV), lse, B, T, H, hs, scale, spec)
+    two = o.attn_bwd(qkv.to(DEV), got, d_o.to(DEV), lse, B, T, H, hs, scale, spec, one_kernel=False)
+    close(one, dref, atol=1.5e-2, rtol=2.0 ** -6, what=f"one-kernel bwd {mode} T={T}")
+    close(one, two.float().cpu(), atol=4e-3, rtol=2.0 ** -7, what="one-kernel vs kernel pair")
+    again = o.attn_bwd(qkv.to(DEV), got, d_o.to(DEV), lse, B, T, H, hs, scale, spec)
+    assert torch.equal(one, again), "one-kernel backward is not run-to-run bitwise"
+    # with the inverse RoPE of the epilogues (what the block passes): the same rotation of the dq and dk thirds in both forms
+    tab = torch.randn(T, hs // 2, generator=torch.Generator().manual_seed(1))
+    rope = (torch.cos(tab).to(DEV), torch.sin(tab).to(DEV))
+    one_r = o.attn_bwd(qkv.to(DEV), got, d_o.to(DEV), lse, B, T, H, hs, scale, spec, rope=rope)
+    two_r = o.attn_bwd(qkv.to(DEV), got, d_o.to(DEV), lse, B, T, H, hs, scale, spec, rope=rope, one_kernel=False)
+    close(one_r, two_r.float().cpu(), atol=4e-3, rtol=2.0 ** -7, what="one-kernel vs kernel pair, inverse RoPE")
+
+
 @pytest.mark.parametrize("hs", [64, 128])
 def test_attention_dense_mask_bounds_edge_cases(hs):
     """Dense additive masks reach the kernels with conservative loop bounds (obte_mask_bounds).  The cases the bounds

@@ -11,6 +11,7 @@ ap.add_argument("--B", type=int, default=8); ap.add_argument("--H", type=int, de
 ap.add_argument("--T", type=int, default=1024); ap.add_argument("--hs", type=int, default=128)
 ap.add_argument("--dense", action="store_true", help="pass the mask as the reference's dense additive (B,H,T,T) expand() view")
 ap.add_argument("--nomask", action="store_true", help="no mask at all (rows without EOS attend everywhere)")
+ap.add_argument("--two_kernel", action="store_true", help="backward as the dQ + dK/dV kernel pair (default: the one-kernel form where it applies)")
 ap.add_argument("--multi", action="store_true", help="multi-document rows (block-diagonal mask) instead of one document per row")
 a = ap.parse_args()
 B, H, T, hs = a.B, a.H, a.T, a.hs
@@ -38,6 +39,6 @@ def timeit(fn):
     ts.sort(); return ts[len(ts) // 2] * 1e3
 o, lse = ops.attn_fwd(qkv, B, T, H, hs, scale, spec)
 tf = timeit(lambda: ops.attn_fwd(qkv, B, T, H, hs, scale, spec))
-tb = timeit(lambda: ops.attn_bwd(qkv, o, d_o, lse, B, T, H, hs, scale, spec))
+tb = timeit(lambda: ops.attn_bwd(qkv, o, d_o, lse, B, T, H, hs, scale, spec, one_kernel=not a.two_kernel))
 fl = 4.0 * B * H * T * T * hs
 print(f"attn fwd {tf:8.1f} us {fl / tf / 1e6:7.1f} TFLOP/s | bwd {tb:8.1f} us {2.5 * fl / tb / 1e6:7.1f} TFLOP/s (algorithmic)", flush=True)
