@@ -12,11 +12,17 @@
 // instruction per element (measured in round 2: 350 copies per tile).  With the flag the builtin products (S, dP, dQ) live in
 // architectural VGPRs and the resident dK / dV accumulators, only ever touched by the asm statements, in the AGPR half.
 //
-// dQ sums over the key blocks of a (batch, head), i.e. over T/256 workgroups.  Each workgroup writes its fp32 contribution
-// tile (32 queries x 128) to its own slab; attn_dq_reduce_kernel adds the slabs in key-block order, applies the softmax
-// scale and the inverse RoPE and rounds once to bf16 — no atomics, bitwise reproducible.  A key block whose keys no query of
-// a slice may see (block-diagonal document masks) skips the slice; the reduce kernel re-derives who took part from the
-// per-key-block query bounds the fused kernel publishes.
+// dQ sums over the key blocks of a (batch, head), i.e. over T/256 workgroups: an ORDERED HAND-OFF, no atomics, bitwise
+// reproducible.  The running fp32 dQ^T tile of every 32-query slice lives in a scratch buffer; the key blocks that take part in a
+// slice add to it one after the other in a fixed order, the last one applies the softmax scale and the inverse RoPE and rounds
+// once to bf16.  Every workgroup sweeps its slices in a ROTATED order (key block k starts k/nkb of the way round), so the
+// members of one slice's chain reach it nsl/nkb iterations apart: nobody waits in steady state, and all workgroups of a
+// (batch, head) start and finish together.  The order of a slice's chain is the order of the members' own visiting times
+// (ties: the lower key block first) — every workgroup derives it from the per-key-block slice ranges the prep kernel publishes —
+// so every wait is for a strictly earlier (time, key block) pair: no cycle, whatever is resident when.  Publication follows
+// cdna_hip_programming.md Guideline 16, R1: write-through (sc1) stores of the tile, every storing wave's vmcnt(0), the
+// workgroup's barrier, one lane's agent-scope add on the slice's counter; the consumer polls the counter with sc1 loads
+// (the poll of the NEXT hand-off is issued an iteration ahead) and reads the tile with sc1 loads.  Spins are bounded.
 #include "attn_common.h"
 
 namespace {
@@ -37,14 +43,18 @@ struct FusedShape {
     static constexpr int KBYTES = FB_KEYS * 2 * D;   // the workgroup's K rows (row reads for S, transposed reads for dQ)
     static constexpr int DSG = FB_KEYS * 8 + 32;     // dS image: one group of 4 queries = [256 keys][4 q] bf16 (+ 32 B: bank spread)
     static constexpr int DSB = 8 * DSG;              // one dS buffer (8 groups = 32 queries)
-    static constexpr int NSTG = 3;
-    static constexpr int SMEM = NSTG * STAGE + KBYTES + 2 * DSB + 64;
+    static constexpr int NSTG = 2;
+    static constexpr int TAB = 1024;                 // chain table: one byte per slice this workgroup sweeps (nsl <= 1024)
+    static constexpr int ACC = 32 * D * 4;           // the dQ^T tile handed on to this workgroup, staged by LDS-DMA (each wave its own 4 KiB)
+    static constexpr int SMEM = NSTG * STAGE + KBYTES + 2 * DSB + ACC + 64 + TAB + 1024;   // (+ the key blocks' slice ranges)
 };
 
 struct FusedParams {
     AttnParams a;
-    float* dq_part;        // fp32 [B*H][nkb][nsl][4 waves][4][64 lanes][4]: per-key-block contributions to dQ^T tiles
-    int32_t* kb_bounds;    // int32 [B*H][nkb][2]: query range [lo, hi) each key block swept (what the reduce kernel sums)
+    float* dq_acc;         // fp32 [B*H][nsl][4 waves][4][64 lanes][4]: the running dQ^T tile of every slice
+    int32_t* flags;        // int32 [B*H][nsl]: contributions completed per slice (zeroed by the prep kernel, every call)
+    int32_t* kb_bounds;    // int32 [B][nkb][2]: the slices [t_begin, t_end) each key block sweeps (prep kernel)
+    int32_t* err;          // int32 [1]: set when a bounded spin gave up (a protocol bug or a workgroup that never ran)
     int nkb, nsl;
 };
 
@@ -79,27 +89,65 @@ __device__ __forceinline__ bf16x4 lds_tr(uint32_t base, int imm) {
 }
 __device__ __forceinline__ uint32_t opaque(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
 
-// delta[b,h,q] = sum_d O[b,q,h,d] dO[b,q,h,d] (the softmax backward's row constant).  One wave per (b, q) row of the [M, C]
-// activations: 16 lanes hold one head's 128 values.
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ d_o, float* __restrict__ delta,
-                                                         int64_t B, int64_t T, int H) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
-    if (row >= B * T) return;
-    const int64_t b = row / T, q = row % T;
-    const int C = H * 128;
-    for (int c0 = 0; c0 < C; c0 += 512) {   // 64 lanes x 8 elements
-        const int c = c0 + lane * 8;
-        float s = 0.f;
-        if (c < C) {
-            const bf16x8 x = *reinterpret_cast<const bf16x8*>(o + row * C + c);
-            const bf16x8 y = *reinterpret_cast<const bf16x8*>(d_o + row * C + c);
+// Prep launch, three jobs by block range:
+//  [0, nb_delta)   delta[b,h,q] = sum_d O[b,q,h,d] dO[b,q,h,d] (the softmax backward's row constant): one wave per (b, q) row of the
+//                  [M, C] activations, 16 lanes hold one head's 128 values;
+//  next nb_flags   zero the slices' hand-off counters (every call: the protocol counts from zero) and the error word;
+//  next B * nkb    the slice range [t_begin, t_end) of key block (b, kb): the union of the query ranges of its keys.
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(FusedParams fp, int mode, int nb_delta, int nb_flags) {
+    const AttnParams& p = fp.a;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int T = (int)p.T, H = p.H;
+    int blk = blockIdx.x;
+    if (blk < nb_delta) {
+        const int64_t row = (int64_t)blk * 4 + wave;
+        if (row >= p.B * T) return;
+        const int64_t b = row / T, q = row % T;
+        const int C = H * 128;
+        for (int c0 = 0; c0 < C; c0 += 512) {   // 64 lanes x 8 elements
+            const int c = c0 + lane * 8;
+            float s = 0.f;
+            if (c < C) {
+                const bf16x8 x = *reinterpret_cast<const bf16x8*>(p.o_in + row * C + c);
+                const bf16x8 y = *reinterpret_cast<const bf16x8*>(p.d_o + row * C + c);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += bf2f(x[j]) * bf2f(y[j]);
+                for (int j = 0; j < 8; ++j) s += bf2f(x[j]) * bf2f(y[j]);
+            }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
+            if (c < C && (lane & 15) == 0) p.delta[(b * H + c / 128) * T + q] = s;
         }
+        return;
+    }
+    blk -= nb_delta;
+    if (blk < nb_flags) {
+        const int64_t i = (int64_t)blk * 256 + tid;
+        if (i < p.B * H * fp.nsl) fp.flags[i] = 0;
+        if (i == 0) *fp.err = 0;
+        return;
+    }
+    blk -= nb_flags;
+    __shared__ int red[8];
+    const int b = blk / fp.nkb, kb = blk % fp.nkb;
+    const int key = kb * FB_KEYS + tid;
+    int lo = T, hi = 0;
+    if (key < T) {
+        int qs = 0, qe = T;
+        if (mode == MASK_RANGES) {
+            const int32_t* src = p.query_bounds ? p.query_bounds : p.key_ranges;
+            qs = max(src[((int64_t)b * T + key) * 2], 0);
+            qe = min(src[((int64_t)b * T + key) * 2 + 1], T);
+        }
+        if (qe > qs) { lo = qs; hi = qe; }
+    }
 #pragma unroll
-        for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
-        if (c < C && (lane & 15) == 0) delta[(b * H + c / 128) * T + q] = s;
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+    if (lane == 0) { red[wave] = lo; red[4 + wave] = hi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) { lo = min(lo, red[w]); hi = max(hi, red[4 + w]); }
+        fp.kb_bounds[(b * fp.nkb + kb) * 2] = hi > lo ? lo / 32 : 0;
+        fp.kb_bounds[(b * fp.nkb + kb) * 2 + 1] = hi > lo ? (hi + 31) / 32 : 0;
     }
 }
 
@@ -123,7 +171,8 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
 
     char* Kblk = smem + S::NSTG * S::STAGE;
     char* dsimg = Kblk + S::KBYTES;
-    int* scratch = reinterpret_cast<int*>(dsimg + 2 * S::DSB);
+    char* accst = dsimg + 2 * S::DSB;
+    int* scratch = reinterpret_cast<int*>(accst + S::ACC);
 
     // ---- this wave's 64 keys: two MFMA tiles of 32, key on the lane ----------------------------------------------
     int key[2], qs[2], qe[2];
@@ -151,17 +200,31 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         const int64_t row0 = (int64_t)kb * FB_KEYS;
         dmk.issue(p.qkv + (b * T + row0) * ld + C + hd * D, (((int64_t)T - row0) * ld - (C + hd * D)) * 2, Kblk, wave);
     }
-    int lo = T, hi = 0;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-        if (k_ok[kt] && qe[kt] > qs[kt]) { lo = min(lo, qs[kt]); hi = max(hi, qe[kt]); }
-    block_minmax<FB_NW>(lo, hi, scratch, wave, lane);
-    const int t_begin = hi > lo ? lo / 32 : 0;
-    const int t_end = hi > lo ? (hi + 31) / 32 : 0;
-    if (tid == 0) {   // what this key block sweeps: the reduce kernel sums exactly these slices of its slab
-        fp.kb_bounds[(bh * fp.nkb + kb) * 2] = t_begin;
-        fp.kb_bounds[(bh * fp.nkb + kb) * 2 + 1] = t_end;
+    // the slices this key block sweeps, their visiting order and, for each, this workgroup's place in the slice's hand-off chain
+    // (header): tab[i] = place | last << 7 of the i-th slice visited, s(i) = t_begin + (i + rot) mod n
+    int* kbb = scratch + 16;                                        // [nkb][2] slice ranges of this batch element's key blocks
+    uint8_t* tab = reinterpret_cast<uint8_t*>(scratch) + 64 + 1024;   // (the 1 KiB in between holds kbb: nkb <= 120)
+    for (int i = tid; i < 2 * fp.nkb; i += FB_NW * 64) kbb[i] = fp.kb_bounds[b * fp.nkb * 2 + i];
+    __syncthreads();
+    const int t_begin = __builtin_amdgcn_readfirstlane(kbb[2 * kb]);
+    const int t_end = __builtin_amdgcn_readfirstlane(kbb[2 * kb + 1]);
+    const int n_sl = t_end - t_begin;
+    const int rot = n_sl > 0 ? (int)(((int64_t)kb * n_sl) / fp.nkb) : 0;
+    for (int i = tid; i < n_sl; i += FB_NW * 64) {
+        const int s = t_begin + (i + rot) % n_sl;
+        int place = 0, cnt = 0;
+        for (int k2 = 0; k2 < fp.nkb; ++k2) {
+            const int tb2 = kbb[2 * k2], te2 = kbb[2 * k2 + 1], n2 = te2 - tb2;
+            if (s < tb2 || s >= te2) continue;
+            ++cnt;
+            if (k2 == kb) continue;
+            const int rot2 = (int)(((int64_t)k2 * n2) / fp.nkb);
+            const int tau2 = (s - tb2 - rot2 + n2) % n2;
+            if (tau2 < i || (tau2 == i && k2 < kb)) ++place;
+        }
+        tab[i] = (uint8_t)(place | ((place == cnt - 1) ? 0x80 : 0));
     }
+    // (published to every wave by the barrier that ends the prologue)
 
     const bf16* qbase = p.qkv + b * T * ld + hd * D;
     const bf16* dobase = p.d_o + b * T * C + hd * D;
@@ -189,12 +252,14 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     const i32x4_t rs_d = make_rsrc_words(dobase, ((int64_t)T * C - hd * D) * 2);
     const int q_step = (int)(32 * ld * 2), d_step = 32 * C * 2;   // bytes per slice
     static_assert(TileDma<D, 32, FB_NW>::NP == 2, "two pieces per wave and tile");
-    auto stage_of = [&](int t) { return smem + ((t - t_begin) % S::NSTG) * S::STAGE; };
-    auto issue_piece = [&](int t, int j) {   // j = 0, 1: Q pieces; 2, 3: dO pieces of this wave
-        const uint32_t base = lds_addr_of(stage_of(t)) + wave * 1024;
+    // i = position in this workgroup's visiting order (stage i mod 3), t = the slice visited there
+    auto stage_of = [&](int i) { return smem + (i % S::NSTG) * S::STAGE; };
+    auto issue_piece = [&](int i, int t, int j) {   // j = 0, 1: Q pieces; 2, 3: dO pieces of this wave
+        const uint32_t base = lds_addr_of(stage_of(i)) + wave * 1024;
         if (j < 2) lds_dma16(rs_q, base + FB_NW * j * 1024, dmq.voff[j] + t * q_step);
         else lds_dma16(rs_d, base + S::QB + FB_NW * (j - 2) * 1024, dmd.voff[j - 2] + t * d_step);
     };
+    auto slice_at = [&](int i) { const int x = i + rot; return t_begin + (x >= n_sl ? x - n_sl : x); };   // i < n_sl
     // lse (threads 0..31) / delta (32..63) of the next slice: ONE load per thread, issued with the tile's LDS-DMA and not touched
     // until the end of the iteration (vmcnt retires in issue order: a use right after the load would also drain the DMA just issued)
     float st_l = 0.f;
@@ -203,6 +268,13 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
             const int q = min(q0 + (tid & 31), T - 1);
             st_l = ((tid >> 5) == 1 ? del_b : lse_b)[q];
         }
+    };
+    // the loop's form: issued by EVERY wave (the counted waits below count the same operations in all four) and through asm (not
+    // waited for by hipcc; the C1 wait names it)
+    const float* const st_src = ((tid >> 5) == 1 ? del_b : lse_b);
+    auto load_stats_issue = [&](int q0) {
+        const float* a = st_src + min(q0 + (tid & 31), T - 1);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(st_l) : "v"(a) : "memory");
     };
     // row constants of a slice: -lse / scale and -delta are the INITIAL ACCUMULATORS of key tile 0's two chains (S - lse / scale,
     // dP - delta come out of the MFMAs ready); key tile 1 starts from zero and adds -lse log2(e), -delta in its arithmetic (its
@@ -215,31 +287,97 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
             reinterpret_cast<float*>(stage + 2 * S::QB)[tid] = v;
         }
     };
-    if (t_begin < t_end) {
+    if (n_sl > 0) {
+        const int t0 = slice_at(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) issue_piece(t_begin, j);
-        load_stats(t_begin * 32);
-        store_stats(stage_of(t_begin), t_begin * 32);
+        for (int j = 0; j < 4; ++j) issue_piece(0, t0, j);
+        load_stats(t0 * 32);
+        store_stats(stage_of(0), t0 * 32);
     }
     dma_wait_all();
     prologue_wait_all();
     __syncthreads();
 
-    // dQ^T tile of one slice: this wave's 32 head-dim columns over all 256 keys, from the dS image the four waves wrote
-    // (the last slice's; the others are formed inside the loop)
-    float* const dq_dummy = fp.dq_part + (int64_t)p.B * p.H * fp.nkb * fp.nsl * 4096;   // where the first iteration's (meaningless) tile goes
-    auto dq_dst = [&](int t) { return fp.dq_part + ((((bh * fp.nkb + kb) * fp.nsl + t) * FB_NW + wave) * 4) * 256 + lane * 4; };
-    auto dq_tile = [&](int t, const char* img) {
-        f32x16 dq;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < FB_KEYS / 16; ++ks)
-            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Kblk, 16 * ks, wave, lane), ds_frag<D>(img, 16 * ks, lane), dq, 0, 0, 0);
-        float* dst = dq_dst(t);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst + i * 256) = f32x4{dq[4 * i], dq[4 * i + 1], dq[4 * i + 2], dq[4 * i + 3]};
+    // ---- the hand-off of the dQ^T tiles (header) -------------------------------------------------------------------------------
+    // this (batch, head)'s tiles through one buffer descriptor: tile of slice t at t * 16 KiB, this lane's four 16-byte pieces at
+    // (4 wave + i) * 1 KiB + 16 lane
+    const __amdgpu_buffer_rsrc_t rs_acc = make_rsrc(fp.dq_acc + bh * fp.nsl * 4096, (int64_t)fp.nsl * 16384);
+    int32_t* const flag_b = fp.flags + bh * fp.nsl;
+    const int acc_lane = wave * 4096 + lane * 16;
+    // The loads of the hand-off are issued through inline asm: hipcc would otherwise put its own s_waitcnt vmcnt(0) in front of
+    // their first use (and of unrelated instructions that reuse a register), which in this in-order queue also drains the LDS-DMA
+    // just issued for the next slice.  Their completion is covered by the waits the loop has anyway (named at each use).
+    const int32_t* const flag_s = flag_b;                                   // wave-uniform: an SGPR pair
+    auto poll_issue = [&](int t, int& dst) {                                // counter of slice t -> dst, NOT waited for
+        const int off = t * 4;
+        asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(dst) : "v"(off), "s"(flag_s) : "memory");
     };
+    // the counter of slice t has reached `place` (every wave polls for itself: its own tile loads follow its own poll); `have` is
+    // the value polled an iteration ago — in steady state it already suffices and nothing is loaded here
+    auto wait_turn = [&](int t, int place, int have) {
+        int spins = 0;
+        while (have < place) {
+            __builtin_amdgcn_s_sleep(8);
+            const int off = t * 4;
+            asm volatile("global_load_dword %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(have) : "v"(off), "s"(flag_s) : "memory");
+            if (++spins > (1 << 20)) { if (lane == 0) *fp.err = 1; break; }
+        }
+    };
+    // The tile so far is requested by LDS-DMA into this wave's own 4 KiB of a staging area (no VGPR destination: hipcc counts an
+    // asm load's destination as written at the end of the statement and may copy or reuse the register while the data is still
+    // in flight — tools/fused_audit.py caught exactly that with register-destination loads here), sc1 like every read of a
+    // handed-off tile; it is read back by the wave that asked for it, behind that wave's own counted vmcnt — no barrier involved.
+    const uint32_t a_acc = lds_addr_of(accst) + wave * 4096;
+    const i32x4_t rs_accw = make_rsrc_words(fp.dq_acc + bh * fp.nsl * 4096, (int64_t)fp.nsl * 16384);
+    auto acc_request = [&](int t, int i) {   // piece i of 4
+        const int off = t * 16384 + acc_lane;
+        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen sc1 lds" : : "s"(a_acc + i * 1024), "v"(off + i * 1024), "s"(rs_accw) : "memory");   // (no instruction offset: it would move the LDS address too)
+    };
+    const uint32_t acc_rd = opaque(a_acc + lane * 16);
+    auto acc_add = [&](f32x16& dq) {   // (behind the wait that covers the request)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 x = lds_f4(acc_rd, i * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dq[4 * i + j] += x[j];
+        }
+    };
+    // (register-destination form, for the epilogue only: each load is waited for in the statement that issues it)
+    struct AccRegs { f32x4 x[4]; };
+    auto load_acc_sync = [&](int t, AccRegs& r) {
+        const int off = t * 16384 + acc_lane;
+        asm volatile("buffer_load_dwordx4 %0, %4, %5, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %4, %5, 0 offen offset:1024 sc1\n\t"
+                     "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:2048 sc1\n\tbuffer_load_dwordx4 %3, %4, %5, 0 offen offset:3072 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(r.x[0]), "=&v"(r.x[1]), "=&v"(r.x[2]), "=&v"(r.x[3]) : "v"(off), "s"(rs_acc) : "memory");
+    };
+    auto store_acc = [&](int t, const f32x16& dq, int i) {   // piece i of 4
+        const f32x4 x = {dq[4 * i], dq[4 * i + 1], dq[4 * i + 2], dq[4 * i + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rs_acc, t * 16384 + acc_lane + i * 1024, 0, 16);   // sc1: write-through
+    };
+    // the last member of a chain: softmax scale, inverse RoPE, one rounding to bf16; registers 4 i .. 4 i + 3 = head-dim columns
+    // 32 wave + 8 i + 4 h .. + 3 of query 32 t + (lane & 31)
+    struct RopeQ { float2 c[4], s[4]; };
+    auto load_rope = [&](int t, RopeQ& r) {
+        const int q = min(t * 32 + (lane & 31), T - 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t at = (int64_t)q * (D / 2) + (32 * wave + 8 * i + 4 * h) / 2;
+            r.c[i] = *reinterpret_cast<const float2*>(p.rope_cos + at);
+            r.s[i] = *reinterpret_cast<const float2*>(p.rope_sin + at);
+        }
+    };
+    auto store_final = [&](int t, const f32x16& dq, const RopeQ& r, int i) {   // piece i of 4
+        const int q = t * 32 + (lane & 31);
+        float g[4] = {dq[4 * i] * p.scale, dq[4 * i + 1] * p.scale, dq[4 * i + 2] * p.scale, dq[4 * i + 3] * p.scale};
+        if (p.rope_cos) {
+            const float e0 = g[0] * r.c[i].x + g[1] * r.s[i].x, o0 = -g[0] * r.s[i].x + g[1] * r.c[i].x;
+            const float e1 = g[2] * r.c[i].y + g[3] * r.s[i].y, o1 = -g[2] * r.s[i].y + g[3] * r.c[i].y;
+            g[0] = e0; g[1] = o0; g[2] = e1; g[3] = o1;
+        }
+        if (q < T) *reinterpret_cast<bf16x4*>(p.dqkv + (b * T + q) * ld + hd * D + 32 * wave + 8 * i + 4 * h) = bf16x4{f2bf(g[0]), f2bf(g[1]), f2bf(g[2]), f2bf(g[3])};
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // ---- the slice loop, scheduled by hand ---------------------------------------------------------------------------------
     // One wave per SIMD: nothing hides a wave's vector-ALU or LDS latency except its own MFMAs, and hipcc left to itself runs
@@ -259,7 +397,6 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     // registers than there are and hipcc spills the V fragments, reloading them behind vmcnt(0) in every slot)
     // The barrier sits where the matrix pipe has eight MFMAs with operands in hand, so nothing drains at the loop edge; that is
     // what the third stage is for (a wave ahead issues the DMA of slice t + 2 while a wave behind still reads stage t).
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #define OBTE_SB() __builtin_amdgcn_sched_barrier(0)
 #ifdef OBTE_DEBUG_HOOKS
     // OBTE_ATTN_TIMES=1 (debug library): s_memtime at the phase boundaries of every slice, summed per workgroup (wave 0) — the SHARES
@@ -290,8 +427,8 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     const uint32_t k_row[2] = {opaque(a_k + lrow0 + (16 * D) * (8 * wave)), opaque(a_k + (lrow0 ^ 32) + (16 * D) * (8 * wave))};   // this wave's 64 K rows
     const uint32_t k_tr[2] = {opaque(a_k + ltr0 + 512 * wave), opaque(a_k + (ltr0 ^ 32) + 16 * D + 512 * wave)};                   // K^T, head-dim tile = wave
     struct SliceBases { uint32_t row[2], tr[2], st; };   // of one stage: Q tile at +0, dO tile at +QB, row constants at +2 QB
-    auto bases_of = [&](int t) {
-        const uint32_t a = a_smem + ((t - t_begin) % S::NSTG) * S::STAGE;
+    auto bases_of = [&](int i) {   // i = position in the visiting order
+        const uint32_t a = a_smem + (i % S::NSTG) * S::STAGE;
         SliceBases b;
         b.row[0] = opaque(a + lrow0); b.row[1] = opaque(a + (lrow0 ^ 32));
         b.tr[0] = opaque(a + ltr0); b.tr[1] = opaque(a + (ltr0 ^ 32) + 16 * D);
@@ -325,32 +462,37 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = ((unsigned)((r & 3) + 8 * (r >> 2) - m_lo) < m_len) ? sc[r] : -INFINITY;
     };
-    SliceBases sb_next = bases_of(t_begin);
-    auto preload = [&](int t, int part) {   // part 0: first fragments; 1: row constants (two slots' worth of LDS reads each)
-        const int q0 = t * 32;
-        if (part == 0) {
-            sb_next = bases_of(t);
-#pragma unroll
-            for (int n = 0; n < RA - 1; ++n) rdA(sb_next, n);
-            return;
-        }
-        inside = __all(q0 >= qs[0] && q0 + 32 <= qe[0] && q0 >= qs[1] && q0 + 32 <= qe[1]);
-        sc0 = row_init(sb_next, 0);
-        dp0 = row_init(sb_next, 1);
-        if (!inside) mask_init(sc0, 0, q0);
-    };
-    if (t_begin < t_end) { preload(t_begin, 0); preload(t_begin, 1); }
-
 #ifdef OBTE_DEBUG_HOOKS
     if (stamping) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory"); }
 #endif
-    for (int t = t_begin; t < t_end; ++t) {
-        const bool more = t + 1 < t_end;
-        const int cur = (t - t_begin) & 1;
-        const SliceBases sb = sb_next;
+    // loop-carried hand-off state: the previous slice (whose dQ^T tile this iteration forms and hands on), this workgroup's place
+    // in that slice's chain, and the counter value polled for it an iteration ago
+    int t_prev = 0, info_prev = 0;          // the slice visited in the previous iteration: its dQ^T tile is formed (D), joined with what the chain
+                                            // handed on and stored (A1) in this one
+    int t_sig = -1;                         // the slice whose tile was stored an iteration ago and has not been counted on yet (-1: none)
+    int have_prev = 0;                      // the previous slice's counter as polled during the previous iteration
+    for (int it = 0; it < n_sl; ++it) {
+        const bool more = it + 1 < n_sl;
+        const int t = slice_at(it), t_next = more ? slice_at(it + 1) : t;
+        const int cur = it & 1;
+        const int info = tab[it];                       // place | last << 7 of slice t for this workgroup
+        const bool last_p = (info_prev & 0x80) != 0, first_it = it == 0;
+        const bool take_p = !first_it && (info_prev & 0x7f) > 0;   // somebody hands the previous slice's tile on to this workgroup
+        int have_cur = 0;
+        const SliceBases sb = bases_of(it);
         const uint32_t ds_rd = opaque(a_ds + (cur ^ 1) * S::DSB + lds0);   // the previous slice's dS image (reads)
         char* img_cur = dsimg + cur * S::DSB;
         const int q0 = t * 32;
+        // the previous slice's tile so far: once it is this workgroup's turn (in steady state the counter polled an iteration ago
+        // already says so), four LDS-DMA pieces in A0's first slots; they are read back in A1
+        if (take_p) wait_turn(t_prev, info_prev & 0x7f, have_prev);
+        // the first fragments and the row constants of this slice (its tiles were published by the barrier that ended the previous iteration)
+#pragma unroll
+        for (int n = 0; n < RA - 1; ++n) rdA(sb, n);
+        inside = __all(q0 >= qs[0] && q0 + 32 <= qe[0] && q0 >= qs[1] && q0 + 32 <= qe[1]);
+        sc0 = row_init(sb, 0);
+        dp0 = row_init(sb, 1);
+        if (!inside) mask_init(sc0, 0, q0);
 
         bf16x8 ka[RD], db[RD];          // D phase: K^T and dS^T fragments of key step ks in ring slot ks % RD
         auto rdD = [&](int ks) {
@@ -429,10 +571,12 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         for (int n = 0; n < 8; ++n) {
             if (n + RA - 1 < 8) rdA(sb, n + RA - 1);
             if (n >= 8 - (RD - 1)) rdD(n - (8 - (RD - 1)));   // D's first fragments
+            if (n < 4 && take_p) acc_request(t_prev, n);   // (before everything else of this iteration: the A1 wait counts what follows)
             if (more && !OBTE_SKIP(128)) {
-                if (n < 4) issue_piece(t + 1, n);
-                if (n == 4) load_stats((t + 1) * 32);
+                if (n >= 4) issue_piece(it + 1, t_next, n - 4);
+                if (n == 7) load_stats_issue(t_next * 32);
             }
+            if (n == 7) poll_issue(t, have_cur);      // this slice's counter, looked at an iteration from now (after the end-of-iteration wait)
             sc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % RA], fk[n % RA], sc0, 0, 0, 0);
             OBTE_SB();
             dp0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[n % RA], vf[0][n], dp0, 0, 0, 0);
@@ -451,21 +595,24 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
             OBTE_SB();
         }
         OBTE_PHASE(1);
-        // ---- A1; beside it the previous slice's dQ contribution leaves ----
-        {
-            float* dst = t > t_begin ? dq_dst(t - 1) : dq_dummy + (wave * 4) * 256 + lane * 4;
+        // ---- A1; beside it the previous slice's dQ^T tile leaves: on to the next member of its chain, or (last member) to dqkv ----
 #pragma unroll
-            for (int n = 8; n < 16; ++n) {
-                if (n + RA - 1 < 16) rdA(sb, n + RA - 1);
-                if (n >= 16 - (RC - 1)) rdC(n - (16 - (RC - 1)));   // C0's first fragments
-                if (n < 12 && !OBTE_SKIP(64)) *reinterpret_cast<f32x4*>(dst + (n - 8) * 256) = f32x4{dq[4 * (n - 8)], dq[4 * (n - 8) + 1], dq[4 * (n - 8) + 2], dq[4 * (n - 8) + 3]};
-                if (n == 15) rd_const1(0);
-                if (n == 8) { sc1 = zero16; if (!inside) mask_init(sc1, 1, q0); }
-                sc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % RA], fk[n % RA], sc1, 0, 0, 0);
-                OBTE_SB();
-                dp1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[n % RA], vf[1][n - 8], n == 8 ? zero16 : dp1, 0, 0, 0);
-                OBTE_SB();
+        for (int n = 8; n < 16; ++n) {
+            if (n + RA - 1 < 16) rdA(sb, n + RA - 1);
+            if (n >= 16 - (RC - 1)) rdC(n - (16 - (RC - 1)));   // C0's first fragments
+            // the tile so far (requested at the top of the iteration; younger than its four pieces: the next slice's four LDS-DMA, its
+            // row-constant load and this slice's poll — past the last slice only the poll) joins this workgroup's contribution, then leaves
+            if (n == 8 && take_p) {
+                if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                acc_add(dq);
             }
+            if (n >= 9 && n < 13 && !first_it && !OBTE_SKIP(64)) store_acc(t_prev, dq, n - 9);   // (a chain's last member too: it finishes its tiles after the loop)
+            if (n == 15) rd_const1(0);
+            if (n == 8) { sc1 = zero16; if (!inside) mask_init(sc1, 1, q0); }
+            sc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % RA], fk[n % RA], sc1, 0, 0, 0);
+            OBTE_SB();
+            dp1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[n % RA], vf[1][n - 8], n == 8 ? zero16 : dp1, 0, 0, 0);
+            OBTE_SB();
         }
         OBTE_PHASE(2);
         // ---- C0: key tile 0's resident accumulators beside the softmax arithmetic of key tile 1; then C1 beside the dS image, the
@@ -494,21 +641,25 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
             const int kk = g >> 2, dt = g & 3;
             if (8 + g + RC - 1 < 16) rdC(8 + g + RC - 1);
             if (g < 4) ds_words(dw1, 1, g);
-            if (g == 3 && more) store_stats(stage_of(t + 1), (t + 1) * 32);
-            if (g == 4) {
-                OBTE_PHASE(4);
-                // the next slice's tiles (four LDS-DMA + one load, all issued before this iteration's four stores) have landed;
-                // the stores may still be in flight
-                if (!OBTE_SKIP(16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                if (!OBTE_SKIP(8)) __syncthreads();
-                OBTE_PHASE(5);
-                preload(t + 1, 0);   // (unconditional: past the last slice it reads a stage nobody wrote, and nobody uses what it read)
-            }
-            if (g == 6) preload(t + 1, 1);
             mfma_acc(dv[1][dt], cdo[(8 + g) % RC], frag_of(pw1, kk)); OBTE_SB();
             mfma_acc(dk[1][dt], cq[(8 + g) % RC], frag_of(dw1, kk)); OBTE_SB();
         }
-        OBTE_PHASE(6);
+        OBTE_PHASE(4);
+        // End of the iteration.  Everything this wave issued before this iteration's four tile stores (A1) is done: the next slice's
+        // tiles and row constants have landed, this slice's counter has been read — and so are the PREVIOUS iteration's tile stores.
+        // Those are what is counted on here: every wave's wait, the barrier, then ONE lane's add (Guideline 16, R1).  This
+        // iteration's stores stay in flight (their acknowledgement takes longer than the 40 slots since) and are counted on an
+        // iteration from now.  The same barrier publishes the next slice's tiles and this slice's dS image.
+        if (!OBTE_SKIP(16)) {
+            if (first_it) asm volatile("s_waitcnt vmcnt(0)" : "+v"(have_cur), "+v"(st_l) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" : "+v"(have_cur), "+v"(st_l) :: "memory");
+        }
+        if (more) store_stats(stage_of(it + 1), t_next * 32);
+        if (!OBTE_SKIP(8)) __syncthreads();
+        if (tid == 0 && t_sig >= 0) __hip_atomic_fetch_add(flag_b + t_sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        OBTE_PHASE(5);
+        t_sig = (!first_it && !last_p) ? t_prev : -1;   // (nobody follows a chain's last member)
+        t_prev = t; info_prev = info; have_prev = have_cur;
     }
 #ifdef OBTE_DEBUG_HOOKS
     if (stamping && tid == 0) {
@@ -519,9 +670,69 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
 #undef OBTE_PHASE
 #undef OBTE_SB
 #undef OBTE_SKIP
+    if (n_sl > 0) {   // the last slice visited: its dQ^T tile (its dS image was completed by the loop's last barrier), handed on the same way
+        const char* img = dsimg + ((n_sl - 1) & 1) * S::DSB;
+        const bool take_p = (info_prev & 0x7f) > 0;
+        if (take_p) {
+            wait_turn(t_prev, info_prev & 0x7f, have_prev);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc_request(t_prev, i);
+        }
+        f32x16 dq = zero16;
+#pragma unroll
+        for (int ks = 0; ks < FB_KEYS / 16; ++ks)
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Kblk, 16 * ks, wave, lane), ds_frag<D>(img, 16 * ks, lane), dq, 0, 0, 0);
+        if (take_p) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); acc_add(dq); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_acc(t_prev, dq, i);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (t_end > t_begin) dq_tile(t_end - 1, dsimg + ((t_end - 1 - t_begin) & 1) * S::DSB);
-    __syncthreads();   // every wave is done with the K rows (all 256 of them feed each wave's dQ tiles): they now carry rows out
+    __syncthreads();   // every wave's tiles have left; and every wave is done with the K rows (all 256 feed each wave's dQ tiles): they now carry rows out
+    if (tid == 0) {
+        if (t_sig >= 0) __hip_atomic_fetch_add(flag_b + t_sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n_sl > 0 && !(info_prev & 0x80)) __hip_atomic_fetch_add(flag_b + t_prev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // The slices whose chain this workgroup ENDED hold their complete fp32 sums, written by this very wave (same lanes, same
+    // addresses): softmax scale, inverse RoPE, one rounding to bf16.  Done here and not in the loop, where the rotation-table
+    // entries would hold 16 registers through its tightest phase; four tiles per round trip.
+    {
+        int* lastlist = kbb;   // (the key blocks' ranges are no longer needed) compact list of those slices, in visiting order
+        int n_last = 0;
+        for (int i = tid; i < n_sl; i += FB_NW * 64)
+            if (tab[i] & 0x80) {
+                int rank = 0;
+                for (int j = 0; j < i; ++j) rank += (tab[j] >> 7);
+                lastlist[rank] = slice_at(i);
+            }
+        for (int j = 0; j < n_sl; ++j) n_last += (tab[j] >> 7);   // (every thread: uniform)
+        n_last = __builtin_amdgcn_readfirstlane(n_last);
+        __syncthreads();
+        for (int base = 0; base < n_last; base += 2) {
+            // (two tiles per round trip: the second tile's loads are in flight while the first one's statement waits — vmcnt(0) in the
+            //  statement that issued them covers both)
+            AccRegs r[2];
+            RopeQ rq[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (base + j < n_last) {
+                    const int t = __builtin_amdgcn_readfirstlane(lastlist[base + j]);
+                    if (p.rope_cos) load_rope(t, rq[j]);
+                    load_acc_sync(t, r[j]);
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (base + j < n_last) {
+                    const int t = __builtin_amdgcn_readfirstlane(lastlist[base + j]);
+                    f32x16 dq;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dq[4 * i + e] = r[j].x[i][e];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) store_final(t, dq, rq[j], i);
+                }
+        }
+    }
 
     {   // dV and dK rows leave through the wave's own K rows in LDS as whole 256-byte rows (wave_rows_out); dK rotated back
         char* wl = Kblk + wave * (64 * 2 * D);
@@ -556,43 +767,6 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     }
 }
 
-// dQ = scale * sum over key blocks (in key-block order) of their fp32 contribution tiles, inverse RoPE, one rounding to bf16.
-// One workgroup per (batch, head, slice); thread (wave w, lane) owns the same 16 values it owned in the fused kernel: head-dim
-// columns 32 w + 8 i + 4 h .. + 3 (i = 0..3) of query 32 t + (lane & 31).
-template <int D>
-__global__ __launch_bounds__(256) void attn_dq_reduce_kernel(FusedParams fp) {
-    const AttnParams& p = fp.a;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-    const int t = blockIdx.x % fp.nsl;
-    const int64_t bh = blockIdx.x / fp.nsl;
-    const int64_t b = bh / p.H;
-    const int hd = (int)(bh % p.H);
-    const int T = (int)p.T, C = p.H * D;
-    const int q = t * 32 + (lane & 31);
-    f32x4 acc[4] = {};
-    for (int kb = 0; kb < fp.nkb; ++kb) {
-        const int tb = fp.kb_bounds[(bh * fp.nkb + kb) * 2], te = fp.kb_bounds[(bh * fp.nkb + kb) * 2 + 1];
-        if (t < tb || t >= te) continue;   // uniform over the workgroup
-        const float* src = fp.dq_part + ((((bh * fp.nkb + kb) * fp.nsl + t) * FB_NW + wave) * 4) * 256 + lane * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] += *reinterpret_cast<const f32x4*>(src + i * 256);
-    }
-    if (q >= T) return;
-    bf16* out = p.dqkv + (b * T + q) * 3 * (int64_t)C + hd * D + 32 * wave + 4 * h;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float g[4] = {acc[i][0] * p.scale, acc[i][1] * p.scale, acc[i][2] * p.scale, acc[i][3] * p.scale};
-        if (p.rope_cos) {
-            const int64_t at = (int64_t)q * (D / 2) + (32 * wave + 8 * i + 4 * h) / 2;
-            const float2 cc = *reinterpret_cast<const float2*>(p.rope_cos + at), ss = *reinterpret_cast<const float2*>(p.rope_sin + at);
-            const float e0 = g[0] * cc.x + g[1] * ss.x, o0 = -g[0] * ss.x + g[1] * cc.x;
-            const float e1 = g[2] * cc.y + g[3] * ss.y, o1 = -g[2] * ss.y + g[3] * cc.y;
-            g[0] = e0; g[1] = o0; g[2] = e1; g[3] = o1;
-        }
-        *reinterpret_cast<bf16x4*>(out + 8 * i) = bf16x4{f2bf(g[0]), f2bf(g[1]), f2bf(g[2]), f2bf(g[3])};
-    }
-}
-
 template __global__ void attn_bwd_fused_kernel<128, MASK_NONE>(FusedParams);
 template __global__ void attn_bwd_fused_kernel<128, MASK_RANGES>(FusedParams);
 #ifdef OBTE_DEBUG_HOOKS
@@ -601,27 +775,41 @@ template __global__ void attn_bwd_fused_kernel<128, MASK_RANGES>(FusedParams);
 OBTE_FUSED_SKIPS(X)
 #undef X
 #endif
-template __global__ void attn_dq_reduce_kernel<128>(FusedParams);
 
 }  // namespace
 
 namespace obte_attn {
 
+// scratch: the running dQ^T tiles, the slices' counters, the key blocks' slice ranges, the error word
+static void ws_layout(int64_t B, int64_t T, int H, int64_t& nkb, int64_t& nsl, int64_t& o_flags, int64_t& o_bounds, int64_t& o_err, int64_t& total) {
+    nkb = (T + FB_KEYS - 1) / FB_KEYS; nsl = (T + 31) / 32;
+    auto up = [](int64_t x) { return (x + 255) & ~int64_t(255); };
+    o_flags = up(B * H * nsl * (32 * 128 * 4));
+    o_bounds = o_flags + up(B * H * nsl * 4);
+    o_err = o_bounds + up(B * nkb * 2 * 4);
+    total = o_err + 256;
+}
 int64_t fused_bwd_ws_bytes(int64_t B, int64_t T, int H) {
-    const int64_t nkb = (T + FB_KEYS - 1) / FB_KEYS, nsl = (T + 31) / 32;
-    return B * H * nkb * nsl * (32 * 128 * 4) + (32 * 128 * 4) + B * H * nkb * 2 * 4 + 256;   // contributions, one scratch tile, bounds
+    int64_t nkb, nsl, a, b2, c, total;
+    ws_layout(B, T, H, nkb, nsl, a, b2, c, total);
+    return (nsl <= FusedShape<128>::TAB && nkb <= 120) ? total : (int64_t)1 << 62;   // longer sequences: the two-kernel form
 }
 
 // mode: MASK_NONE or MASK_RANGES.  ws: fused_bwd_ws_bytes() bytes.
 int launch_bwd_fused(const AttnParams& p, int mode, void* ws, hipStream_t st) {
     FusedParams fp;
     fp.a = p;
-    fp.nkb = (int)((p.T + FB_KEYS - 1) / FB_KEYS);
-    fp.nsl = (int)((p.T + 31) / 32);
-    fp.dq_part = reinterpret_cast<float*>(ws);
-    fp.kb_bounds = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + (p.B * p.H * (int64_t)fp.nkb * fp.nsl + 1) * (32 * 128 * 4));
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)cdiv64(p.B * p.T, 4)), dim3(256), 0, st, p.o_in, p.d_o, p.delta, p.B, p.T, p.H);
-    OBTE_CHECK_LAUNCH("obte_attn_bwd(delta)");
+    int64_t nkb, nsl, o_flags, o_bounds, o_err, total;
+    ws_layout(p.B, p.T, p.H, nkb, nsl, o_flags, o_bounds, o_err, total);
+    fp.nkb = (int)nkb; fp.nsl = (int)nsl;
+    char* w = reinterpret_cast<char*>(ws);
+    fp.dq_acc = reinterpret_cast<float*>(w);
+    fp.flags = reinterpret_cast<int32_t*>(w + o_flags);
+    fp.kb_bounds = reinterpret_cast<int32_t*>(w + o_bounds);
+    fp.err = reinterpret_cast<int32_t*>(w + o_err);
+    const int nb_delta = (int)cdiv64(p.B * p.T, 4), nb_flags = (int)cdiv64(p.B * p.H * nsl, 256);
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)(nb_delta + nb_flags + p.B * nkb)), dim3(256), 0, st, fp, mode, nb_delta, nb_flags);
+    OBTE_CHECK_LAUNCH("obte_attn_bwd(prep)");
     const int smem = FusedShape<128>::SMEM;
     const dim3 grid((unsigned)(fp.nkb * p.H * p.B)), block(FB_NW * 64);
     if (mode == MASK_NONE) {
@@ -648,7 +836,7 @@ int launch_bwd_fused(const AttnParams& p, int mode, void* ws, hipStream_t st) {
         if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hbuf.data(), p.dbg_times, hbuf.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
             double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int i = 0; i < n; ++i) for (int k = 0; k < 8; ++k) sum[k] += (double)hbuf[(size_t)i * 8 + k];
-            const char* names[8] = {"A0", "D+SM0", "A1", "C0+SM1", "C1a", "wait+barrier", "C1b+preload", "loop edge"};
+            const char* names[8] = {"A0", "D+SM0", "A1", "C0+SM1", "C1", "wait+barrier+signal", "-", "top (tile request, first reads)"};
             double tot = 0; for (int k = 0; k < 8; ++k) tot += sum[k];
             fprintf(stderr, "[attn fused phases, cycles per slice per workgroup (%d slices)]", fp.nsl);
             for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.0f (%.0f%%)", names[k], sum[k] / n / fp.nsl, 100.0 * sum[k] / tot);
@@ -656,8 +844,6 @@ int launch_bwd_fused(const AttnParams& p, int mode, void* ws, hipStream_t st) {
         }
     }
 #endif
-    hipLaunchKernelGGL((attn_dq_reduce_kernel<128>), dim3((unsigned)(p.B * p.H * fp.nsl)), dim3(256), 0, st, fp);
-    OBTE_CHECK_LAUNCH("obte_attn_bwd(dq reduce)");
     return OBTE_OK;
 }
 

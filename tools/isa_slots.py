@@ -6,7 +6,7 @@ import sys
 s = open(sys.argv[1]).read()
 want = sys.argv[2]
 dump = sys.argv[sys.argv.index("--dump") + 1] if "--dump" in sys.argv else None
-for k in re.split(r'\n(?=_Z\w+:)', s):
+for k in re.split(r'\n(?=_Z\w+:\s*\n)', s):
     m = re.match(r'(_Z\w+):', k)
     if not m or want not in m.group(1):
         continue
@@ -14,7 +14,7 @@ for k in re.split(r'\n(?=_Z\w+:)', s):
     labels = {mm.group(1): i for i, l in enumerate(lines) for mm in [re.match(r'(\.LBB\d+_\d+):', l)] if mm}
     print(m.group(1))
     for i, l in enumerate(lines):
-        mm = re.search(r's_cbranch\w+\s+(\.LBB\d+_\d+)', l)
+        mm = re.search(r's_c?branch\w*\s+(\.LBB\d+_\d+)', l)
         if mm and labels.get(mm.group(1), 1 << 30) < i:
             a = labels[mm.group(1)]
             body = lines[a:i]
