@@ -46,7 +46,8 @@ struct FusedShape {
     static constexpr int NSTG = 2;
     static constexpr int TAB = 1024;                 // chain table: one byte per slice this workgroup sweeps (nsl <= 1024)
     static constexpr int ACC = 32 * D * 4;           // the dQ^T tile handed on to this workgroup, staged by LDS-DMA (each wave its own 4 KiB)
-    static constexpr int SMEM = NSTG * STAGE + KBYTES + 2 * DSB + ACC + 64 + TAB + 1024;   // (+ the key blocks' slice ranges)
+    static constexpr int RAW = FB_NW * 512;          // per wave: the next slice's lse / delta values and this slice's counter as LDS-DMA left them
+    static constexpr int SMEM = NSTG * STAGE + KBYTES + 2 * DSB + ACC + 64 + TAB + 1024 + RAW;   // (+ the key blocks' slice ranges)
 };
 
 struct FusedParams {
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     char* dsimg = Kblk + S::KBYTES;
     char* accst = dsimg + 2 * S::DSB;
     int* scratch = reinterpret_cast<int*>(accst + S::ACC);
+    char* rawst = accst + S::ACC + 64 + S::TAB + 1024;
 
     // ---- this wave's 64 keys: two MFMA tiles of 32, key on the lane ----------------------------------------------
     int key[2], qs[2], qe[2];
@@ -269,12 +271,18 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
             st_l = ((tid >> 5) == 1 ? del_b : lse_b)[q];
         }
     };
-    // the loop's form: issued by EVERY wave (the counted waits below count the same operations in all four) and through asm (not
-    // waited for by hipcc; the C1 wait names it)
+    // the loop's form: issued by EVERY wave (the counted waits below count the same operations in all four), through asm (hipcc
+    // does not wait for it) and by LDS-DMA into the wave's own 256 bytes: NO load with a register destination stays in flight
+    // across statements in this kernel.  (It used to: hipcc counts such a destination as written when the asm statement ends and
+    // is free to copy it, and it did copy it in front of the end-of-iteration wait — harmless while the load had long returned,
+    // the previous slice's lse / delta whenever the memory system was busy enough to make it late.)
     const float* const st_src = ((tid >> 5) == 1 ? del_b : lse_b);
+    const uint32_t a_raw = lds_addr_of(rawst) + wave * 512;
+    const float* const raw_st = reinterpret_cast<const float*>(rawst + wave * 512) + lane;
+    const int* const raw_poll = reinterpret_cast<const int*>(rawst + wave * 512 + 256) + lane;
     auto load_stats_issue = [&](int q0) {
         const float* a = st_src + min(q0 + (tid & 31), T - 1);
-        asm volatile("global_load_dword %0, %1, off" : "=v"(st_l) : "v"(a) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off" : : "s"(a_raw), "v"(a) : "memory");
     };
     // row constants of a slice: -lse / scale and -delta are the INITIAL ACCUMULATORS of key tile 0's two chains (S - lse / scale,
     // dP - delta come out of the MFMAs ready); key tile 1 starts from zero and adds -lse log2(e), -delta in its arithmetic (its
@@ -308,9 +316,9 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     // their first use (and of unrelated instructions that reuse a register), which in this in-order queue also drains the LDS-DMA
     // just issued for the next slice.  Their completion is covered by the waits the loop has anyway (named at each use).
     const int32_t* const flag_s = flag_b;                                   // wave-uniform: an SGPR pair
-    auto poll_issue = [&](int t, int& dst) {                                // counter of slice t -> dst, NOT waited for
+    auto poll_issue = [&](int t) {                                          // counter of slice t -> the wave's raw area, NOT waited for
         const int off = t * 4;
-        asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(dst) : "v"(off), "s"(flag_s) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2 sc1" : : "s"(a_raw + 256), "v"(off), "s"(flag_s) : "memory");
     };
     // the counter of slice t has reached `place` (every wave polls for itself: its own tile loads follow its own poll); `have` is
     // the value polled an iteration ago — in steady state it already suffices and nothing is loaded here
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
                 if (n >= 4) issue_piece(it + 1, t_next, n - 4);
                 if (n == 7) load_stats_issue(t_next * 32);
             }
-            if (n == 7) poll_issue(t, have_cur);      // this slice's counter, looked at an iteration from now (after the end-of-iteration wait)
+            if (n == 7) poll_issue(t);                // this slice's counter, looked at an iteration from now (after the end-of-iteration wait)
             sc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % RA], fk[n % RA], sc0, 0, 0, 0);
             OBTE_SB();
             dp0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[n % RA], vf[0][n], dp0, 0, 0, 0);
@@ -651,9 +659,11 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         // iteration's stores stay in flight (their acknowledgement takes longer than the 40 slots since) and are counted on an
         // iteration from now.  The same barrier publishes the next slice's tiles and this slice's dS image.
         if (!OBTE_SKIP(16)) {
-            if (first_it) asm volatile("s_waitcnt vmcnt(0)" : "+v"(have_cur), "+v"(st_l) :: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" : "+v"(have_cur), "+v"(st_l) :: "memory");
+            if (first_it) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         }
+        st_l = *raw_st;          // (behind the wait: what the two LDS-DMA loads of this iteration left in this wave's raw area)
+        have_cur = *raw_poll;
         if (more) store_stats(stage_of(it + 1), t_next * 32);
         if (!OBTE_SKIP(8)) __syncthreads();
         if (tid == 0 && t_sig >= 0) __hip_atomic_fetch_add(flag_b + t_sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

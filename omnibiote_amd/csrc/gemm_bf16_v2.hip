@@ -42,7 +42,7 @@ template <int BN> struct Cfg {
     static constexpr int NSTAGE = BN == 128 ? 3 : 2;
     static constexpr int EPI_BYTES = 8 * 64 * 272;       // epilogue staging: 8 waves x 64 rows x (<=128 bf16 | 64 f32, + pad)
     static constexpr int SMEM = NSTAGE * STAGE > EPI_BYTES ? NSTAGE * STAGE : EPI_BYTES;   // 144 KiB / 136 KiB: one workgroup per CU
-    static constexpr int NPB = BN / 64;                  // LDS-DMA pieces per wave for the B tile (A: 4)
+    static constexpr int NPB = BN / 64;                  // LDS-DMA pieces per wave for the B tile (A: 4); BN = 192: 3
     static constexpr int NJ = BN / 32;                   // 16-wide n sub-tiles per wave (wave tile 64 x BN/2)
 };
 constexpr int EPI_LD_F32 = 272;                 // bytes per staged f32 row: 64 f32 + 16 B pad
@@ -157,10 +157,15 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
         return;
     }
 
-    // staged row: NW bf16 + 16 B pad (144 B for the 64-wide wave tile, 272 B for the 128-wide one)
+    // staged row: NW bf16 + 16 B pad (144 B for the 64-wide wave tile, 208 B for the 96-wide, 272 B for the 128-wide one)
     constexpr int LDE = NW * 2 + 16;
     constexpr int CPRE = NW / 8;            // 16-B chunks per staged row
-    constexpr int RPI = 64 / CPRE;          // rows covered by one wave-wide 16-B access
+    // the wave's 64 x NW tile leaves as 64 * CPRE 16-byte chunks, 64 per wave-wide access: chunk 64 it + lane = (row, c8).  For a
+    // power-of-two CPRE that is rows it * (64 / CPRE) + lane / CPRE of one column chunk per lane; the 96-wide wave tile
+    // (BN = 192, CPRE = 12) walks rows and columns together.
+    constexpr int NIT = CPRE;
+    auto chunk_row = [&](int it) { return (64 * it + lane) / CPRE; };
+    auto chunk_c8 = [&](int it) { return (64 * it + lane) % CPRE; };
     char* stg = smem + wave * (64 * LDE);
 #pragma unroll
     for (int ni = 0; ni < NJ; ++ni)
@@ -177,35 +182,38 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     // across, and vmcnt retires in issue order: every load waited for the previous iteration's STORE to reach memory — 16
     // dependent round trips per tile (c_fc dgrad + GELU': 38 of its 103 us were this epilogue).
     constexpr bool READS = EPI == OBTE_EPI_ADD || EPI == OBTE_EPI_GELU_BWD || EPI == OBTE_EPI_ADD_DROPOUT || EPI == OBTE_EPI_ROPE_QK;
-    constexpr int NIT = 64 / RPI;
     const bool interior = m0 + BM <= p.store_rows && n0 + tile_n <= p.N && (EPI != OBTE_EPI_ADD || p.aux != nullptr);
     if (interior) {   // (the epilogues without loads take it too: no bounds branches, so the staged reads are issued ahead of the arithmetic)
-        const int row_l = lane / CPRE, c8 = lane % CPRE;
-        const int64_t n = n0 + wn * NW + c8 * 8;
-        const int64_t o0 = (m0 + wm * 64 + row_l) * p.ldd + n;
+        // output offset and column of chunk `it`: for a power-of-two CPRE the lane keeps its column and steps 64 / CPRE rows
+        constexpr bool POW2 = (CPRE & (CPRE - 1)) == 0;
+        const int64_t n_l = n0 + wn * NW + (lane % CPRE) * 8;
+        const int64_t o_l = (m0 + wm * 64 + lane / CPRE) * p.ldd + n_l;
+        auto nn_of = [&](int it) { return POW2 ? n_l : n0 + wn * NW + chunk_c8(it) * 8; };
+        auto oo_of = [&](int it) { return POW2 ? o_l + (int64_t)it * (64 / CPRE) * p.ldd : (m0 + wm * 64 + chunk_row(it)) * p.ldd + nn_of(it); };
         bf16x8 r[NIT];
         f32x4 rc[NIT], rs[NIT];
-        bool rot = false;
         if (EPI == OBTE_EPI_ROPE_QK) {
-            rot = n < 2 * (p.N / 3);   // lanes on the v third load the same (valid) table rows and leave their values alone
-            const uint32_t T32 = (uint32_t)p.rope_T, hs32 = (uint32_t)p.rope_hs, nu = (uint32_t)n;
-            const uint32_t dd = (hs32 & (hs32 - 1)) == 0 ? (nu & (hs32 - 1)) : (nu % hs32);
+            const uint32_t T32 = (uint32_t)p.rope_T, hs32 = (uint32_t)p.rope_hs;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const uint32_t mu = (uint32_t)(m0 + wm * 64 + row_l + it * RPI);
+            for (int it = 0; it < NIT; ++it) {   // lanes on the v third load the same (valid) table rows and leave their values alone
+                const uint32_t nu = (uint32_t)nn_of(it);
+                const uint32_t dd = (hs32 & (hs32 - 1)) == 0 ? (nu & (hs32 - 1)) : (nu % hs32);
+                const uint32_t mu = (uint32_t)(m0 + wm * 64 + chunk_row(it));
                 const uint32_t t = (T32 & (T32 - 1)) == 0 ? (mu & (T32 - 1)) : (mu % T32);
                 rc[it] = *reinterpret_cast<const f32x4*>(p.rope_cos + t * (hs32 / 2) + dd / 2);
                 rs[it] = *reinterpret_cast<const f32x4*>(p.rope_sin + t * (hs32 / 2) + dd / 2);
             }
         } else if (READS) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) r[it] = *reinterpret_cast<const bf16x8*>(p.aux + o0 + (int64_t)it * RPI * p.ldd);
+            for (int it = 0; it < NIT; ++it) r[it] = *reinterpret_cast<const bf16x8*>(p.aux + oo_of(it));
         }
         __syncthreads();   // the staged tile is complete
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + (it * RPI + row_l) * LDE + c8 * 16);
-            const int64_t o = o0 + (int64_t)it * RPI * p.ldd;
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + chunk_row(it) * LDE + chunk_c8(it) * 16);
+            const int64_t o = oo_of(it);
+            const int64_t n = nn_of(it);
+            const bool rot = n < 2 * (p.N / 3);
             if (EPI == OBTE_EPI_GELU) {
                 bf16x8 g;
 #pragma unroll
@@ -231,7 +239,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
                     v[2 * j + 1] = rot ? no : v[2 * j + 1];
                 }
             } else if (EPI == OBTE_EPI_ADD_DROPOUT) {
-                const int64_t m = m0 + wm * 64 + row_l + it * RPI;
+                const int64_t m = m0 + wm * 64 + chunk_row(it);
                 const uint32_t rk = drop_rowkey((uint64_t)m, p.drop);   // dropout element = (row m, column n + j)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
@@ -251,9 +259,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 64 / RPI; ++it) {
-        const int row = it * RPI + lane / CPRE;
-        const int c8 = lane % CPRE;
+    for (int it = 0; it < NIT; ++it) {
+        const int row = chunk_row(it);
+        const int c8 = chunk_c8(it);
         const int64_t m = m0 + wm * 64 + row;
         const int64_t n = n0 + wn * NW + c8 * 8;
         if (m < p.store_rows && n < p.N) {
@@ -456,6 +464,12 @@ OBTE_INST(true, false, 256)
 OBTE_INST(false, true, 256)
 OBTE_INST(false, false, 256)
 #undef OBTE_INST
+// BN = 192: k-contiguous operands only (the forward projections), no split-K.  For outputs whose width is a multiple of 192 but
+// leaves the 256-wide tiling a ragged last round — c_attn at the small config: N = 3072 is 384 tiles of 256 x 256 = 1.5 rounds of
+// the 256 CUs, and 512 tiles of 256 x 192 = two full ones (a quarter less work per round).
+#define OBTE_INST192(EPI) template __global__ void gemm_v2_kernel<true, true, EPI, false, 192>(GemmParams);
+OBTE_INST192(OBTE_EPI_NONE) OBTE_INST192(OBTE_EPI_GELU) OBTE_INST192(OBTE_EPI_ADD) OBTE_INST192(OBTE_EPI_ADD_DROPOUT) OBTE_INST192(OBTE_EPI_ROPE_QK)
+#undef OBTE_INST192
 
 // ---- third structure: 256x256 tile, ring of FOUR half K-tiles (32 k each, 32 KiB), loads three half-steps ahead ----
 // The 2-stage ring above keeps at most one 64-KiB K-tile in flight per CU and each burst has to complete inside one
@@ -982,6 +996,17 @@ template <bool AK, bool BK>
 int dispatch(const GemmParams& p, int epi, int bn, hipStream_t st) {
     return bn == 256 ? dispatch_bn<AK, BK, 256>(p, epi, st) : dispatch_bn<AK, BK, 128>(p, epi, st);
 }
+int dispatch192(const GemmParams& p, int epi, hipStream_t st) {   // k-contiguous A and B, no split
+    switch (epi) {
+        case OBTE_EPI_NONE: return launch<true, true, OBTE_EPI_NONE, false, 192>(p, st);
+        case OBTE_EPI_GELU: return launch<true, true, OBTE_EPI_GELU, false, 192>(p, st);
+        case OBTE_EPI_ADD: return launch<true, true, OBTE_EPI_ADD, false, 192>(p, st);
+        case OBTE_EPI_ADD_DROPOUT: return launch<true, true, OBTE_EPI_ADD_DROPOUT, false, 192>(p, st);
+        case OBTE_EPI_ROPE_QK: return launch<true, true, OBTE_EPI_ROPE_QK, false, 192>(p, st);
+    }
+    obte_set_error("obte_gemm_bf16: epilogue %d has no 192-wide form", epi);
+    return OBTE_EINVAL;
+}
 
 bool use_v1() {
     static int v = -1;
@@ -1073,7 +1098,9 @@ static bool lookup_plan(const obte_gemm_args* g, Plan* out, bool* near_match = n
 
 extern "C" int obte_gemm_plan_set(int a_kmajor, int b_kmajor, int epilogue, int64_t M, int64_t N, int64_t K, int variant,
                                   int bn, int splits) {
-    OBTE_REQUIRE(variant >= 1 && variant <= 4 && (bn == 128 || bn == 256) && splits >= 1 && splits <= 64, "obte_gemm_plan_set: bad plan");
+    OBTE_REQUIRE(variant >= 1 && variant <= 4 && (bn == 128 || bn == 256 || bn == 192) && splits >= 1 && splits <= 64, "obte_gemm_plan_set: bad plan");
+    OBTE_REQUIRE(!(bn == 192 && (variant != 2 || splits != 1 || !a_kmajor || !b_kmajor || epilogue == OBTE_EPI_GELU_BWD)),
+                 "obte_gemm_plan_set: the 192-wide tile exists for the K-tile ring, k-contiguous operands, no split-K");
     OBTE_REQUIRE(!(variant == 3 && bn != 256), "obte_gemm_plan_set: the four-half-stage structure is 256 wide");
     OBTE_REQUIRE(!(variant == 4 && bn != 128), "obte_gemm_plan_set: the two-workgroups-per-CU structure is 128 wide");
     OBTE_REQUIRE(!(variant == 1 && splits != 1), "obte_gemm_plan_set: the first structure has no split-K");
@@ -1222,6 +1249,7 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
         while (pl.splits > 1 && tiles <= 256 && tiles * pl.splits > 256) --pl.splits;
     }
     if (pl.splits > 1 && (!can_split || (int64_t)pl.splits * g->M * g->N * 4 > workspace_bytes)) pl = make_plan(g->M, g->N, g->K, false);
+    if (pl.bn == 192 && !(g->a_kmajor && g->b_kmajor && g->epilogue != OBTE_EPI_GELU_BWD)) pl = make_plan(g->M, g->N, g->K, false);
     // profiler record kind = layout/epilogue code + 1000 * kernel structure (1: gemm_bf16_kernel, 2: gemm_v2_kernel, 3: gemm_v3_kernel)
     const int kind0 = (g->a_kmajor ? 8 : 0) + (g->b_kmajor ? 4 : 0) + g->epilogue;
     if (use_v1() || pl.variant == 1) {
@@ -1259,7 +1287,8 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
         else if (g->a_kmajor && !g->b_kmajor) rc = dispatch3<true, false>(p, g->epilogue, st);
         else if (!g->a_kmajor && g->b_kmajor) rc = dispatch3<false, true>(p, g->epilogue, st);
         else rc = dispatch3<false, false>(p, g->epilogue, st);
-    } else if (g->a_kmajor && g->b_kmajor) rc = dispatch<true, true>(p, g->epilogue, pl.bn, st);
+    } else if (pl.bn == 192) rc = dispatch192(p, g->epilogue, st);
+    else if (g->a_kmajor && g->b_kmajor) rc = dispatch<true, true>(p, g->epilogue, pl.bn, st);
     else if (g->a_kmajor && !g->b_kmajor) rc = dispatch<true, false>(p, g->epilogue, pl.bn, st);
     else if (!g->a_kmajor && g->b_kmajor) rc = dispatch<false, true>(p, g->epilogue, pl.bn, st);
     else rc = dispatch<false, false>(p, g->epilogue, pl.bn, st);

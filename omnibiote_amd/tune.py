@@ -50,9 +50,11 @@ def _time_once(a, b, M, N, K, ak, bk, epi, aux, out, reps=6, rope=None) -> float
     return best
 
 
-def candidates(M: int, N: int, K: int, epi: int) -> List[Tuple[int, int, int]]:
+def candidates(M: int, N: int, K: int, epi: int, a_kmajor: bool = False, b_kmajor: bool = False) -> List[Tuple[int, int, int]]:
     """(variant, bn, splits)."""
     c = [(1, 128, 1), (2, 128, 1)]
+    if a_kmajor and b_kmajor and N % 192 == 0 and epi != L.EPI_GELU_BWD:
+        c.append((2, 192, 1))      # 256 x 192 tiles: full rounds where N / 256 leaves a ragged one (c_attn: 3072 -> 512 tiles)
     if K >= 128:
         c.append((4, 128, 1))      # the half-tile ring at two workgroups per CU
     if N >= 256:
@@ -102,7 +104,7 @@ def tune_gemm(M: int, N: int, K: int, a_kmajor: bool, b_kmajor: bool, epi: int =
         rope = (torch.cos(tab), torch.sin(tab), T, hs)
     # round-robin over the candidates (three rounds, best time kept): the clock the chip holds drifts while it is being
     # measured, and timing the candidates one after the other hands the later ones a different machine
-    cands = candidates(M, N, K, epi)
+    cands = candidates(M, N, K, epi, a_kmajor, b_kmajor)
     best = {c: float("inf") for c in cands}
     for _ in range(3):
         for c in cands:

@@ -130,15 +130,18 @@ def _run_headline_step(per_pass, pipeline_streams, tuned, impl="masked"):
             tune._done.clear()
     loss = out["loss"].item()
     assert abs(loss - ref_loss) <= 0.02, (loss, ref_loss)
-    worst = (1.0, 0.0, "")
+    errs = []
     for k, p in m.named_parameters():
         got, want = p.grad.float().cpu().flatten(), ref_grads[k].flatten()
         assert torch.isfinite(got).all(), k
         cos = (torch.dot(got, want) / (got.norm() * want.norm() + 1e-30)).item()
         rel = ((got - want).norm() / (want.norm() + 1e-30)).item()
-        if cos < worst[0]:
-            worst = (cos, rel, k)
-        assert cos >= 0.9995 and rel <= 0.04, (k, cos, rel)    # the bars of test_hip_configs45.py's full-size tests
+        errs.append((cos, rel, k))
+    errs.sort()
+    worst = errs[0]
+    print("[headline] least-aligned gradients: " + "; ".join(f"{k} cos {c:.5f} rel {r:.4f}" for c, r, k in errs[:4]))
+    bad = [(k, c, r) for c, r, k in errs if not (c >= 0.9995 and r <= 0.04)]   # the bars of test_hip_configs45.py's full-size tests
+    assert not bad, bad
     # rows of the embedding no (masked) token selected receive no gradient at all
     touched = torch.zeros(s["V"], dtype=torch.bool)
     touched[R.mlm_corrupt(ids, mlm)[0].reshape(-1)] = True

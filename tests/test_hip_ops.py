@@ -694,6 +694,54 @@ def test_gemm_both_tile_widths(monkeypatch, bn):
     close(o.linear_fwd(x.to(DEV), w.to(DEV), alpha=1 / 42.0), acc / 42.0, atol=2e-3, what="alpha")
 
 
+def test_gemm_192_wide_tile():
+    """The 256 x 192 tile of the K-tile ring (N = 3072 is sixteen of them: two full rounds of 256 workgroups instead of
+    one and a half of the 256-wide tile), installed through the plan table for x @ W^T: plain, GELU pair, residual add,
+    RoPE epilogue, ragged M/N/K edges, and an exact identity product."""
+    o, lib = ops(), L().lib()
+    def plan(epi, M, N, K):
+        L().check(lib.obte_gemm_plan_set(1, 1, epi, M, N, K, 2, 192, 1), "obte_gemm_plan_set")
+    try:
+        for (M, N, K) in [(520, 392, 256), (256, 192, 128), (300, 1000, 1024), (1024, 3072, 1024), (77, 576, 192)]:
+            plan(L().EPI_NONE, M, N, K)
+            x, w = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=0.2)
+            close(o.linear_fwd(x.to(DEV), w.to(DEV)), x.float() @ w.float().t(), atol=0.02 * math.sqrt(K) * 0.2, what=f"NT 192 {M}x{N}x{K}")
+        plan(L().EPI_NONE, 256, 512, 256)
+        eye = torch.eye(256).to(BF)
+        b = (torch.arange(512 * 256).reshape(512, 256) % 251 - 125).float().to(BF)
+        assert torch.equal(o.linear_fwd(eye.to(DEV), b.to(DEV)).cpu().float(), b.float().t())
+        M, N, K = 300, 520, 128
+        x, w, r = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=0.2), rnd(M, N, seed=9)
+        acc = x.float() @ w.float().t()
+        plan(L().EPI_ADD, M, N, K)
+        close(o.linear_fwd(x.to(DEV), w.to(DEV), epilogue=L().EPI_ADD, aux=r.to(DEV)), r.float() + acc.to(BF).float(), atol=0.03, what="add 192")
+        plan(L().EPI_GELU, M, N, K)
+        d, d2 = o.linear_fwd(x.to(DEV), w.to(DEV), epilogue=L().EPI_GELU)
+        pre = acc.to(BF).float().requires_grad_(True)
+        R.gelu_erf(pre).sum().backward()
+        close(d, pre.grad, atol=0.03, what="gelu derivative 192")   # (d carries GELU'(pre-activation), what the backward multiplies by)
+        close(d2, R.gelu_erf(acc.to(BF).float()), atol=0.03, what="gelu act 192")
+        # the plan may not be installed for layouts or epilogues the tile does not implement
+        with pytest.raises(RuntimeError, match="192-wide tile"):
+            L().check(lib.obte_gemm_plan_set(0, 0, 0, M, N, K, 2, 192, 1), "obte_gemm_plan_set")
+        with pytest.raises(RuntimeError, match="192-wide tile"):
+            L().check(lib.obte_gemm_plan_set(1, 1, L().EPI_GELU_BWD, M, N, K, 2, 192, 1), "obte_gemm_plan_set")
+        # RoPE epilogue: bit-equal to the projection under the same tile followed by the stand-alone RoPE kernel
+        from omnibiote_amd.model import rope_tables
+        for hs, B, T, H in [(128, 2, 77, 3), (64, 2, 130, 6)]:
+            C = H * hs
+            x, w = rnd(B * T, C, seed=61), rnd(3 * C, C, seed=62, scale=0.1)
+            cos, sin = rope_tables(R.cast_rope_table(R.rope_table(hs, 256), BF).to(DEV))
+            plan(L().EPI_ROPE_QK, B * T, 3 * C, C)
+            plan(L().EPI_NONE, B * T, 3 * C, C)
+            fused = o.gemm(x.to(DEV), w.to(DEV), B * T, 3 * C, C, True, True, L().EPI_ROPE_QK, rope=(cos, sin, T, hs))
+            plain = o.linear_fwd(x.to(DEV), w.to(DEV))
+            o.rope_qk_(plain, cos, sin, B, T, H, hs)
+            assert torch.equal(fused, plain)
+    finally:
+        L().check(lib.obte_gemm_plan_clear(), "obte_gemm_plan_clear")
+
+
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_gemm_grouped_matches_single_launches(accumulate):
     """One grouped launch of four weight-gradient shaped products (ragged M/N, K not a multiple of 64) plus a shorter

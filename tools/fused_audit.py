@@ -1,7 +1,7 @@
 """Audit of csrc/attention_bwd_fused.hip's ISA (hipcc -S output): inside the slice loop, (1) no scratch access (a spill reload is a
-vector-memory operation: it breaks the counted s_waitcnt vmcnt the loop relies on), and (2) no instruction touches the destination
-registers of an asm-issued load between the load and the wait that covers it (hipcc counts an asm load's destination as written at
-the end of the statement).    python tools/fused_audit.py /tmp/t/f/fused.s"""
+vector-memory operation: it breaks the counted s_waitcnt vmcnt the loop relies on), and (2) no vector-memory load with a register destination is left in flight
+past its own statement (hipcc counts an asm load's destination as written at the end of the statement and may copy it at any point
+after that: round 4's stale lse / delta under load was such a copy, placed right in front of the wait that covered the load).    python tools/fused_audit.py /tmp/t/f/fused.s"""
 import re
 import sys
 
@@ -33,17 +33,15 @@ for name in re.findall(r'^(_ZN\S*attn_bwd_fused_kernel\S*?):', s, re.M):
         nscr = sum('scratch_' in x for x in body)
         print(f"{name[:70]}: loop of {len(body)} lines, scratch accesses {nscr}")
         bad += nscr
+        # every vector-memory load with a REGISTER destination is waited for by the very next instruction (its own asm statement):
+        # the register allocator may copy such a destination anywhere after the statement, so nothing may stay in flight past it
         for k, x in enumerate(body):
-            if 'lds' in x or not re.search(r'(global_load_dword\w* v|buffer_load_dword\w* v)', x):
+            if re.search(r'\blds\b|_load_lds_', x) or not re.search(r'(global_load_\w+ v|buffer_load_\w+ v|flat_load_\w+ v)', x):
                 continue
-            dst = regs(x.split(',')[0])
-            for kk in range(k + 1, k + len(body)):
-                y = body[kk % len(body)].strip()
-                if re.match(r's_waitcnt vmcnt\(\d+\)', y):
-                    break
-                if y and not y.startswith(';') and regs(y) & dst:
-                    print(f"   TOUCHED before its wait: {x.strip()}  <-  {y}")
-                    bad += 1
+            nxt = next(y.strip() for y in body[k + 1:] if y.strip() and not y.strip().startswith(';'))
+            if not re.match(r's_waitcnt vmcnt\(0\)', nxt):
+                print(f"   register-destination load left in flight: {x.strip()}  (next: {nxt})")
+                bad += 1
         break
 print("audit", "FAILED" if bad else "ok")
 sys.exit(1 if bad else 0)
