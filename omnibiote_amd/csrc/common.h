@@ -51,6 +51,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// The same sum through DPP (quad swaps, the two mirrors of a row of 16, row_bcast:15 / :31 of the wave64 form, lane 63 read back):
+// seven ~8-cycle steps instead of six ds_bpermute round trips of ~64+ cycles each — in a one-row-per-wave kernel those round trips sit
+// on the path between the row's load and its store.  Another summation order than wave_sum: equal to fp32 rounding, not bitwise.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_moved(float v) {   // lanes outside ROW_MASK (and sources outside the wave) read 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_moved<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_moved<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_moved<0x141>(v);         // row_half_mirror
+    v += dpp_moved<0x140>(v);         // row_mirror: every lane holds the sum of its row of 16
+    v += dpp_moved<0x142, 0xa>(v);    // row_bcast:15 -> rows 1 and 3 add the row before them
+    v += dpp_moved<0x143, 0xc>(v);    // row_bcast:31 -> rows 2 and 3 add lanes 0..31's total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

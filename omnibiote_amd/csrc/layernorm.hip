@@ -9,46 +9,64 @@ namespace {
 
 constexpr int LN_BWD_MAX_BLOCKS = 512;   // rows of the fp32 partial workspace; the grid itself is 256 workgroups (see the pipelined kernel)
 
-template <int NCH>
+// FULL: cols == 512 * NCH exactly (1024, 2048: every hot-path shape).  Nothing is conditional then, so the row's loads AND the weight's
+// are all in flight before the first use and the reductions go through DPP: one memory round trip per row.  (With the column tests
+// hipcc waits for each 16-byte load before it issues the next and fetches the weights after the second reduction — four dependent
+// round trips per row, found in the ISA in round 4.)
+template <int NCH, bool FULL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
                                                       bf16* __restrict__ y, float* __restrict__ mean,
                                                       float* __restrict__ rstd, int64_t rows, int cols, float eps) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     if (row >= rows) return;
     const bf16* xr = x + row * cols;
     float v[NCH][8];
+    bf16x8 wq[NCH];
     float sum = 0.f;
+    if (FULL) {
+        bf16x8 t[NCH];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = (lane + 64 * i) * 8;
-        if (c < cols) {
-            const bf16x8 t = *reinterpret_cast<const bf16x8*>(xr + c);
+        for (int i = 0; i < NCH; ++i) t[i] = *reinterpret_cast<const bf16x8*>(xr + (lane + 64 * i) * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[i][j] = bf2f(t[j]); sum += v[i][j]; }
-        } else {
+        for (int i = 0; i < NCH; ++i) wq[i] = *reinterpret_cast<const bf16x8*>(w + (lane + 64 * i) * 8);
+        __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks the weight loads below the reductions)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] = bf2f(t[i][j]); sum += v[i][j]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 8;
+            if (c < cols) {
+                const bf16x8 t = *reinterpret_cast<const bf16x8*>(xr + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[i][j] = bf2f(t[j]); sum += v[i][j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+            }
         }
     }
-    const float mu = wave_sum(sum) / (float)cols;
+    const float mu = (FULL ? wave_sum_dpp(sum) : wave_sum(sum)) / (float)cols;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + 64 * i) * 8;
-        if (c < cols) {
+        if (FULL || c < cols) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mu; sq += d * d; }
         }
     }
-    const float rs = 1.0f / sqrtf(wave_sum(sq) / (float)cols + eps);
+    const float rs = 1.0f / sqrtf((FULL ? wave_sum_dpp(sq) : wave_sum(sq)) / (float)cols + eps);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     bf16* yr = y + row * cols;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + 64 * i) * 8;
-        if (c < cols) {
-            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c);
+        if (FULL || c < cols) {
+            const bf16x8 wv = FULL ? wq[i] : *reinterpret_cast<const bf16x8*>(w + c);
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = f2bf((v[i][j] - mu) * rs * bf2f(wv[j]));
@@ -152,7 +170,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
 // summation order follows the grid size.
 // DROP2: also write dropout(dx) (the library's counter-based mask, element (row, col) of `dc`) to dx_drop — the gradient the
 // attention projection of the same block consumes (x1 = x + dropout(y W_proj^T): block.cpp), which used to be a pass of its own.
-template <int NCH, bool HAS_RESID, bool DROP2>
+// FULL: cols == 512 * NCH exactly.  No column tests, the steady-state loop is peeled from the last row so that the prefetch is
+// unconditional (a conditional prefetch makes hipcc join two wait states with vmcnt(0): the "prefetched" row was waited for before
+// the current one was touched, and the kernel ran at one row in flight per wave), and the two reductions go through DPP.
+template <int NCH, bool HAS_RESID, bool DROP2, bool FULL>
 __global__ __launch_bounds__(256) void ln_bwd_pipe_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                            const bf16* __restrict__ w, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const bf16* __restrict__ dresid,
@@ -160,13 +181,13 @@ __global__ __launch_bounds__(256) void ln_bwd_pipe_kernel(const bf16* __restrict
                                                            bf16* __restrict__ dx_drop, DropCfg dc) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = reinterpret_cast<float*>(smem_raw);  // [4][cols]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float wv[NCH][8], dwacc[NCH][8];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + 64 * i) * 8;
         bf16x8 t = {};
-        if (c < cols) t = *reinterpret_cast<const bf16x8*>(w + c);
+        if (FULL || c < cols) t = *reinterpret_cast<const bf16x8*>(w + c);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { wv[i][j] = bf2f(t[j]); dwacc[i][j] = 0.f; }
     }
@@ -181,23 +202,21 @@ __global__ __launch_bounds__(256) void ln_bwd_pipe_kernel(const bf16* __restrict
         for (int i = 0; i < NCH; ++i) {
             const int c = (lane + 64 * i) * 8;
             fx[i] = bf16x8{}; fd[i] = bf16x8{}; fr[i] = bf16x8{};
-            if (c < cols) {
+            if (FULL || c < cols) {
                 if (HAS_RESID) fr[i] = *reinterpret_cast<const bf16x8*>(dresid + r * cols + c);
                 fx[i] = *reinterpret_cast<const bf16x8*>(x + r * cols + c);
                 fd[i] = *reinterpret_cast<const bf16x8*>(dy + r * cols + c);
             }
         }
     };
-    if (row < rows) fetch(row, cx, cd, cr, cmu, crs);
-    for (; row < rows; row += stride) {
-        if (row + stride < rows) fetch(row + stride, nx, nd, nr, nmu, nrs);
+    auto process = [&](int64_t r) {   // row r is in cx / cd / cr / cmu / crs
         const float mu = cmu, rs = crs;
         float xh[NCH][8], g[NCH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = (lane + 64 * i) * 8;
-            if (c < cols) {
+            if (FULL || c < cols) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float d = bf2f(cd[i][j]);
@@ -212,13 +231,13 @@ __global__ __launch_bounds__(256) void ln_bwd_pipe_kernel(const bf16* __restrict
                 for (int j = 0; j < 8; ++j) { xh[i][j] = 0.f; g[i][j] = 0.f; }
             }
         }
-        s1 = wave_sum(s1) * inv_c;
-        s2 = wave_sum(s2) * inv_c;
-        const uint32_t rk = DROP2 ? drop_rowkey((uint64_t)row, dc) : 0u;
+        s1 = (FULL ? wave_sum_dpp(s1) : wave_sum(s1)) * inv_c;
+        s2 = (FULL ? wave_sum_dpp(s2) : wave_sum(s2)) * inv_c;
+        const uint32_t rk = DROP2 ? drop_rowkey((uint64_t)r, dc) : 0u;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = (lane + 64 * i) * 8;
-            if (c < cols) {
+            if (FULL || c < cols) {
                 bf16x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -226,7 +245,7 @@ __global__ __launch_bounds__(256) void ln_bwd_pipe_kernel(const bf16* __restrict
                     if (HAS_RESID) d += bf2f(cr[i][j]);
                     o[j] = f2bf(d);
                 }
-                *reinterpret_cast<bf16x8*>(dx + row * cols + c) = o;
+                *reinterpret_cast<bf16x8*>(dx + r * cols + c) = o;
                 if (DROP2) {
                     bf16x8 od;
 #pragma unroll
@@ -236,18 +255,27 @@ __global__ __launch_bounds__(256) void ln_bwd_pipe_kernel(const bf16* __restrict
                         for (int e = 0; e < 2; ++e)
                             od[2 * jj + e] = drop_keep_bits(bits, (uint32_t)e, dc) ? f2bf(bf2f(o[2 * jj + e]) * dc.scale) : f2bf(0.f);
                     }
-                    *reinterpret_cast<bf16x8*>(dx_drop + row * cols + c) = od;
+                    *reinterpret_cast<bf16x8*>(dx_drop + r * cols + c) = od;
                 }
             }
         }
+    };
+    if (row < rows) {
+        fetch(row, cx, cd, cr, cmu, crs);
+        for (; row + stride < rows; row += stride) {   // steady state: the next row's loads are in flight while this one is reduced and stored
+            fetch(row + stride, nx, nd, nr, nmu, nrs);
+            __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise issues these loads after the row's arithmetic: one row in flight per wave)
+            process(row);
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) { cx[i] = nx[i]; cd[i] = nd[i]; cr[i] = nr[i]; }
-        cmu = nmu; crs = nrs;
+            for (int i = 0; i < NCH; ++i) { cx[i] = nx[i]; cd[i] = nd[i]; cr[i] = nr[i]; }
+            cmu = nmu; crs = nrs;
+        }
+        process(row);
     }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + 64 * i) * 8;
-        if (c < cols) {
+        if (FULL || c < cols) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) red[wave * cols + c + j] = dwacc[i][j];
         }
@@ -308,7 +336,8 @@ extern "C" int obte_layernorm_fwd(const obte_bf16* x, const obte_bf16* w, obte_b
     const dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
     hipStream_t st = (hipStream_t)s;
     const int prof = obte_prof_begin(st, 110, rows, cols, 1);   // HBM-bound: algorithmic bytes = 4 * rows * cols
-#define LN_FWD(N) hipLaunchKernelGGL((ln_fwd_kernel<N>), grid, block, 0, st, (const bf16*)x, (const bf16*)w, (bf16*)y, mean, rstd, rows, cols, eps)
+#define LN_FWD(N) do { if (cols == 512 * N) hipLaunchKernelGGL((ln_fwd_kernel<N, true>), grid, block, 0, st, (const bf16*)x, (const bf16*)w, (bf16*)y, mean, rstd, rows, cols, eps); \
+                       else hipLaunchKernelGGL((ln_fwd_kernel<N, false>), grid, block, 0, st, (const bf16*)x, (const bf16*)w, (bf16*)y, mean, rstd, rows, cols, eps); } while (0)
     switch (nch_for(cols)) {
         case 1: LN_FWD(1); break;
         case 2: LN_FWD(2); break;
@@ -353,14 +382,14 @@ static int ln_bwd_impl(const obte_bf16* dy, const obte_bf16* x, const obte_bf16*
     if (pipe_on < 0) { const char* e = getenv("OBTE_LN_PIPE"); pipe_on = (e && e[0] == '0') ? 0 : 1; }
     const bool drop2 = dx_drop != nullptr && dc.thresh16 != 0;
 #define LN_BWD_GO(K, ...) hipLaunchKernelGGL((K), grid, block, smem, st, (const bf16*)dy, (const bf16*)x, (const bf16*)w, mean, rstd, __VA_ARGS__)
+#define LN_PIPE(N, R, D, F) LN_BWD_GO((ln_bwd_pipe_kernel<N, R, D, F>), (const bf16*)(R ? dresid : nullptr), (bf16*)dx, ws, rows, cols, ws_acc, (bf16*)(D ? dx_drop : nullptr), dc)
+#define LN_PIPE_F(N, R, D) do { if (cols == 512 * N) LN_PIPE(N, R, D, true); else LN_PIPE(N, R, D, false); } while (0)
 #define LN_BWD(N)                                                                                                           \
     do {                                                                                                                    \
         if (drop2) {                                                                                                        \
-            if (dresid) LN_BWD_GO((ln_bwd_pipe_kernel<N, true, true>), (const bf16*)dresid, (bf16*)dx, ws, rows, cols, ws_acc, (bf16*)dx_drop, dc);   \
-            else LN_BWD_GO((ln_bwd_pipe_kernel<N, false, true>), (const bf16*)nullptr, (bf16*)dx, ws, rows, cols, ws_acc, (bf16*)dx_drop, dc);      \
+            if (dresid) LN_PIPE_F(N, true, true); else LN_PIPE_F(N, false, true);                                           \
         } else if (pipe_on) {                                                                                               \
-            if (dresid) LN_BWD_GO((ln_bwd_pipe_kernel<N, true, false>), (const bf16*)dresid, (bf16*)dx, ws, rows, cols, ws_acc, (bf16*)nullptr, dc); \
-            else LN_BWD_GO((ln_bwd_pipe_kernel<N, false, false>), (const bf16*)nullptr, (bf16*)dx, ws, rows, cols, ws_acc, (bf16*)nullptr, dc);    \
+            if (dresid) LN_PIPE_F(N, true, false); else LN_PIPE_F(N, false, false);                                         \
         } else {                                                                                                            \
             if (dresid) LN_BWD_GO((ln_bwd_kernel<N, true>), (const bf16*)dresid, (bf16*)dx, ws, rows, cols, ws_acc);        \
             else LN_BWD_GO((ln_bwd_kernel<N, false>), (const bf16*)nullptr, (bf16*)dx, ws, rows, cols, ws_acc);             \
@@ -374,6 +403,8 @@ static int ln_bwd_impl(const obte_bf16* dy, const obte_bf16* x, const obte_bf16*
         default: LN_BWD(16); break;
     }
 #undef LN_BWD
+#undef LN_PIPE_F
+#undef LN_PIPE
 #undef LN_BWD_GO
     if (!reduce) obte_prof_end(prof, st);
     OBTE_CHECK_LAUNCH("obte_layernorm_bwd");

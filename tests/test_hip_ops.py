@@ -304,6 +304,42 @@ def test_attention_backward_one_kernel_form(T, mode):
     close(one_r, two_r.float().cpu(), atol=4e-3, rtol=2.0 ** -7, what="one-kernel vs kernel pair, inverse RoPE")
 
 
+def test_attention_backward_one_kernel_beside_another_stream():
+    """The one-kernel backward at the benchmark's shape (B = 8, H = 8, T = 1024, multi-document rows) repeated while a second
+    stream keeps the memory system busy with GEMMs: every repeat equals the quiet result bit for bit.  (Round 4: the loop's
+    lse / delta load was an asm load with a register destination that hipcc copied in front of the wait covering it — the
+    previous slice's row constants whenever the load was late, i.e. only beside other work: tools/fused_race.py.)"""
+    B, H, T, hs = 8, 8, 1024, 128
+    g = torch.Generator(device=DEV).manual_seed(0)
+    qkv = torch.randn(B, T, 3 * H * hs, device=DEV, generator=g).to(BF)
+    d_o = torch.randn(B, T, H * hs, device=DEV, generator=g).to(BF)
+    tok = np.random.default_rng(3).integers(20, 100, size=(B, T))
+    for b in range(B):
+        tok[b, np.random.default_rng(10 + b).choice(np.arange(8, T - 8), size=3, replace=False)] = R.EOS_TOKEN
+    _, ranges = _blocks_to_masks(tok, T)
+    o = ops()
+    spec = o.MaskSpec(ranges=ranges.to(DEV))
+    scale = 8.0 / (H * hs)
+    out, lse = o.attn_fwd(qkv, B, T, H, hs, scale, spec)
+    quiet = o.attn_bwd(qkv, out, d_o, lse, B, T, H, hs, scale, spec).clone()
+    pair = o.attn_bwd(qkv, out, d_o, lse, B, T, H, hs, scale, spec, one_kernel=False)
+    close(quiet, pair.float().cpu(), atol=4e-3, rtol=2.0 ** -7, what="one-kernel vs kernel pair")
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    x, w = torch.randn(8192, 1024, device=DEV).to(BF), torch.randn(4096, 1024, device=DEV).to(BF)
+    differ = 0
+    for r in range(24):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                o.linear_fwd(x, w)
+                if r % 2:
+                    o.attn_fwd(qkv, B, T, H, hs, scale, spec)
+        got = o.attn_bwd(qkv, out, d_o, lse, B, T, H, hs, scale, spec)
+        torch.cuda.synchronize()
+        differ += int(not torch.equal(got, quiet))
+    assert differ == 0, f"{differ}/24 repeats beside another stream differ from the quiet result"
+
+
 @pytest.mark.parametrize("hs", [64, 128])
 def test_attention_dense_mask_bounds_edge_cases(hs):
     """Dense additive masks reach the kernels with conservative loop bounds (obte_mask_bounds).  The cases the bounds
