@@ -329,6 +329,111 @@ __global__ __launch_bounds__(256, 2) void masked_ce_regs_kernel(const bf16* __re
     }
 }
 
+// The same arithmetic again for vocab == 256 x NCH x 8 exactly (65 536 at NCH = 32), as a PERSISTENT kernel: one workgroup per CU,
+// rows blockIdx.x, + gridDim.x, ...  The workgroup's NEXT row travels global -> LDS by LDS-DMA (no registers: 128 KiB of the CU's
+// 160) while the current row is reduced, exponentiated and stored from registers, so its HBM reads run beside the current row's
+// writes instead of after them, and the 1 229-row launch is 4.8 rows per workgroup (96 % balanced) instead of 2.4 rounds of 512
+// resident workgroups (the third round 40 % full).  Each wave reads back exactly the bytes its own lanes requested, so the only
+// synchronisation of the staging is the wave's own counted vmcnt; every scalar of the row (list entry, target, weights, the target's
+// logit) comes through the scalar cache or LDS, so that NO compiler-issued vector load sits among the hand-counted ones.
+template <int NCH, bool NT>
+__global__ __launch_bounds__(256, 1) void masked_ce_pipe_kernel(const bf16* __restrict__ logits, const int64_t* __restrict__ target,
+                                                                 const float* __restrict__ grad_scale, float row_scale,
+                                                                 float* __restrict__ row_loss, bf16* __restrict__ dlogits, int64_t n_rows,
+                                                                 const int64_t* __restrict__ row_index, const float* __restrict__ row_scale_vec) {
+    constexpr int64_t vocab = (int64_t)256 * NCH * 8;
+    extern __shared__ __attribute__((aligned(16))) char ce_smem[];   // [vocab] bf16 staging + the reduction scratch behind it
+    float* red = reinterpret_cast<float*>(ce_smem + vocab * 2);     // [2][8]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t stride = gridDim.x;
+    const uint32_t a_wave = lds_addr_of(ce_smem) + wave * 1024;     // chunk i of this wave: + 4096 i (the row's own byte order)
+    const int voff = (int)threadIdx.x * 16;
+    auto request = [&](int64_t r) {   // 32 LDS-DMA loads of 16 B per lane
+        const int64_t src = row_index ? row_index[r] : r;
+        const i32x4_t rs = make_rsrc_words(logits + src * vocab, vocab * 2);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)   // chunk i: + 4096 i bytes on both sides, through M0 and the scalar offset (no per-chunk VGPR)
+            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(a_wave + i * 4096), "v"(voff), "s"(rs), "s"(i * 4096) : "memory");
+    };
+    int64_t r = blockIdx.x;
+    if (r >= n_rows) return;
+    request(r);
+    bool first = true;
+    int par = 0;
+    for (; r < n_rows; r += stride, par ^= 1) {
+        const int64_t src = row_index ? row_index[r] : r;
+        int64_t tgt = target[src];
+        tgt = tgt < 0 ? 0 : (tgt >= vocab ? vocab - 1 : tgt);
+        const float rsc = row_scale_vec ? row_scale * row_scale_vec[r] : row_scale;
+        const float gs = grad_scale ? rsc * grad_scale[0] : rsc;
+        // this row has landed (older than the 32 stores of the previous row, which may still be in flight)
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        first = false;
+        bf16x8 v[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) v[i] = *reinterpret_cast<const bf16x8*>(ce_smem + wave * 1024 + lane * 16 + i * 4096);
+        // (the target's logit is read by the thread whose own LDS-DMA fetched it: no barrier needed for the staging)
+        const int tgt32 = (int)tgt;
+        const bool owns_target = ((tgt32 >> 3) & 255) == (int)threadIdx.x;
+        float xt = 0.f;
+        if (owns_target) xt = bf2f(reinterpret_cast<const bf16*>(ce_smem)[tgt32]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row is in registers: its staging may be overwritten
+        if (r + stride < n_rows) request(r + stride);
+        // ONE exponential per element: e = exp(x - running max of the thread at that chunk) is kept (fp32, 8 NCH registers: this
+        // kernel has the whole register file of its SIMD) together with the chunk's maximum; the gradient pass multiplies it by
+        // exp(chunk max - lse) * scale, one exponential per CHUNK.  (The one-row-per-workgroup kernels evaluate exp(x - lse) per
+        // element a second time: 2 x 256 quarter-rate instructions per thread and row, which is what bounded them — 10 us of vector
+        // ALU per row against 11 us of memory time at 6 TB/s.)  Equal to those kernels to fp32 rounding, not bitwise.
+        float e[NCH][8], mc[NCH];
+        float m = -INFINITY, l = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = bf2f(v[i][j]);
+            float mx = x[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, x[j]);
+            const float mn = fmaxf(m, mx);
+            float add = 0.f;
+            const float mnl = -mn * 1.4426950408889634f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { e[i][j] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[j], 1.4426950408889634f, mnl)); add += e[i][j]; }   // exp(x - mn): one FMA, one v_exp
+            l = l * __expf(m - mn) + add;
+            m = mn;
+            mc[i] = mn;
+            __builtin_amdgcn_sched_barrier(0);   // (chunk by chunk: left to itself hipcc converts the whole row first and spills; a spill reload is a vector load among the counted ones)
+        }
+        const float wm = wave_max(m);
+        l = wave_sum(m == -INFINITY ? 0.f : l * __expf(m - wm));
+        float* rd = red + par * 12;
+        if (owns_target) rd[8] = xt;   // the target's logit, published with the wave partials (one barrier per row; scratch by row parity)
+        if (lane == 0) { rd[wave] = wm; rd[4 + wave] = l; }
+        __syncthreads();
+        const float bm = fmaxf(fmaxf(rd[0], rd[1]), fmaxf(rd[2], rd[3]));
+        const float bl = rd[4] * __expf(rd[0] - bm) + rd[5] * __expf(rd[1] - bm) + rd[6] * __expf(rd[2] - bm) + rd[7] * __expf(rd[3] - bm);
+        const float lse = bm + __logf(bl);
+        if (threadIdx.x == 0 && row_loss) row_loss[r] = (lse - rd[8]) * rsc;
+        bf16* drow = dlogits + r * vocab + (int64_t)threadIdx.x * 8;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const float f = __expf(mc[i] - lse) * gs;
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(e[i][j] * f);
+            // (asm: exactly one store instruction per chunk, whatever hipcc would have made of it — the wait above counts 32; the s_nop
+            //  is the wait state an asm store of more than 8 bytes needs before its data registers are written again: hipcc pads only
+            //  its own stores, and without it the next chunk's first conversion landed in this chunk's first dword)
+            if (NT) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(drow + (int64_t)i * 256 * 8), "v"(o) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(drow + (int64_t)i * 256 * 8), "v"(o) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // (p - 1) * scale at the target: ONE element, rewritten by the thread whose chunk store just covered it (same wave, same
+        // address: the two stores stay in order; for that wave the next row's wait counts one store too many, i.e. waits longer)
+        if (owns_target) dlogits[r * vocab + tgt32] = f2bf((__expf(xt - lse) - 1.0f) * gs);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // AdamW in the reference's pure-bf16 regime (train_encoder.py:170,199): p, g, m, v all bf16; the update is
 // evaluated in fp32 per element and each state is rounded once.
@@ -648,7 +753,26 @@ extern "C" int obte_masked_ce_rows(const obte_bf16* logits, const int64_t* targe
     const int prof = obte_prof_begin((hipStream_t)s, 112, n_rows, vocab, 1);   // algorithmic bytes = 4 * n_rows * vocab (read + write)
     static int regs_on = -1;   // OBTE_CE_REGS=0: the two-pass kernel (A/B timing; bitwise the same results)
     if (regs_on < 0) { const char* e = getenv("OBTE_CE_REGS"); regs_on = (e && e[0] == '0') ? 0 : 1; }
-    if (regs_on && vocab <= 256 * 8 * 8)
+    static int pipe_on = -1, nt_on = -1, pipe_grid = 0;   // OBTE_CE_PIPE=0: one workgroup per row (A/B timing; bitwise the same results)
+    if (pipe_on < 0) {
+        const char* e = getenv("OBTE_CE_PIPE"); pipe_on = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("OBTE_CE_NT"); nt_on = (e && e[0] == '1') ? 1 : 0;
+        e = getenv("OBTE_CE_GRID"); pipe_grid = e ? atoi(e) : 256;
+        if (pipe_grid < 1 || pipe_grid > 4096) pipe_grid = 256;
+    }
+    if (regs_on && pipe_on && vocab == 256 * 32 * 8 && n_rows > pipe_grid) {
+        const dim3 grid((unsigned)pipe_grid);
+        const int smem = (int)(vocab * 2 + 128);
+        if (nt_on) {
+            (void)hipFuncSetAttribute((const void*)masked_ce_pipe_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            hipLaunchKernelGGL((masked_ce_pipe_kernel<32, true>), grid, dim3(256), smem, (hipStream_t)s, (const bf16*)logits, target, grad_scale, row_scale,
+                               row_loss, (bf16*)dlogits_rows, n_rows, row_index, row_scale_vec);
+        } else {
+            (void)hipFuncSetAttribute((const void*)masked_ce_pipe_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            hipLaunchKernelGGL((masked_ce_pipe_kernel<32, false>), grid, dim3(256), smem, (hipStream_t)s, (const bf16*)logits, target, grad_scale, row_scale,
+                               row_loss, (bf16*)dlogits_rows, n_rows, row_index, row_scale_vec);
+        }
+    } else if (regs_on && vocab <= 256 * 8 * 8)
         hipLaunchKernelGGL((masked_ce_regs_kernel<8>), dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)s, (const bf16*)logits, target,
                            grad_scale, row_scale, row_loss, (bf16*)dlogits_rows, vocab, row_index, row_scale_vec);
     else if (regs_on && vocab <= 256 * 32 * 8)

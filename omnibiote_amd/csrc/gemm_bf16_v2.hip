@@ -252,7 +252,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
                     }
                 }
             }
-            if (p.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p.d + o), "v"(v) : "memory");
+            if (p.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p.d + o), "v"(v) : "memory");   // (s_nop: an asm store of more than 8 bytes must not be followed at once by a write of its data registers; hipcc pads only its own stores)
             else *reinterpret_cast<bf16x8*>(p.d + o) = v;
         }
         return;
@@ -325,7 +325,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
             // an output larger than the Infinity Cache (the 1-GiB logits) is stored non-temporally: it cannot stay on
             // die for its consumer anyway, and this way it does not evict the operand panels the XCD's other
             // workgroups are still streaming from L2 (+7 % on the readout forward; smaller outputs measured slower)
-            if (p.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p.d + o), "v"(v) : "memory");   // (the builtin form is folded into the plain store below)
+            if (p.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p.d + o), "v"(v) : "memory");   // (s_nop: an asm store of more than 8 bytes must not be followed at once by a write of its data registers; hipcc pads only its own stores)   // (the builtin form is folded into the plain store below)
             else *reinterpret_cast<bf16x8*>(p.d + o) = v;
         }
     }
