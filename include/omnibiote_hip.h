@@ -333,6 +333,12 @@ typedef struct {
      * half's backward runs as usual.  With dropout, site 3 (the MLP projection) masks element (i, c) of the [n_out_rows, C]
      * output, forward and backward alike; sites 1 and 2 are unchanged.  NULL / 0: the whole block on every position. */
     const int64_t* out_rows; int64_t n_out_rows;
+    /* backward only, optional, dropout only (p > 0): the hand-off of the masked gradient between consecutive blocks.  Block i's
+     * MLP projection needs dy under ITS (seed, site 3) mask, and dy is the dx of block i + 1 — so block i + 1's last LayerNorm
+     * backward can write that masked copy beside dx instead of block i spending a pass on it.
+     *   dy_masked      in : dropout(dy) under this block's (dropout_seed, site 3) mask, same shape as dy (NULL: computed here);
+     *   dx_masked      out: dropout(dx) under (dx_mask_seed, site 3) — the seed of the block BELOW — [B*T, C] (NULL: not written). */
+    const obte_bf16* dy_masked; obte_bf16* dx_masked; uint64_t dx_mask_seed;
 } obte_block_desc;
 int64_t obte_block_act_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head);
 int64_t obte_block_bwd_ws_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head);

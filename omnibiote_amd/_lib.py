@@ -52,7 +52,8 @@ class BlockDesc(C.Structure):
                 ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
                 ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("query_bounds", C.c_void_p),
                 ("ln1_partials", C.c_void_p), ("ln2_partials", C.c_void_p), ("ln_partial_mode", C.c_int32),
-                ("ranges_exact", C.c_void_p), ("out_rows", C.c_void_p), ("n_out_rows", C.c_int64)]
+                ("ranges_exact", C.c_void_p), ("out_rows", C.c_void_p), ("n_out_rows", C.c_int64),
+                ("dy_masked", C.c_void_p), ("dx_masked", C.c_void_p), ("dx_mask_seed", C.c_uint64)]
 
 
 LN_PARTIAL_FIRST, LN_PARTIAL_MORE, LN_PARTIAL_LAST = 1, 2, 3

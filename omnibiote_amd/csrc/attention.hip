@@ -605,10 +605,29 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
         {
             // 32 queries that every key of the wave is seen by (the inside of a document): no per-element range test
             auto p_ds_rows = [&](auto checked) {
+                // Dropout: the 32 bits that decide (query, key pair) are shared by the two lanes that hold the pair's keys, and here
+                // every lane is ONE key against 16 queries — so the even lane of a pair hashes the queries of register groups
+                // i = 0, 1, the odd lane those of i = 2, 3, and each takes the other half over by a quad permute: 8 hashes per lane
+                // and slice instead of 16 (this kernel paid twice what the query-major kernels pay per element).
+                uint32_t pairw[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+                const uint32_t pair_g = (uint32_t)key_c >> 1;
+                const int odd_lane = lane & 1;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const f32x4 l4 = *reinterpret_cast<const f32x4*>(stats + 8 * i + 4 * h);
                     const f32x4 d4 = *reinterpret_cast<const f32x4*>(stats + 32 + 8 * i + 4 * h);
+                    uint32_t w4[4] = {0u, 0u, 0u, 0u};
+                    if (DROP) {
+                        if (i < 2) {   // this lane's share: group i (even lane) or i + 2 (odd lane)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                pairw[i][j] = drop_pair_bits(__float_as_uint(stats[64 + 8 * (i + 2 * odd_lane) + 4 * h + j]), pair_g);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)   // quad_perm [0,0,2,2]: from the even lane; [1,1,3,3]: from the odd one
+                            w4[j] = i < 2 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pairw[i][j], 0xA0, 0xf, 0xf, false)
+                                          : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pairw[i - 2][j], 0xF5, 0xf, 0xf, false);
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int r = 4 * i + j;
@@ -618,8 +637,8 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
                         float pv = fast_exp2(x);
                         if (decltype(checked)::value && (q < qs || q >= qe)) pv = 0.f;
                         float pd = pv, dpd = dp[r];
-                        if (DROP) {   // row key of query q from the stage's table, this lane's key as the column
-                            const bool kp = drop_keep(__float_as_uint(stats[64 + 8 * i + 4 * h + j]), (uint32_t)key_c, p.drop);
+                        if (DROP) {   // (row key of query q from the stage's table, this lane's key as the column)
+                            const bool kp = drop_keep_bits(w4[j], (uint32_t)key_c, p.drop);
                             pd = kp ? pv * p.drop.scale : 0.f;
                             dpd = kp ? dpd * p.drop.scale : 0.f;
                         }

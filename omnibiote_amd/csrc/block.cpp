@@ -212,7 +212,9 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     const bool grouped_mlp = grouped && !rows_form;
     // MLP: out = x1 + dropout(hact W_mlp^T): the projection sees dy masked by the same (seed, site 3) mask
     const obte_bf16* dy_mlp = dy;
-    if (drop) {   // (rows form: dy and the mask of site 3 are [Mm, C] — element (i, c) of the compact output, as in the forward)
+    if (drop && d->dy_masked) {   // handed over by the block above: its last LayerNorm backward wrote dropout(dx) under this block's mask
+        dy_mlp = d->dy_masked;
+    } else if (drop) {   // (rows form: dy and the mask of site 3 are [Mm, C] — element (i, c) of the compact output, as in the forward)
         TRY(obte_dropout_bf16(dy, dym, Mm * C, C, d->dropout_p, d->dropout_seed, SITE_MLP, s));
         dy_mlp = dym;
     }
@@ -298,7 +300,11 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
         }
         TRY(obte_gemm_grouped_bf16(gs, np, s));
     }
-    if (lnp) TRY(obte_layernorm_bwd_partial(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, d->ln1_partials, M, C, lnp, s));
-    else TRY(obte_layernorm_bwd_acc(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, lnws, M, C, acc_ln, s));                      // dx = dx1 + LN1'(dh1)
+    // dx = dx1 + LN1'(dh1); with dropout and a block below, also dropout(dx) under that block's (seed, site 3) mask
+    if (drop && d->dx_masked)
+        TRY(obte_layernorm_bwd_dropout(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, d->dx_masked, dln1_w, lnp ? d->ln1_partials : lnws, M, C, lnp, acc_ln,
+                                       d->dropout_p, d->dx_mask_seed, SITE_MLP, s));
+    else if (lnp) TRY(obte_layernorm_bwd_partial(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, d->ln1_partials, M, C, lnp, s));
+    else TRY(obte_layernorm_bwd_acc(dh, x, d->ln1_w, mean1, rstd1, dx1, dx, dln1_w, lnws, M, C, acc_ln, s));
     return OBTE_OK;
 }

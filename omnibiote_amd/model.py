@@ -373,12 +373,39 @@ class _EmbeddingFn(torch.autograd.Function):
         return None, dw, None, None, None
 
 
+# The hand-off of the dropout-masked gradient between consecutive blocks' backward passes (ops.block_bwd, dy_masked): the dx a
+# block just produced -> dropout(dx) under the mask of the block below, keyed by dx's storage.  The taker checks that the gradient
+# it received IS that tensor (same storage and shape) and that probability and seed are its own; anything else is ignored and the
+# block masks dy itself (the same values either way).  Entries are consumed by the very next block of the same backward; the
+# table is capped so that an interrupted backward cannot leave tensors behind for long.
+_masked_grad = {}
+
+
+def _masked_grad_put(dx, dx_masked, p, seed):
+    if dx_masked is None:
+        return
+    while len(_masked_grad) >= 8:
+        _masked_grad.pop(next(iter(_masked_grad)), None)
+    _masked_grad[dx.data_ptr()] = (dx_masked, tuple(dx.shape), float(p), int(seed))
+
+
+def _masked_grad_take(dy, drop):
+    if os.environ.get("OBTE_DROPOUT_HANDOFF") == "0":   # A/B and tests: every block masks its own dy
+        return None
+    ent = _masked_grad.pop(dy.data_ptr(), None)
+    if ent is None or ent[1] != tuple(dy.shape) or ent[2] != float(drop[0]) or ent[3] != int(drop[1]):
+        return None
+    return ent[0]
+
+
 class _BlockFn(torch.autograd.Function):
     """One pre-LN transformer block (model.py:170-181): a single C call per pass."""
 
     @staticmethod
-    def forward(ctx, x, ln1, attn_w, proj_w, ln2, fc_w, mlp_w, rope_cos, rope_sin, n_head, mask, dropout_p, dropout_seed, out_rows=None):
+    def forward(ctx, x, ln1, attn_w, proj_w, ln2, fc_w, mlp_w, rope_cos, rope_sin, n_head, mask, dropout_p, dropout_seed, out_rows=None,
+                below_seed=None):
         x = x.contiguous()
+        ctx.below_seed = below_seed if dropout_p > 0 else None   # the dropout seed of the block below (None: no block there)
         params = (ln1, attn_w, proj_w, ln2, fc_w, mlp_w)
         y, act = ops.block_fwd(x, params, (rope_cos, rope_sin), n_head, mask, dropout_p, dropout_seed, out_rows=out_rows)
         ctx.save_for_backward(x, act, rope_cos, rope_sin, *params)
@@ -396,11 +423,17 @@ class _BlockFn(torch.autograd.Function):
         _ord_wait(pol, id(ctx.w_params[0]))   # one group per block: its six weights are updated by this one call
         slots = [_grad_slot(w, pol) for w in ctx.w_params]
         lnp = (_ln_partials(ctx.w_params[0], pol), _ln_partials(ctx.w_params[3], pol)) if pol.ln_mode else None
-        dx, grads = ops.block_bwd(x, dy.contiguous(), act, tuple(params), (rope_cos, rope_sin), ctx.n_head, ctx.mask,
-                                  accumulate_into=slots, dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1], ln_partials=lnp,
-                                  ln_partial_mode=pol.ln_mode, out_rows=ctx.out_rows)
+        dy = dy.contiguous()
+        # dropout: the block above may have left dropout(dy) under this block's MLP-projection mask (one pass less per block)
+        dy_masked = _masked_grad_take(dy, ctx.drop) if ctx.drop[0] > 0 else None
+        res = ops.block_bwd(x, dy, act, tuple(params), (rope_cos, rope_sin), ctx.n_head, ctx.mask,
+                            accumulate_into=slots, dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1], ln_partials=lnp,
+                            ln_partial_mode=pol.ln_mode, out_rows=ctx.out_rows, dy_masked=dy_masked, dx_mask_seed=ctx.below_seed)
+        dx, grads = res[0], res[1]
+        if ctx.below_seed is not None:
+            _masked_grad_put(dx, res[2], ctx.drop[0], ctx.below_seed)
         _ord_done(pol, id(ctx.w_params[0]))
-        return (dx, *grads, None, None, None, None, None, None, None)
+        return (dx, *grads, None, None, None, None, None, None, None, None)
 
 
 class _AttnCoreFn(torch.autograd.Function):
@@ -546,8 +579,10 @@ class Block(nn.Module):
         if config.bias:
             raise NotImplementedError("bias=True is not used by the reference (model.py:191) and not implemented")
 
-    def forward(self, x, attn_mask=None, out_rows=None):
-        """out_rows (optional, int64 (n,), ascending distinct rows of the flattened (b*t, n_embd) activation): the caller
+    def forward(self, x, attn_mask=None, out_rows=None, below_seed=None):
+        """below_seed (internal, OmniBioTA.forward): the dropout seed the block BELOW drew in this forward — this block's
+        backward then also writes its dx under that block's MLP-projection mask (ops.block_bwd).
+        out_rows (optional, int64 (n,), ascending distinct rows of the flattened (b*t, n_embd) activation): the caller
         wants the block's output at those positions alone and gets it as (n, n_embd) — the attention half runs on every
         position, the MLP half on the listed ones (per-position arithmetic: the same values there; in training mode the
         dropout mask of the MLP projection is drawn for the (n, n_embd) output)."""
@@ -563,8 +598,10 @@ class Block(nn.Module):
         # one dropout probability per block, as in the reference (config.dropout feeds all three nn.Dropout modules)
         p = _active_p(self, self.attn.dropout)
         seed = _new_seed() if p > 0 else 0
+        self._last_seed = seed if p > 0 else None
         return _BlockFn.apply(x, self.ln_1.weight, self.attn.c_attn.weight, self.attn.c_proj.weight, self.ln_2.weight,
-                              self.mlp.c_fc.weight, self.mlp.c_proj.weight, cos, sin, self.attn.n_head, mask, p, seed, out_rows)
+                              self.mlp.c_fc.weight, self.mlp.c_proj.weight, cos, sin, self.attn.n_head, mask, p, seed, out_rows,
+                              below_seed if p > 0 else None)
 
 
 def _check_rows(rows, total: int, n_blocks: int) -> None:
@@ -660,12 +697,15 @@ class OmniBioTA(nn.Module):
         n_blocks = len(self.transformer.h)
         if rows is not None:
             _check_rows(rows, b * t, n_blocks)
+        below = None   # dropout: the seed of the block just run, handed to the next one (its backward masks dx for the block below)
         for i, block in enumerate(self.transformer.h):
             last_rows = rows if (rows is not None and i == n_blocks - 1) else None
             if self.config.checkpoint_freq > 0 and i % self.config.checkpoint_freq == 0:
                 x = checkpoint(block, x, mask, last_rows, use_reentrant=False)
+                below = None   # (a recomputed block redraws nothing, but keep the hand-off out of checkpointed segments)
             else:
-                x = block(x, attn_mask=mask, out_rows=last_rows)
+                x = block(x, attn_mask=mask, out_rows=last_rows, below_seed=below)
+                below = getattr(block, "_last_seed", None)
         emb = self.transformer.ln_f(x)
         if return_embeddings:
             return emb

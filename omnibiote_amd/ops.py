@@ -440,7 +440,8 @@ def sumsq_(g, out):
 
 
 # -------------------------------------------------------------------------------------------------------- block
-def _block_desc(B, T, Cc, H, params, rope, mask: MaskSpec, dropout_p=0.0, dropout_seed=0, ln_partials=None, ln_partial_mode=0, out_rows=None):
+def _block_desc(B, T, Cc, H, params, rope, mask: MaskSpec, dropout_p=0.0, dropout_seed=0, ln_partials=None, ln_partial_mode=0, out_rows=None,
+                dy_masked=None, dx_masked=None, dx_mask_seed=0):
     ln1, attn_w, proj_w, ln2, fc_w, mlp_w = params
     p1, p2 = ln_partials if ln_partials is not None else (None, None)
     if out_rows is not None:
@@ -449,7 +450,7 @@ def _block_desc(B, T, Cc, H, params, rope, mask: MaskSpec, dropout_p=0.0, dropou
     return L.BlockDesc(B, T, Cc, H, _ptr(ln1), _ptr(attn_w), _ptr(proj_w), _ptr(ln2), _ptr(fc_w), _ptr(mlp_w),
                        _ptr(rope[0]), _ptr(rope[1]), _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq,
                        float(dropout_p), int(dropout_seed), _ptr(mask.qbounds), _ptr(p1), _ptr(p2), int(ln_partial_mode), _ptr(mask.exact),
-                       _ptr(out_rows), 0 if out_rows is None else out_rows.numel())
+                       _ptr(out_rows), 0 if out_rows is None else out_rows.numel(), _ptr(dy_masked), _ptr(dx_masked), int(dx_mask_seed))
 
 
 def block_fwd(x, params, rope, H, mask: MaskSpec, dropout_p=0.0, dropout_seed=0, out_rows=None):
@@ -471,12 +472,15 @@ def block_fwd(x, params, rope, H, mask: MaskSpec, dropout_p=0.0, dropout_seed=0,
 
 
 def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec, accumulate_into=None, dropout_p=0.0, dropout_seed=0, ln_partials=None,
-              ln_partial_mode=0, out_rows=None):
+              ln_partial_mode=0, out_rows=None, dy_masked=None, dx_mask_seed=None):
     """accumulate_into: optional list of 6 tensors-or-None (same order as params).  When the four matrix entries are all
     given, their gradients are added into those tensors in place and the corresponding returned grads are None; the
     same, independently, for the two LayerNorm weights (entries 0 and 3).
     ln_partials=(buf1, buf2) + ln_partial_mode (L.LN_PARTIAL_*): the two LayerNorm weight gradients are accumulated over
-    calls in those fp32 buffers instead (see layernorm_bwd); their returned grads are None except with LN_PARTIAL_LAST."""
+    calls in those fp32 buffers instead (see layernorm_bwd); their returned grads are None except with LN_PARTIAL_LAST.
+    Dropout hand-off between blocks (include/omnibiote_hip.h, obte_block_desc::dy_masked): dy_masked = dropout(dy) under THIS
+    block's (seed, site 3) mask if the block above already wrote it; dx_mask_seed = the seed of the block BELOW: then
+    dropout(dx) under that block's mask is written too and returned as a third value (else None)."""
     _need(x, "x"); _need(dy, "dy")
     B, T, Cc = x.shape
     assert dy.numel() == (B * T if out_rows is None else out_rows.numel()) * Cc, "dy: one row per (wanted) position"
@@ -496,9 +500,15 @@ def block_bwd(x, dy, act, params, rope, H, mask: MaskSpec, accumulate_into=None,
             grads.append(g)
         else:
             grads.append(torch.empty_like(w))
-    d = _block_desc(B, T, Cc, H, params, rope, mask, dropout_p, dropout_seed, ln_partials, ln_partial_mode, out_rows=out_rows)
+    dx_masked = torch.empty_like(x) if (dx_mask_seed is not None and dropout_p > 0.0) else None
+    if dy_masked is not None:
+        _need(dy_masked, "dy_masked"); assert dy_masked.numel() == dy.numel() and dropout_p > 0.0
+    d = _block_desc(B, T, Cc, H, params, rope, mask, dropout_p, dropout_seed, ln_partials, ln_partial_mode, out_rows=out_rows,
+                    dy_masked=dy_masked, dx_masked=dx_masked, dx_mask_seed=dx_mask_seed or 0)
     L.check(L.lib().obte_block_bwd_acc(C.byref(d), _ptr(x), _ptr(dy), _ptr(act), _ptr(ws), _ptr(dx), *[_ptr(g) for g in grads],
                                         int(acc) + 2 * int(acc_ln), _stream()), "obte_block_bwd")
     ln_none = ln_partial_mode in (L.LN_PARTIAL_FIRST, L.LN_PARTIAL_MORE)
     grads = [None if ((acc and i in (1, 2, 4, 5)) or ((acc_ln or ln_none) and i in (0, 3))) else g for i, g in enumerate(grads)]
+    if dx_mask_seed is not None:
+        return dx, grads, dx_masked
     return dx, grads

@@ -768,6 +768,41 @@ def test_pipelined_step_with_dropout_is_bitwise_the_single_stream_step():
         assert torch.equal(out[1][1][k], out[2][1][k]), "weight " + k
 
 
+def test_dropout_masked_gradient_handoff_between_blocks(monkeypatch):
+    """With dropout on, a block's backward also writes its dx under the MLP-projection mask of the block below (one stand-alone
+    mask pass less per block).  The hand-off must be taken (3 of 4 blocks here: the top block has nobody above it) and change
+    nothing: losses and every gradient equal, bit for bit, the step in which each block masks its own incoming gradient."""
+    from omnibiote_amd import train_encoder as TE
+    from omnibiote_amd import model as M
+    C, H, Lyr, V, T, rows, mini = 256, 2, 4, 1024, 128, 8, 4
+    w = R.hash_weights(R.RefConfig(block_size=T, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C))
+    ids = torch.from_numpy(TE.synthetic_rows(rows, T, V, np.random.default_rng(0), single_document=False)).to(DEV)
+    out, taken = {}, {}
+    real_take = M._masked_grad_take
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OBTE_DROPOUT_HANDOFF", mode)
+        count = [0]
+
+        def counting_take(dy, drop, _c=count):
+            r = real_take(dy, drop)
+            _c[0] += int(r is not None)
+            return r
+        monkeypatch.setattr(M, "_masked_grad_take", counting_take)
+        m = _tiny_model(w, C, H, Lyr, V, T)
+        TE.set_dropout(m, 0.1)
+        step = TE.TrainStep(m, torch.optim.SGD(m.parameters(), lr=0.0), None, mini_batch_size=mini, n_head=H, max_grad_norm=1e9)
+        torch.manual_seed(7)
+        np.random.seed(3)
+        loss = step(ids)["loss"].item()
+        torch.cuda.synchronize()
+        out[mode] = (loss, {k: p.grad.clone() for k, p in m.named_parameters()})
+        taken[mode] = count[0]
+    assert taken["1"] == (Lyr - 1) * (rows // mini) and taken["0"] == 0, taken
+    assert out["1"][0] == out["0"][0]
+    for k in out["1"][1]:
+        assert torch.equal(out["1"][1][k], out["0"][1][k]), k
+
+
 def test_two_train_steps_on_two_models_in_two_threads_share_no_state():
     """The backward switches (in-place accumulation, fp32 LayerNorm partials, the embedding sort order) belong to the
     TrainStep that built the graph: each autograd node captures them at forward time (model.GradPolicy on ctx), the fp32

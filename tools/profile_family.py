@@ -5,7 +5,9 @@ import csv
 import sys
 
 FAMILIES = [("gemm", ("gemm_v2_kernel", "gemm_v3_", "gemm_v4_kernel", "gemm_bf16_kernel")), ("splitk_reduce", ("splitk_reduce",)),
-            ("attn_fwd", ("attn_fwd_kernel",)), ("attn_bwd", ("attn_bwd_", "attn_delta", "attn_dq_reduce"))  # (attn_bwd_prep_kernel, attn_bwd_fused_kernel, the dQ / dK/dV pair), ("layernorm", ("ln_",)),
+            ("attn_fwd", ("attn_fwd_kernel",)),
+            ("attn_bwd", ("attn_bwd_", "attn_delta", "attn_dq_reduce")),   # (attn_bwd_prep_kernel, attn_bwd_fused_kernel, the dQ / dK/dV pair)
+            ("layernorm", ("ln_",)),
             ("masked_ce", ("masked_ce",)), ("adamw/sumsq", ("adamw", "sumsq")), ("embedding", ("embed",))]
 
 
