@@ -84,9 +84,10 @@ def parse():
     p.add_argument("--backward_order", default="layer", choices=["layer", "pass"],
                    help="two streams: order the backward passes per parameter group (the next backward follows one layer behind) or per pass; "
                         "bitwise the same results")
-    p.add_argument("--micro_batches_per_pass", type=int, default=1,
-                   help="k > 1: k micro-batches per forward/backward pass (k * mini_batch_size rows per launch), the loss keeping the "
-                        "per-micro-batch normalisation; an execution option, 1 in the headline")
+    p.add_argument("--micro_batches_per_pass", type=int, default=0,
+                   help="k micro-batches per forward/backward pass (k * mini_batch_size rows per launch; masks and the loss normalisation stay "
+                        "per micro-batch, so --mini_batch_size keeps the reference's meaning and loss / gradients are those of separate passes). "
+                        "An execution option like the GEMM plans.  0 (default): k in {1, 2, 4} timed at start-up over two steps each, the fastest kept")
     p.add_argument("--plan_cache", default="", help="JSON file of tuned GEMM plans: loaded if present (no tuning launches), else tuned and written")
     p.add_argument("--shapes_out", default="", help="write the per-shape launch table (from the profiler step) to this file")
     return p.parse_args()
@@ -446,15 +447,13 @@ def main():
     else:
         # every rank times the candidates on its own GPU (in parallel), then all adopt rank 0's table, so that the N
         # replicas run the same kernels (same arithmetic, same speed)
-        tune.tune_model_shapes(a.micro_batches_per_pass * a.mini_batch_size * cfg["ctx_len"], cfg["n_embd"], 2 ** 16, device=dev,
+        tune.tune_model_shapes(max(1, a.micro_batches_per_pass) * a.mini_batch_size * cfg["ctx_len"], cfg["n_embd"], 2 ** 16, device=dev,
                                verbose=(rank == 0 and bool(a.shapes_out)))
         if world > 1:
             box = [tune.export_plans() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             if rank != 0:
                 tune.import_plans(box[0])
-        if a.plan_cache and rank == 0:
-            tune.save_plans(a.plan_cache)
     force_ddp = os.environ.get("OBTE_FORCE_DDP") == "1"   # rehearse the N>1 code path on one GPU
     if force_ddp and world == 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
@@ -463,7 +462,7 @@ def main():
     total_iters = 1000
     opt, sched = TE.build_optimizer(m, h, total_iters)
     step = TE.TrainStep(model, opt, sched, mini_batch_size=a.mini_batch_size, n_head=cfg["n_head"],
-                        lm_head_impl=a.readout, pipeline_streams=a.pipeline_streams, micro_batches_per_pass=a.micro_batches_per_pass, backward_order=a.backward_order, rows_forward=not a.full_last_block,
+                        lm_head_impl=a.readout, pipeline_streams=a.pipeline_streams, micro_batches_per_pass=max(1, a.micro_batches_per_pass), backward_order=a.backward_order, rows_forward=not a.full_last_block,
                         mask_impl="dense" if a.dense_mask else "ranges")
     rng = np.random.default_rng(1234 + rank)
     T = cfg["ctx_len"]
@@ -482,6 +481,50 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- micro-batches per pass: an execution option chosen by measurement, like the GEMM plans ---------------------------------
+    # k micro-batches of mini_batch_size rows go through the model in ONE pass of k * mini_batch_size rows (TrainStep: the mask
+    # builder's per-micro-batch behaviour and the reference's per-micro-batch loss normalisation are kept, so loss and gradients are
+    # those of k separate passes — tests/test_hip_headline.py, test_hip_model.py); every kernel sees k times the rows per launch.
+    # Which k is fastest depends on the shapes (more tile rounds per launch against fewer passes to pipeline): each candidate is
+    # timed over two steps after one warm-up, before the warm-up steps of the contract; all ranks adopt rank 0's choice.
+    per_pass_selection = None
+    n_accum_rank = a.rows_per_rank // a.mini_batch_size
+    if a.micro_batches_per_pass == 0:
+        cands = [k for k in (1, 2, 4) if a.readout in ("dense", "masked") and n_accum_rank % k == 0 and n_accum_rank // k >= 2] or [1]
+        per_pass_selection = {}
+        if len(cands) > 1:
+            with Watchdog(600.0, "choosing micro-batches per pass"):
+                for k in cands:
+                    if not plans_loaded and k > 1:
+                        tune.tune_model_shapes(k * a.mini_batch_size * cfg["ctx_len"], cfg["n_embd"], 2 ** 16, device=dev)
+                        if world > 1:
+                            box = [tune.export_plans() if rank == 0 else None]
+                            dist.broadcast_object_list(box, src=0)
+                            if rank != 0:
+                                tune.import_plans(box[0])
+                    _step.per_pass = k
+                    step(batches[0])
+                    sync()
+                    t0 = time.perf_counter()
+                    for i in range(2):
+                        step(batches[(1 + i) % len(batches)])
+                    sync()
+                    tk = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                    if world > 1:
+                        dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+                    per_pass_selection[k] = round(float(tk.item()) / 2 * 1e3, 3)
+            best = min(per_pass_selection, key=per_pass_selection.get)
+            if world > 1:
+                box = [best if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                best = box[0]
+        else:
+            best = cands[0]
+        a.micro_batches_per_pass = best
+        log(f"micro-batches per pass: {best} (ms per step over two steps: {per_pass_selection})")
+    _step.per_pass = a.micro_batches_per_pass
+    if a.plan_cache and rank == 0 and not plans_loaded:
+        tune.save_plans(a.plan_cache)
     log(f"model built, plans ready; timing {a.warmup}+{a.steps} steps")
     losses = []
     step_budget_s = float(os.environ.get("OBTE_BENCH_STEP_TIMEOUT_S", "30")) * (4.0 if rehearse else 1.0)
@@ -601,19 +644,25 @@ def main():
                                                        "note": "the reference's literal graph: dense [M,V] d(logits) and full-size readout backward products "
                                                                "(85 % of those rows are exact zeros); identical loss and gradients"}
             _step.lm_head_impl = a.readout
-        if a.readout in ("dense", "masked") and a.micro_batches_per_pass == 1 and (a.rows_per_rank // a.mini_batch_size) % 2 == 0:
-            _step.per_pass = 2
-            tune.tune_model_shapes(2 * a.mini_batch_size * cfg["ctx_len"], cfg["n_embd"], 2 ** 16, device=dev)   # plans for the 16-row shapes
-            if world > 1:
-                box = [tune.export_plans() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                if rank != 0:
-                    tune.import_plans(box[0])
-            variants["two_micro_batches_per_pass"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 10,
-                                                      "note": "an execution option, off in the headline: two micro-batches of 8 rows go through the model in one "
-                                                              "16-row pass, every masked row weighted by its own micro-batch's count, so loss and gradients are those of "
-                                                              "separate passes (tested); every kernel sees twice the rows per launch"}
-            _step.per_pass = 1
+        if a.readout in ("dense", "masked"):
+            # the headline's k was chosen at start-up; here the neighbouring choices over 10 steps each (k = 1 is one pass per
+            # micro-batch, the form rounds 1-3 quoted)
+            for k_alt in (1, 2, 4):
+                if k_alt == a.micro_batches_per_pass or n_accum_rank % k_alt != 0 or n_accum_rank // k_alt < 2:
+                    continue
+                _step.per_pass = k_alt
+                if not plans_loaded:
+                    tune.tune_model_shapes(k_alt * a.mini_batch_size * cfg["ctx_len"], cfg["n_embd"], 2 ** 16, device=dev)   # plans for its shapes
+                    if world > 1:
+                        box = [tune.export_plans() if rank == 0 else None]
+                        dist.broadcast_object_list(box, src=0)
+                        if rank != 0:
+                            tune.import_plans(box[0])
+                variants[f"micro_batches_per_pass_{k_alt}"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 10,
+                                                               "note": f"{k_alt} micro-batch{'es' if k_alt > 1 else ''} of {a.mini_batch_size} rows per forward/backward pass "
+                                                                       f"(the headline runs {a.micro_batches_per_pass}); same loss and gradients (per-micro-batch masks and loss "
+                                                                       "normalisation are kept), every kernel sees that many times the rows per launch"}
+            _step.per_pass = a.micro_batches_per_pass
         if a.dropout == 0.0:
             TE.set_dropout(m, 0.1)
             variants["dropout_0.1"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 10,
@@ -669,9 +718,11 @@ def main():
             "dtype": "bf16", "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU over gloo; not a measurement)",
             "config": {"workload": f"{READOUT_LEAD['masked_full' if (a.readout == 'masked' and a.full_last_block) else a.readout]}; "
                                    f"OmniBioTA {a.config} ({cfg['n_layer']}L/{cfg['n_embd']}d/{cfg['n_head']}h) ctx={T} MLM train step: "
-                                   f"{a.rows_per_rank} rows/rank = {a.rows_per_rank // a.mini_batch_size} micro-batches of {a.mini_batch_size}, "
+                                   f"{a.rows_per_rank} rows/rank = {a.rows_per_rank // a.mini_batch_size} micro-batches of {a.mini_batch_size} ({a.micro_batches_per_pass} per pass), "
                                    f"{READOUT_TEXT[a.readout]}, dropout {a.dropout:g}, {'multi' if a.multi_document else 'single'}-document rows",
                        "global_batch_rows": a.rows_per_rank * world, "mini_batch_size": a.mini_batch_size, "seq_len": T,
+                       "micro_batches_per_pass": a.micro_batches_per_pass,
+                       "micro_batches_per_pass_selection_ms_per_step": per_pass_selection,
                        "parallelism": f"dp{world}", "dropout": a.dropout, "vocab": 65536,
                        "collectives": collectives},
             # FLOP the step actually executes per token: the reference's 6N + 12LCT (train_encoder.py:360) minus the part of the
