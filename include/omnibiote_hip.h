@@ -128,10 +128,13 @@ int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s);
  * a NULL or smaller workspace simply disables the split.  Split-K needs epilogue NONE or ADD and ldd == N. */
 int64_t obte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64_t workspace_bytes, obte_stream s);
-/* Tuned plans.  The library holds two GEMM structures (1: 128x128 tiles, two workgroups per CU; 2: 256x128 or
- * 256x256 tiles, one workgroup per CU, optional split-K); which is fastest depends on the shape (tile quantisation
- * against 256 CUs, K length, where the operands are served from).  A host-side tuner times the candidates once per
- * (layout, epilogue, M, N, K) and records the winner here; unknown shapes fall back to a built-in heuristic.
+/* Tuned plans.  The library holds five GEMM structures (variant 1: 128x128 tiles, two workgroups per CU; 2: the K-tile ring,
+ * 256x128 / 256x192 / 256x256 tiles, one workgroup per CU, optional split-K; 3: the half-tile ring, 256x256; 4: the half-tile
+ * ring at 256x128 and two workgroups per CU; 5: persistent 256x128 tiles whose output is stored from inside the next tile's
+ * main loop — whole tiles, k-contiguous operands, >= 2 tiles per workgroup, no split-K); which is fastest depends on the shape
+ * (tile quantisation against 256 CUs, K length, where the operands are served from).  A host-side tuner times the candidates once
+ * per (layout, epilogue, M, N, K) and records the winner here; unknown shapes fall back to a built-in heuristic, and a plan a shape
+ * cannot run (a borrowed near-match, edge tiles) falls back the same way.
  * obte_gemm_workspace_bytes_max: a workspace size that admits any recordable plan. */
 int obte_gemm_plan_set(int a_kmajor, int b_kmajor, int epilogue, int64_t M, int64_t N, int64_t K, int variant, int bn,
                        int splits);

@@ -667,6 +667,9 @@ def parse_args(argv=None):
     p.add_argument("--multi_document", action="store_true", default=False, help="synthetic rows with interior EOS")
     p.add_argument("--pipeline_streams", type=int, default=2, choices=[1, 2, 3],
                    help="2: overlap the forward of micro-batch j+1 with the backward of micro-batch j (same results)")
+    p.add_argument("--micro_batches_per_pass", type=int, default=1,
+                   help="k > 1: k micro-batches of --mini_batch_size rows per forward/backward pass (masks and loss normalisation stay per "
+                        "micro-batch: same loss and gradients; +4-6 %% at k = 2-4 on the small config, bench.py chooses it by measurement)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="torch.distributed backend: nccl (= RCCL over xGMI, the production path) or gloo (plumbing runs: "
                         "BASELINE config 1; gradients then cross the host)")
@@ -842,7 +845,8 @@ def run(args):
     n_params = m.get_num_params()
     if on_gpu:
         from . import tune
-        tune.tune_model_shapes(args.mini_batch_size * args.ctx_len, args.n_embd, 2 ** 16, device=device, verbose=(rank == 0))
+        tune.tune_model_shapes(max(1, getattr(args, "micro_batches_per_pass", 1)) * args.mini_batch_size * args.ctx_len, args.n_embd, 2 ** 16,
+                               device=device, verbose=(rank == 0))
         if world > 1:   # every rank adopts rank 0's plan table: the replicas then run the same kernels
             box = [tune.export_plans() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
@@ -852,7 +856,7 @@ def run(args):
     total_iters = int(args.token_budget / (world * batch_size * args.ctx_len))
     opt, sched = build_optimizer(m, args, total_iters, fused=on_gpu)
     step = TrainStep(model, opt, sched, mini_batch_size=args.mini_batch_size, n_head=args.n_head, use_padding=args.use_padding,
-                     pipeline_streams=getattr(args, "pipeline_streams", 1))
+                     pipeline_streams=getattr(args, "pipeline_streams", 1), micro_batches_per_pass=getattr(args, "micro_batches_per_pass", 1))
     rng = np.random.default_rng(1234 + rank)
     next_batch, source, close_source = make_batch_source(args, batch_size, device, rng)
     test_sources = make_test_sources(args, device, rng)

@@ -55,6 +55,9 @@ def candidates(M: int, N: int, K: int, epi: int, a_kmajor: bool = False, b_kmajo
     c = [(1, 128, 1), (2, 128, 1)]
     if a_kmajor and b_kmajor and N % 192 == 0 and epi != L.EPI_GELU_BWD:
         c.append((2, 192, 1))      # 256 x 192 tiles: full rounds where N / 256 leaves a ragged one (c_attn: 3072 -> 512 tiles)
+    if (a_kmajor and b_kmajor and M % 256 == 0 and N % 128 == 0 and K % 64 == 0 and K >= 640 and (M // 256) * (N // 128) >= 512
+            and epi in (L.EPI_NONE, L.EPI_GELU, L.EPI_ADD, L.EPI_GELU_BWD)):
+        c.append((5, 128, 1))      # persistent 256 x 128 tiles, a tile's stores leave under the next tile's main loop
     if K >= 128:
         c.append((4, 128, 1))      # the half-tile ring at two workgroups per CU
     if N >= 256:
@@ -80,7 +83,7 @@ def rank_candidates(times: dict) -> list:
     goes first — inside the step, with warm operands and neighbours, it is the one that holds its time (the row-compact readout
     input gradient: 160-195 us on the half-tile ring against 190-215 us when the K-tile ring won the coin toss)."""
     results = sorted((t, c[0], c[1], c[2]) for c, t in times.items())
-    prefer = {3: 0, 2: 1, 4: 2, 1: 3}
+    prefer = {5: 0, 3: 1, 2: 2, 4: 3, 1: 4}
     tied = [r for r in results if r[0] <= results[0][0] * 1.03]
     tied.sort(key=lambda r: (prefer.get(r[1], 9), r[0]))
     return tied[:1] + [r for r in results if r is not tied[0]]

@@ -10,7 +10,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omnibiote_amd import _lib as L, ops  # noqa: E402
 
-M, C, V = 8192, 1024, 65536
+M = int(os.environ.get("OBTE_BENCH_M", "8192"))   # rows per launch (8192 = one micro-batch of 8 x 1024 tokens)
+C, V = 1024, 65536
 SHAPES = {
     # name: (kind, M, N, K)
     "fwd_qkv": ("nt", M, 3 * C, C), "fwd_proj": ("nt_add", M, C, C), "fwd_fc": ("nt_gelu", M, 4 * C, C),

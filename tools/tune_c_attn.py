@@ -1,4 +1,8 @@
+"""Verbose tuning of a few block GEMM shapes (which structure wins and by how much).   python tools/tune_c_attn.py [rows]"""
 import sys; sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omnibiote_amd import tune, _lib as L
-for (M,N,K,epi) in [(8192,3072,1024,L.EPI_ROPE_QK),(8192,3072,1024,L.EPI_NONE),(8192,4096,1024,L.EPI_GELU),(8192,6144,2048,L.EPI_ROPE_QK),(32768,3072,1024,L.EPI_ROPE_QK)]:
-    tune.tune_gemm(M,N,K,True,True,epi,verbose=True)
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+for (N, K, epi) in [(3072, 1024, L.EPI_ROPE_QK), (3072, 1024, L.EPI_NONE), (4096, 1024, L.EPI_GELU), (1024, 1024, L.EPI_ADD), (1024, 4096, L.EPI_ADD)]:
+    tune.tune_gemm(M, N, K, True, True, epi, verbose=True)
