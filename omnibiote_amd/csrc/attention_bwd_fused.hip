@@ -702,48 +702,6 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         if (t_sig >= 0) __hip_atomic_fetch_add(flag_b + t_sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (n_sl > 0 && !(info_prev & 0x80)) __hip_atomic_fetch_add(flag_b + t_prev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // The slices whose chain this workgroup ENDED hold their complete fp32 sums, written by this very wave (same lanes, same
-    // addresses): softmax scale, inverse RoPE, one rounding to bf16.  Done here and not in the loop, where the rotation-table
-    // entries would hold 16 registers through its tightest phase; four tiles per round trip.
-    {
-        int* lastlist = kbb;   // (the key blocks' ranges are no longer needed) compact list of those slices, in visiting order
-        int n_last = 0;
-        for (int i = tid; i < n_sl; i += FB_NW * 64)
-            if (tab[i] & 0x80) {
-                int rank = 0;
-                for (int j = 0; j < i; ++j) rank += (tab[j] >> 7);
-                lastlist[rank] = slice_at(i);
-            }
-        for (int j = 0; j < n_sl; ++j) n_last += (tab[j] >> 7);   // (every thread: uniform)
-        n_last = __builtin_amdgcn_readfirstlane(n_last);
-        __syncthreads();
-        for (int base = 0; base < n_last; base += 2) {
-            // (two tiles per round trip: the second tile's loads are in flight while the first one's statement waits — vmcnt(0) in the
-            //  statement that issued them covers both)
-            AccRegs r[2];
-            RopeQ rq[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                if (base + j < n_last) {
-                    const int t = __builtin_amdgcn_readfirstlane(lastlist[base + j]);
-                    if (p.rope_cos) load_rope(t, rq[j]);
-                    load_acc_sync(t, r[j]);
-                }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                if (base + j < n_last) {
-                    const int t = __builtin_amdgcn_readfirstlane(lastlist[base + j]);
-                    f32x16 dq;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) dq[4 * i + e] = r[j].x[i][e];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) store_final(t, dq, rq[j], i);
-                }
-        }
-    }
-
     {   // dV and dK rows leave through the wave's own K rows in LDS as whole 256-byte rows (wave_rows_out); dK rotated back
         char* wl = Kblk + wave * (64 * 2 * D);
 #pragma unroll
@@ -773,6 +731,49 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
                     for (int j = 0; j < 4; ++j) gb[4 * dt + i][j] = f2bf(g[j]);
                 }
             wave_rows_out<D>(wl + 32 * 2 * D, gb, dk0, ld, rows_ok, lane);
+        }
+    }
+
+    // The slices whose chain this workgroup ENDED hold their complete fp32 sums, written by this very wave (same lanes, same
+    // addresses): softmax scale, inverse RoPE, one rounding to bf16.  Done here and not in the loop, where the rotation-table
+    // entries would hold 16 registers through its tightest phase — and AFTER the dK / dV rows have left, so that the 256
+    // accumulator registers are free and four tiles (with their rotation entries) travel per dependent round trip.
+    {
+        constexpr int FIN = 4;
+        int* lastlist = kbb;   // (the key blocks' ranges are no longer needed) compact list of those slices, in visiting order
+        int n_last = 0;
+        for (int i = tid; i < n_sl; i += FB_NW * 64)
+            if (tab[i] & 0x80) {
+                int rank = 0;
+                for (int j = 0; j < i; ++j) rank += (tab[j] >> 7);
+                lastlist[rank] = slice_at(i);
+            }
+        for (int j = 0; j < n_sl; ++j) n_last += (tab[j] >> 7);   // (every thread: uniform)
+        n_last = __builtin_amdgcn_readfirstlane(n_last);
+        __syncthreads();
+        for (int base = 0; base < n_last; base += FIN) {
+            // (FIN tiles per round trip: the later tiles' loads are in flight while the first one's statement waits)
+            AccRegs r[FIN];
+            RopeQ rq[FIN];
+#pragma unroll
+            for (int j = 0; j < FIN; ++j)
+                if (base + j < n_last) {
+                    const int t = __builtin_amdgcn_readfirstlane(lastlist[base + j]);
+                    if (p.rope_cos) load_rope(t, rq[j]);
+                    load_acc_sync(t, r[j]);
+                }
+#pragma unroll
+            for (int j = 0; j < FIN; ++j)
+                if (base + j < n_last) {
+                    const int t = __builtin_amdgcn_readfirstlane(lastlist[base + j]);
+                    f32x16 dq;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dq[4 * i + e] = r[j].x[i][e];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) store_final(t, dq, rq[j], i);
+                }
         }
     }
 }

@@ -7,7 +7,11 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_other_configs --no_variants --no_roofline --plan_cache $OUT/plans.json > $OUT/plan_run.log 2>&1
 echo "plans cached: $(wc -c < $OUT/plans.json) bytes"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_other_configs --no_variants --pipeline_streams 1 --plan_cache $OUT/plans.json --shapes_out $OUT/shapes.txt > $OUT/bench_line.json 2> $OUT/kt.log
+# the micro-batches per pass that run chose at start-up: the traced run takes it as given (no selection steps in the trace)
+PP=$(python3 -c "import json; print(json.loads(open('$OUT/plan_run.log').read().strip().splitlines()[-1])['config']['micro_batches_per_pass'])" 2>/dev/null || echo 1)
+echo "micro-batches per pass: $PP"
+echo $PP > $OUT/per_pass.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_other_configs --no_variants --pipeline_streams 1 --micro_batches_per_pass $PP --plan_cache $OUT/plans.json --shapes_out $OUT/shapes.txt > $OUT/bench_line.json 2> $OUT/kt.log
 echo "kernel trace rc=$?"
 find $OUT/kt -name "*kernel_stats.csv" | head -2
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $OUT/pmc_a -o a -- python3 tools/attn_bench.py --reps 3 > $OUT/pmc_a.log 2>&1
