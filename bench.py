@@ -568,8 +568,15 @@ def main():
             roofline = roofline_from_profile(ms, dims, kind, 1)
             # HBM bytes per launch of the GEMM family: PMC counters cannot be read from inside this process, so the
             # figure comes from the committed rocprofv3 --pmc passes over this same workload (tools/pmc_traffic.py)
-            pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_gemm_family_traffic.json", "r02_pmc_gemm_family_traffic.json", "r01_pmc_gemm_family_traffic.json"))
-                        if os.path.exists(q)), "")
+            # (a pass recorded at another number of micro-batches per pass has other launches: only a matching one is quoted)
+            def _pmc_matches(q):
+                try:
+                    with open(q) as f:
+                        return json.load(f).get("micro_batches_per_pass", 1) == a.micro_batches_per_pass
+                except Exception:
+                    return False
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_gemm_family_traffic.json", "r03_pmc_gemm_family_traffic.json", "r02_pmc_gemm_family_traffic.json"))
+                        if os.path.exists(q) and _pmc_matches(q)), "")
             default_workload = (a.config == "small" and a.readout == "masked" and a.dropout == 0.0 and not a.multi_document
                                 and a.rows_per_rank == 128 and a.mini_batch_size == 8)
             if default_workload and pmc:
