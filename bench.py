@@ -3,7 +3,8 @@
     python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torchrun, one rank per GPU)
 
 A *step* is one optimizer step of the reference's training loop (training/train_encoder.py:241-323) on this rank's
-128 rows of 1024 synthetic tokens: 16 accumulated micro-batches of mini_batch_size 8 through the drop-in
+128 rows of 1024 synthetic tokens: 16 accumulated micro-batches of mini_batch_size 8 (k of them per forward/backward pass,
+k in {1, 2, 4} chosen by measurement at start-up and named in ``config``: masks and loss normalisation stay per micro-batch) through the drop-in
 ``OmniBioTA`` (small: 8L/1024d/8h, bf16, dropout 0), the 65 536-way readout and masked-LM cross entropy evaluated on the
 MLM-masked positions only (``--readout masked``, the default since round 3: the loss multiplies every other position by
 zero, train_encoder.py:304, so loss and gradients are the reference's; the last block's MLP half and ln_f run on those
