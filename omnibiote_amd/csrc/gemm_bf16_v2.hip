@@ -653,6 +653,136 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v5_kernel(GemmParams p) {
 OBTE_INST5(true, true) OBTE_INST5(true, false)
 #undef OBTE_INST5
 
+// ---- structure 6: 256 x 256 tile, FOUR waves (one per SIMD), 128 x 128 per wave, accumulators in AGPRs ---------------------------
+// One wave per SIMD has the SIMD's whole register file: the 64 accumulator quads (256 registers) live in AGPRs through asm MFMAs
+// with "+a" operands, the VGPRs hold double-buffered fragments — and, in the persistent form, the previous tile's output on its
+// way out.  Per k-step of 32 a wave reads 16 fragments for 64 MFMAs (the eight-wave structures: 12 for 32), i.e. 2/3 of their LDS
+// traffic per FLOP.  K-tile ring of two 64-KiB stages as in the 256-wide structure 2; x W^T layouts (k-contiguous A and B).
+constexpr int V6_THREADS = 256;
+constexpr int V6_STAGE = 2 * BM * BKT * 2;            // 64 KiB: A 256 x 64, B 256 x 64
+constexpr int V6_LDE = 128 * 2 + 16;                   // staged row of the 128-wide wave tile
+constexpr int V6_SMEM = 4 * 128 * V6_LDE > 2 * V6_STAGE ? 4 * 128 * V6_LDE : 2 * V6_STAGE;   // 136 KiB
+__device__ __forceinline__ void mfma16_acc(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("s_nop 0\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+template <int EPI>
+__global__ __launch_bounds__(V6_THREADS, 1) void gemm_v6_kernel(GemmParams p) {
+    constexpr int BN = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int tid_ = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int group_sz = 8 * p.tiles_n;
+    const int first_m = (tid_ / group_sz) * 8;
+    const int gsz = min(p.tiles_m - first_m, 8);
+    const int tm = first_m + (tid_ % group_sz) % gsz;
+    const int tn = (tid_ % group_sz) / gsz;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    // LDS-DMA pieces of 1 KiB (8 rows x 128 B of a k-contiguous tile): piece = wave + 4 i, i < 8, per operand
+    int voff_a[8], voff_b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = (wave + 4 * i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        voff_a[i] = (int)((row * p.lda + chunk * 8) * 2);
+        voff_b[i] = (int)((row * p.ldb + chunk * 8) * 2);
+    }
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4 acc[8][8];   // [ni][mi]: C^T quads, row = n, col = m
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = (int)((p.K + BKT - 1) / BKT);
+    auto issue = [&](int t, int stage) {
+        const int64_t k0 = (int64_t)t * BKT;
+        const int64_t ao = m0 * p.lda + k0, bo = n0 * p.ldb + k0;
+        const i32x4_t ra = make_rsrc_words(p.a + ao, (p.a_elems - ao) * 2), rb = make_rsrc_words(p.b + bo, (p.b_elems - bo) * 2);
+        const uint32_t base = lds_addr_of(smem + stage * V6_STAGE) + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lds_dma16(ra, base + 4 * i * 1024, voff_a[i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lds_dma16(rb, base + A_TILE + 4 * i * 1024, voff_b[i]);
+    };
+    auto load_a = [&](int t, int ks, bf16x8 (&af)[8]) {
+        const char* ta = smem + (t & 1) * V6_STAGE;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = load_frag<true, BM>(ta, wm * 128 + i * 16, ks, lane);
+    };
+    auto load_b = [&](int t, int ks, bf16x8 (&bfr)[8]) {
+        const char* tb = smem + (t & 1) * V6_STAGE + A_TILE;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bfr[i] = load_frag<true, BN>(tb, wn * 128 + i * 16, ks, lane);
+    };
+    auto mma = [&](const bf16x8 (&af)[8], const bf16x8 (&bfr)[8]) {
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) mfma16_acc(acc[ni][mi], bfr[ni], af[mi]);
+    };
+    bf16x8 a0[8], b0[8], a1[8], b1[8];
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    load_a(0, 0, a0); load_b(0, 0, b0);
+    for (int t = 0; t + 1 < nk; ++t) {
+        load_a(t, 1, a1); load_b(t, 1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // K-tile t + 1 has landed; this wave's reads of tile t are in registers
+        __builtin_amdgcn_s_barrier();
+        load_a(t + 1, 0, a0); load_b(t + 1, 0, b0);
+        if (t + 2 < nk) issue(t + 2, t & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    load_a(nk - 1, 1, a1); load_b(nk - 1, 1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0);
+    mma(a1, b1);
+
+    // ---- epilogue: accumulators -> per-wave staging (128 rows x 128 bf16) -> 16-byte row chunks -> global --------------------
+    __syncthreads();
+    const int em = lane & 15, en = (lane >> 4) * 4;
+    char* stg = smem + wave * (128 * V6_LDE);
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            bf16x4 v;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) v[rr] = f2bf(acc[ni][mi][rr] * p.alpha);
+            *reinterpret_cast<bf16x4*>(stg + (mi * 16 + em) * V6_LDE + (ni * 16 + en) * 2) = v;
+        }
+    __syncthreads();
+    const int64_t o_l = (m0 + wm * 128 + lane / 16) * p.ldd + n0 + wn * 128 + (lane % 16) * 8;
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + (4 * it + lane / 16) * V6_LDE + (lane % 16) * 16);
+        const int64_t o = o_l + (int64_t)it * 4 * p.ldd;
+        if (EPI == OBTE_EPI_GELU) {
+            bf16x8 g;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                f32x2_t act, der;
+                gelu_ref_both2(f32x2_t{bf2f(v[j]), bf2f(v[j + 1])}, act, der);
+                g[j] = f2bf(act[0]); g[j + 1] = f2bf(act[1]);
+                v[j] = f2bf(der[0]); v[j + 1] = f2bf(der[1]);
+            }
+            *reinterpret_cast<bf16x8*>(p.d2 + o) = g;
+        }
+        *reinterpret_cast<bf16x8*>(p.d + o) = v;
+    }
+}
+template __global__ void gemm_v6_kernel<OBTE_EPI_NONE>(GemmParams);
+template __global__ void gemm_v6_kernel<OBTE_EPI_GELU>(GemmParams);
+
 // Explicit instantiations: with implicit instantiation alone hipcc (ROCm 7.2) emitted the host stub of only the
 // first specialisation it met; the library then failed to load with undefined kernel symbols.
 #define OBTE_INST(AK, BK, BN)                                                                    \
@@ -1268,6 +1398,21 @@ int dispatch5(const GemmParams& p, int epi, hipStream_t st) {
     obte_set_error("obte_gemm_bf16: epilogue %d has no persistent form", epi);
     return OBTE_EINVAL;
 }
+template <int EPI>
+int launch6(const GemmParams& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_v6_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, V6_SMEM);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_v6_kernel<EPI>), dim3(p.tiles_m * p.tiles_n), dim3(V6_THREADS), V6_SMEM, st, p);
+    OBTE_CHECK_LAUNCH("obte_gemm_bf16");
+    return OBTE_OK;
+}
+static bool v6_eligible(const obte_gemm_args* g) {
+    return g->a_kmajor && g->b_kmajor && g->M % BM == 0 && g->N % 256 == 0 && g->K % BKT == 0 && g->K >= 2 * BKT &&
+           (g->epilogue == OBTE_EPI_NONE || g->epilogue == OBTE_EPI_GELU);
+}
 // the persistent structure takes whole 256 x 128 tiles of k-contiguous A, at least two per workgroup, ten K-tiles or more
 static bool v5_eligible(const obte_gemm_args* g) {
     if (!g->b_kmajor) { const char* e = getenv("OBTE_GEMM_V5_NN"); if (!(e && e[0] == '1')) return false; }   // (B not k-contiguous: the build spills; opt-in for experiments)
@@ -1337,7 +1482,8 @@ static bool lookup_plan(const obte_gemm_args* g, Plan* out, bool* near_match = n
 
 extern "C" int obte_gemm_plan_set(int a_kmajor, int b_kmajor, int epilogue, int64_t M, int64_t N, int64_t K, int variant,
                                   int bn, int splits) {
-    OBTE_REQUIRE(variant >= 1 && variant <= 5 && (bn == 128 || bn == 256 || bn == 192) && splits >= 1 && splits <= 64, "obte_gemm_plan_set: bad plan");
+    OBTE_REQUIRE(variant >= 1 && variant <= 6 && (bn == 128 || bn == 256 || bn == 192) && splits >= 1 && splits <= 64, "obte_gemm_plan_set: bad plan");
+    OBTE_REQUIRE(!(variant == 6 && (bn != 256 || splits != 1 || !a_kmajor || !b_kmajor)), "obte_gemm_plan_set: the four-wave structure is 256 wide, k-contiguous operands, no split-K");
     OBTE_REQUIRE(!(variant == 5 && (bn != 128 || splits != 1 || !a_kmajor)), "obte_gemm_plan_set: the persistent structure is 128 wide, k-contiguous A, no split-K");
     OBTE_REQUIRE(!(bn == 192 && (variant != 2 || splits != 1 || !a_kmajor || !b_kmajor || epilogue == OBTE_EPI_GELU_BWD)),
                  "obte_gemm_plan_set: the 192-wide tile exists for the K-tile ring, k-contiguous operands, no split-K");
@@ -1491,6 +1637,7 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     if (pl.splits > 1 && (!can_split || (int64_t)pl.splits * g->M * g->N * 4 > workspace_bytes)) pl = make_plan(g->M, g->N, g->K, false);
     if (pl.bn == 192 && !(g->a_kmajor && g->b_kmajor && g->epilogue != OBTE_EPI_GELU_BWD)) pl = make_plan(g->M, g->N, g->K, false);
     if (pl.variant == 5 && !v5_eligible(g)) pl = make_plan(g->M, g->N, g->K, false);   // (a plan borrowed by a near shape, or edge tiles)
+    if (pl.variant == 6 && !v6_eligible(g)) pl = make_plan(g->M, g->N, g->K, false);
     // profiler record kind = layout/epilogue code + 1000 * kernel structure (1: gemm_bf16_kernel, 2: gemm_v2_kernel, 3: gemm_v3_kernel)
     const int kind0 = (g->a_kmajor ? 8 : 0) + (g->b_kmajor ? 4 : 0) + g->epilogue;
     if (use_v1() || pl.variant == 1) {
@@ -1515,6 +1662,13 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     p.dbg_times = debug_gemm_times_buffer((int64_t)p.tiles_m * p.tiles_n * p.splits);
 #endif
     const bool long_enough = p.k_per_split >= 2 && nk - (int64_t)(p.splits - 1) * p.k_per_split >= 2;   // the half-tile rings need >= 4 half-steps
+    const bool v6 = pl.variant == 6 && pl.bn == 256 && p.splits == 1;
+    if (v6) {
+        const int prof6 = obte_prof_begin(st, kind0 + 6000, g->M, g->N, g->K);
+        rc = g->epilogue == OBTE_EPI_GELU ? launch6<OBTE_EPI_GELU>(p, st) : launch6<OBTE_EPI_NONE>(p, st);
+        obte_prof_end(prof6, st);
+        return rc;
+    }
     const bool v5 = pl.variant == 5 && pl.bn == 128 && p.splits == 1;
     const bool v3 = !v5 && use_v3(pl.variant) && pl.bn == 256 && long_enough;
     const bool v4 = !v5 && !v3 && use_v4(pl.variant) && pl.bn == 128 && long_enough;

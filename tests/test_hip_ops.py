@@ -779,6 +779,30 @@ def test_gemm_persistent_structure_with_deferred_stores():
         L().check(lib.obte_gemm_plan_clear(), "obte_gemm_plan_clear")
 
 
+def test_gemm_four_wave_structure():
+    """Structure 6 (256 x 256 tile, four waves, one per SIMD, the 64 accumulator quads in AGPRs through asm MFMAs): an A/B
+    candidate reachable through the plan table (x @ W^T, plain and GELU pair).  Same per-tile arithmetic as the K-tile ring: equal
+    bit for bit, 2 to 64 K-tiles, one tile to several rounds; shapes it does not take fall back."""
+    o, lib = ops(), L().lib()
+    try:
+        for (M, N, K, epi) in [(256, 256, 128, 0), (512, 512, 192, 0), (1024, 768, 1024, 0), (8192, 4096, 1024, 1), (2048, 1024, 4096, 0)]:
+            x, w = rnd(M, K, seed=3).to(DEV), rnd(N, K, seed=4, scale=0.2).to(DEV)
+            outs = {}
+            for variant in (2, 6):
+                L().check(lib.obte_gemm_plan_set(1, 1, epi, M, N, K, variant, 256, 1), "obte_gemm_plan_set")
+                outs[variant] = o.linear_fwd(x, w, epilogue=epi)
+            if epi == L().EPI_GELU:
+                assert torch.equal(outs[2][0], outs[6][0]) and torch.equal(outs[2][1], outs[6][1])
+            else:
+                assert torch.equal(outs[2], outs[6]), (M, N, K)
+                close(outs[6][:256], x[:256].float().cpu() @ w.float().cpu().t(), atol=0.02 * math.sqrt(K) * 0.2, what="four-wave structure")
+        L().check(lib.obte_gemm_plan_set(1, 1, 0, 300, 520, 128, 6, 256, 1), "obte_gemm_plan_set")   # ragged: heuristic plan instead
+        xs, ws = rnd(300, 128, seed=1), rnd(520, 128, seed=2, scale=0.2)
+        close(o.linear_fwd(xs.to(DEV), ws.to(DEV)), xs.float() @ ws.float().t(), atol=0.02 * math.sqrt(128) * 0.2, what="fallback")
+    finally:
+        L().check(lib.obte_gemm_plan_clear(), "obte_gemm_plan_clear")
+
+
 def test_gemm_192_wide_tile():
     """The 256 x 192 tile of the K-tile ring (N = 3072 is sixteen of them: two full rounds of 256 workgroups instead of
     one and a half of the 256-wide tile), installed through the plan table for x @ W^T: plain, GELU pair, residual add,

@@ -15,7 +15,7 @@ aux = torch.randn(M * N, device=dev, generator=g).to(torch.bfloat16) if epi in (
 out = torch.empty(M * N, device=dev, dtype=torch.bfloat16)
 big = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 lib = L.lib()
-for variant, bn in ((2, 128), (5, 128), (4, 128), (2, 256), (3, 256)):
+for variant, bn in ((2, 128), (5, 128), (4, 128), (2, 256), (3, 256), (6, 256)):
     if lib.obte_gemm_plan_set(int(ak), int(bk), epi, M, N, K, variant, bn, 1) != 0:
         continue
     res = {}
