@@ -169,6 +169,10 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     const int C = p.H * D;
     const int64_t ld = 3 * (int64_t)C;
     const int64_t bh = b * p.H + hd;
+#ifdef OBTE_DEBUG_HOOKS
+    unsigned long long t_entry = 0;
+    if (p.dbg_times) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) :: "memory");
+#endif
 
     char* Kblk = smem + S::NSTG * S::STAGE;
     char* dsimg = Kblk + S::KBYTES;
@@ -353,11 +357,13 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     // (register-destination form, for the epilogue only: each load is waited for in the statement that issues it)
     struct AccRegs { f32x4 x[4]; };
     auto load_acc_sync = [&](int t, AccRegs& r) {
+        // (compiler-issued, plain loads: after the slice loop nothing hand-counted is in flight, so hipcc may put the loads of several
+        //  tiles in flight and wait once — the asm form of round 4's first version waited inside every tile's statement, one
+        //  dependent round trip per tile; plain because these tiles were last written by this very wave, same lanes and addresses,
+        //  through this XCD's L2: the line there is the final one)
         const int off = t * 16384 + acc_lane;
-        asm volatile("buffer_load_dwordx4 %0, %4, %5, 0 offen sc1\n\tbuffer_load_dwordx4 %1, %4, %5, 0 offen offset:1024 sc1\n\t"
-                     "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:2048 sc1\n\tbuffer_load_dwordx4 %3, %4, %5, 0 offen offset:3072 sc1\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(r.x[0]), "=&v"(r.x[1]), "=&v"(r.x[2]), "=&v"(r.x[3]) : "v"(off), "s"(rs_acc) : "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.x[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_acc, off + i * 1024, 0, 0));
     };
     auto store_acc = [&](int t, const f32x16& dq, int i) {   // piece i of 4
         const f32x4 x = {dq[4 * i], dq[4 * i + 1], dq[4 * i + 2], dq[4 * i + 3]};
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         for (int r = 0; r < 16; ++r) sc[r] = ((unsigned)((r & 3) + 8 * (r >> 2) - m_lo) < m_len) ? sc[r] : -INFINITY;
     };
 #ifdef OBTE_DEBUG_HOOKS
-    if (stamping) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory"); }
+    if (stamping) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast) :: "memory"); tsum[6] = tlast - t_entry; }   // slot 6: everything outside the slice loop (prologue here, the rest at the end)
 #endif
     // loop-carried hand-off state: the previous slice (whose dQ^T tile this iteration forms and hands on), this workgroup's place
     // in that slice's chain, and the counter value polled for it an iteration ago
@@ -672,10 +678,7 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         t_prev = t; info_prev = info; have_prev = have_cur;
     }
 #ifdef OBTE_DEBUG_HOOKS
-    if (stamping && tid == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) p.dbg_times[(size_t)blockIdx.x * 8 + k] = tsum[k];
-    }
+    const unsigned long long t_loop_end = tlast;
 #endif
 #undef OBTE_PHASE
 #undef OBTE_SB
@@ -702,6 +705,10 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         if (t_sig >= 0) __hip_atomic_fetch_add(flag_b + t_sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (n_sl > 0 && !(info_prev & 0x80)) __hip_atomic_fetch_add(flag_b + t_prev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef OBTE_DEBUG_HOOKS
+    unsigned long long t_a = 0, t_b = 0;   // (OBTE_ATTN_SKIP=1 / 2 / 3 with the stamps: slot 6 = prologue / + last slice and signals / + dK, dV rows)
+    if (p.dbg_times) asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_a) :: "memory");
+#endif
     {   // dV and dK rows leave through the wave's own K rows in LDS as whole 256-byte rows (wave_rows_out); dK rotated back
         char* wl = Kblk + wave * (64 * 2 * D);
 #pragma unroll
@@ -734,12 +741,15 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         }
     }
 
+#ifdef OBTE_DEBUG_HOOKS
+    if (p.dbg_times) asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_b) :: "memory");
+#endif
     // The slices whose chain this workgroup ENDED hold their complete fp32 sums, written by this very wave (same lanes, same
     // addresses): softmax scale, inverse RoPE, one rounding to bf16.  Done here and not in the loop, where the rotation-table
     // entries would hold 16 registers through its tightest phase — and AFTER the dK / dV rows have left, so that the 256
-    // accumulator registers are free and four tiles (with their rotation entries) travel per dependent round trip.
+    // accumulator registers are free and eight tiles (with their rotation entries) travel per dependent round trip.
     {
-        constexpr int FIN = 4;
+        constexpr int FIN = 8;
         int* lastlist = kbb;   // (the key blocks' ranges are no longer needed) compact list of those slices, in visiting order
         int n_last = 0;
         for (int i = tid; i < n_sl; i += FB_NW * 64)
@@ -776,6 +786,17 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
                 }
         }
     }
+#ifdef OBTE_DEBUG_HOOKS
+    if (p.dbg_times && tid == 0) {
+        unsigned long long t_exit;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_exit) :: "memory");
+        if (p.dbg_skip == 2) tsum[6] += t_a - t_loop_end;
+        else if (p.dbg_skip == 3) tsum[6] += t_b - t_loop_end;
+        else if (p.dbg_skip != 1) tsum[6] += t_exit - t_loop_end;
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) p.dbg_times[(size_t)blockIdx.x * 8 + k2] = tsum[k2];
+    }
+#endif
 }
 
 template __global__ void attn_bwd_fused_kernel<128, MASK_NONE>(FusedParams);
@@ -803,7 +824,9 @@ static void ws_layout(int64_t B, int64_t T, int H, int64_t& nkb, int64_t& nsl, i
 int64_t fused_bwd_ws_bytes(int64_t B, int64_t T, int H) {
     int64_t nkb, nsl, a, b2, c, total;
     ws_layout(B, T, H, nkb, nsl, a, b2, c, total);
-    return (nsl <= FusedShape<128>::TAB && nkb <= 120) ? total : (int64_t)1 << 62;   // longer sequences: the two-kernel form
+    // longer sequences: the two-kernel form.  (256 slices = T <= 8192: the list of the slices a workgroup finishes is kept in the
+    //  1 KiB of LDS the key blocks' ranges occupied, one int per slice, and a mask can make one key block finish all of its slices)
+    return (nsl <= 256 && nsl <= FusedShape<128>::TAB && nkb <= 120) ? total : (int64_t)1 << 62;
 }
 
 // mode: MASK_NONE or MASK_RANGES.  ws: fused_bwd_ws_bytes() bytes.
@@ -847,7 +870,7 @@ int launch_bwd_fused(const AttnParams& p, int mode, void* ws, hipStream_t st) {
         if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hbuf.data(), p.dbg_times, hbuf.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
             double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int i = 0; i < n; ++i) for (int k = 0; k < 8; ++k) sum[k] += (double)hbuf[(size_t)i * 8 + k];
-            const char* names[8] = {"A0", "D+SM0", "A1", "C0+SM1", "C1", "wait+barrier+signal", "-", "top (tile request, first reads)"};
+            const char* names[8] = {"A0", "D+SM0", "A1", "C0+SM1", "C1", "wait+barrier+signal", "OUTSIDE the loop (prologue + last slice + rows out + finishing; per slice share)", "top (tile request, first reads)"};
             double tot = 0; for (int k = 0; k < 8; ++k) tot += sum[k];
             fprintf(stderr, "[attn fused phases, cycles per slice per workgroup (%d slices)]", fp.nsl);
             for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.0f (%.0f%%)", names[k], sum[k] / n / fp.nsl, 100.0 * sum[k] / tot);
