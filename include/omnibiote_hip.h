@@ -182,6 +182,10 @@ typedef struct {
     int64_t B, T; int32_t n_head, head_dim; float scale;
     float dropout_p; uint64_t dropout_seed;     /* attention-probability dropout (site 1); p = 0 disables */
     const int32_t* ranges_exact;                /* nullable; with mask + key_ranges: the device flag obte_mask_bounds wrote */
+    /* nullable, dropout only (head_dim 128, key ranges or no mask): uint32 [B*H][ceil(T/32)][T] (obte_attn_drop_bits_bytes) — the
+     * keep decisions the forward takes, written once in key-major order: bit i of word (b*H+h, t, key) = keep(query 32 t + i, key).
+     * Handed to obte_attn_bwd, its key-major kernel reads one word per key and 32 queries instead of hashing per element. */
+    uint32_t* drop_bits;
 } obte_attn_fwd_args;
 int obte_attn_fwd(const obte_attn_fwd_args* a, obte_stream s);
 
@@ -202,8 +206,10 @@ typedef struct {
      * dQ + dK/dV kernel pair): per-key-block fp32 contributions to dQ land in the scratch and are summed in key-block order
      * (no atomics: bitwise reproducible).  NULL / too small: the two-kernel form. */
     void* ws; int64_t ws_bytes;
+    const uint32_t* drop_bits;                  /* nullable: what the forward call wrote (obte_attn_fwd_args::drop_bits), same p and seed */
 } obte_attn_bwd_args;
 int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s);
+int64_t obte_attn_drop_bits_bytes(int64_t B, int64_t T, int32_t n_head);
 int64_t obte_attn_bwd_ws_bytes(int64_t B, int64_t T, int32_t n_head, int32_t head_dim);
 /* A/B switch (process-wide, measurement only): 0 = automatic (the one-kernel form wherever it applies), 1 = always the
  * two-kernel form.  Returns the previous value.  The environment variable OBTE_ATTN_BWD=two sets 1 at load time. */

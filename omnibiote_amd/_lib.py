@@ -30,7 +30,7 @@ class AttnFwdArgs(C.Structure):
                 ("key_ranges", C.c_void_p), ("mask", C.c_void_p),
                 ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
                 ("B", C.c_int64), ("T", C.c_int64), ("n_head", C.c_int32), ("head_dim", C.c_int32), ("scale", C.c_float),
-                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("ranges_exact", C.c_void_p)]
+                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("ranges_exact", C.c_void_p), ("drop_bits", C.c_void_p)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -40,7 +40,7 @@ class AttnBwdArgs(C.Structure):
                 ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_sq", C.c_int64),
                 ("B", C.c_int64), ("T", C.c_int64), ("n_head", C.c_int32), ("head_dim", C.c_int32), ("scale", C.c_float),
                 ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64), ("query_bounds", C.c_void_p), ("ranges_exact", C.c_void_p),
-                ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
+                ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("drop_bits", C.c_void_p)]
 
 
 class BlockDesc(C.Structure):
@@ -95,6 +95,7 @@ SYMBOLS = {
     "obte_mask_bounds": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
     "obte_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), c_stream]),
+    "obte_attn_drop_bits_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32]),
     "obte_attn_bwd_ws_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "obte_attn_bwd_select": (C.c_int, [C.c_int]),
     "obte_embedding_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int64, c_stream]),

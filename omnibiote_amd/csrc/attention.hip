@@ -192,7 +192,13 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem) {
         }
         float rs = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt) {
+            // dropout, optional second output: the keep decisions of this wave's 32 queries for the 32 keys of this half tile, as one
+            // word per KEY (bit = query): the compare's own lane mask is that word — lanes 0..31 hold key 8i + j, lanes 32..63 key
+            // 8i + j + 4 — and v_writelane gathers the 32 words into lanes 0..31 for one 128-byte store.  The key-major backward
+            // kernel then reads one word per key and slice instead of hashing every (query, key) pair again.
+            uint32_t keyword = 0u;
+            unsigned long long km[16];   // the sixteen compares' lane masks of this half tile (SGPR pairs)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 // registers 4i .. 4i+3 hold four consecutive keys (a multiple of 4 onwards): two pairs, one hash each
@@ -207,10 +213,42 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem) {
                     const int r = 4 * i + j;
                     float pv = fast_exp2(__builtin_fmaf(sc[mt][r], sx, -m_safe));
                     rs += pv;   // the normaliser uses the un-dropped probabilities
-                    if (DROP) pv = drop_keep_bits(bits[j >> 1], (uint32_t)(j & 1), p.drop) ? pv * p.drop.scale : 0.f;
+                    if (DROP) {
+                        const bool kp = drop_keep_bits(bits[j >> 1], (uint32_t)(j & 1), p.drop);
+                        pv = kp ? pv * p.drop.scale : 0.f;
+                        km[r] = __ballot(kp);
+                    }
                     sc[mt][r] = pv;
                 }
             }
+            if (DROP && p.drop_bits_out) {
+                // lane 8i + j of `keyword` <- low word of mask (i, j), lane 8i + j + 4 <- its high word: two asm blocks of 16
+                // v_writelane (this hipcc has no writelane builtin).  s_nop 3 in front: a v_writelane that reads an SGPR a
+                // vector compare has just written needs four wait states, and the hazard recogniser does not look into asm —
+                // without it the low word was the PREVIOUS compare's mask.
+#define OBTE_WL(M, L) "v_writelane_b32 %0, %" #M ", " #L "\n\t"
+                asm volatile("s_nop 3\n\t" OBTE_WL(1, 0) OBTE_WL(2, 4) OBTE_WL(3, 1) OBTE_WL(4, 5) OBTE_WL(5, 2) OBTE_WL(6, 6) OBTE_WL(7, 3) OBTE_WL(8, 7)
+                             OBTE_WL(9, 8) OBTE_WL(10, 12) OBTE_WL(11, 9) OBTE_WL(12, 13) OBTE_WL(13, 10) OBTE_WL(14, 14) OBTE_WL(15, 11) OBTE_WL(16, 15)
+                             : "+v"(keyword)
+                             : "s"((uint32_t)km[0]), "s"((uint32_t)(km[0] >> 32)), "s"((uint32_t)km[1]), "s"((uint32_t)(km[1] >> 32)),
+                               "s"((uint32_t)km[2]), "s"((uint32_t)(km[2] >> 32)), "s"((uint32_t)km[3]), "s"((uint32_t)(km[3] >> 32)),
+                               "s"((uint32_t)km[4]), "s"((uint32_t)(km[4] >> 32)), "s"((uint32_t)km[5]), "s"((uint32_t)(km[5] >> 32)),
+                               "s"((uint32_t)km[6]), "s"((uint32_t)(km[6] >> 32)), "s"((uint32_t)km[7]), "s"((uint32_t)(km[7] >> 32)));
+                asm volatile("s_nop 3\n\t" OBTE_WL(1, 16) OBTE_WL(2, 20) OBTE_WL(3, 17) OBTE_WL(4, 21) OBTE_WL(5, 18) OBTE_WL(6, 22) OBTE_WL(7, 19) OBTE_WL(8, 23)
+                             OBTE_WL(9, 24) OBTE_WL(10, 28) OBTE_WL(11, 25) OBTE_WL(12, 29) OBTE_WL(13, 26) OBTE_WL(14, 30) OBTE_WL(15, 27) OBTE_WL(16, 31)
+                             : "+v"(keyword)
+                             : "s"((uint32_t)km[8]), "s"((uint32_t)(km[8] >> 32)), "s"((uint32_t)km[9]), "s"((uint32_t)(km[9] >> 32)),
+                               "s"((uint32_t)km[10]), "s"((uint32_t)(km[10] >> 32)), "s"((uint32_t)km[11]), "s"((uint32_t)(km[11] >> 32)),
+                               "s"((uint32_t)km[12]), "s"((uint32_t)(km[12] >> 32)), "s"((uint32_t)km[13]), "s"((uint32_t)(km[13] >> 32)),
+                               "s"((uint32_t)km[14]), "s"((uint32_t)(km[14] >> 32)), "s"((uint32_t)km[15]), "s"((uint32_t)(km[15] >> 32)));
+#undef OBTE_WL
+            }
+            if (DROP && p.drop_bits_out && lane < 32 && q_row - (lane & 31) < T) {
+                const int key = key0 + 32 * mt + lane;
+                const int64_t nsl = ((int64_t)T + 31) / 32;
+                if (key < T) p.drop_bits_out[(((int64_t)b * p.H + hd) * nsl + (q_row >> 5)) * T + key] = keyword;
+            }
+        }
         l += rs;
         // O^T += V^T P^T : P^T accumulators are the B operand as they stand.  The V fragments of key step kk+1 are requested
         // before the MFMAs of step kk (two register sets, order pinned).
@@ -464,7 +502,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
 // waits (320 KiB of LDS reads per step per CU, 40 KiB per wave), not by the vector pipe, and de-phasing the halves puts both
 // LDS-heavy phases (A: 24 x b128, C: 32 x tr_b64) side by side.  Also measured and dropped: 64-row Q/dO stages (two MFMA tiles
 // per barrier, half the barriers): 86.9 vs 87.0 us, 314.7 vs 312.5 at T = 4096 — the barrier count is not what parks the waves.
-template <int D, int MODE, bool DROP>
+template <int D, int MODE, bool DROP, bool BITS = false>   // BITS: dropout decisions from the forward's keep bits (p.drop_bits_in), no hash
 __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* smem) {
     constexpr int NW = FwdShape<DROP>::NW;
     constexpr int QB = 32 * 2 * D;  // bytes of one 32-row tile
@@ -576,12 +614,18 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
     __syncthreads();
     OBTE_STAMP(p, 1);
 
+    // dropout with the forward's keep bits (one word per key and 32-query slice): this lane's word of the current slice, the next
+    // one requested a slice ahead and taken over beside the end-of-iteration wait (like the row constants)
+    const uint32_t* keyw_src = (DROP && BITS) ? p.drop_bits_in + ((b * p.H + hd) * (((int64_t)T + 31) / 32)) * T + key_c : nullptr;
+    uint32_t keyw = 0u, keyw_next = 0u;
+    if (keyw_src && t_begin < t_end) keyw = keyw_src[(int64_t)t_begin * T];
     for (int t = t_begin; t < t_end; ++t) {
         const int cur = (t - t_begin) & 1;
         const bool more = t + 1 < t_end;
         if (more) {
             issue_qd(t + 1, smem + (cur ^ 1) * STAGE);
             load_stats((t + 1) * 32);
+            if (keyw_src) keyw_next = keyw_src[(int64_t)(t + 1) * T];
         }
         const char* Qt = smem + cur * STAGE;
         const char* Dt = Qt + QB;
@@ -612,12 +656,15 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
                 uint32_t pairw[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
                 const uint32_t pair_g = (uint32_t)key_c >> 1;
                 const int odd_lane = lane & 1;
+                // (the forward's keep bits, if it left them: one word per key and slice, bit = query — no hash at all)
+                constexpr bool have_bits = DROP && BITS;
+                const uint32_t kw = have_bits ? (keyw >> (4 * h)) : 0u;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const f32x4 l4 = *reinterpret_cast<const f32x4*>(stats + 8 * i + 4 * h);
                     const f32x4 d4 = *reinterpret_cast<const f32x4*>(stats + 32 + 8 * i + 4 * h);
                     uint32_t w4[4] = {0u, 0u, 0u, 0u};
-                    if (DROP) {
+                    if (DROP && !have_bits) {
                         if (i < 2) {   // this lane's share: group i (even lane) or i + 2 (odd lane)
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
@@ -638,7 +685,7 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
                         if (decltype(checked)::value && (q < qs || q >= qe)) pv = 0.f;
                         float pd = pv, dpd = dp[r];
                         if (DROP) {   // (row key of query q from the stage's table, this lane's key as the column)
-                            const bool kp = drop_keep_bits(w4[j], (uint32_t)key_c, p.drop);
+                            const bool kp = have_bits ? ((kw >> (8 * i + j)) & 1u) != 0u : drop_keep_bits(w4[j], (uint32_t)key_c, p.drop);
                             pd = kp ? pv * p.drop.scale : 0.f;
                             dpd = kp ? dpd * p.drop.scale : 0.f;
                         }
@@ -669,6 +716,7 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
 #endif
         if (more) store_stats(smem + (cur ^ 1) * STAGE);
         if (!p.no_wait) dma_wait_all();
+        if (DROP && BITS) { asm volatile("" : "+v"(keyw_next)); keyw = keyw_next; }   // (its load is waited for HERE, not behind the next slice's requests)
 #ifdef OBTE_DEBUG_HOOKS
         if (!(p.dbg_skip & 8))
 #endif
@@ -733,6 +781,14 @@ OBTE_ATTN_KERNEL(attn_fwd)
 OBTE_ATTN_KERNEL(attn_bwd_dq)
 OBTE_ATTN_KERNEL(attn_bwd_dkdv)
 #undef OBTE_ATTN_KERNEL
+// dropout with the forward's keep bits (head size 128, key ranges or no mask)
+template <int MODE>
+__global__ __launch_bounds__(FwdShape<true>::NW * 64, 1) void attn_bwd_dkdv_bits_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_bwd_dkdv_body<128, MODE, true, true>(p, smem);
+}
+template __global__ void attn_bwd_dkdv_bits_kernel<MASK_NONE>(AttnParams);
+template __global__ void attn_bwd_dkdv_bits_kernel<MASK_RANGES>(AttnParams);
 
 // Explicit instantiations (implicit instantiation alone left some host stubs undefined with hipcc / ROCm 7.2).
 #define OBTE_INST_ATTN(D, M)                                                       \
@@ -845,6 +901,15 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
         const int smem = 2 * (2 * 32 * 2 * D + 384) + 32 * FwdShape<false>::NW * 2 * D + 64;   // >= the dropout variant's
         const dim3 grid_d((unsigned)(cdiv64(p.T, 32 * FwdShape<true>::NW) * p.H * p.B)), block_d(64 * FwdShape<true>::NW);
         const dim3 grid((unsigned)(cdiv64(p.T, 32 * FwdShape<false>::NW) * p.H * p.B)), block(64 * FwdShape<false>::NW);
+        if (p.drop.thresh16 && p.drop_bits_in && D == 128 && mode != MASK_DENSE) {
+            if (mode == MASK_NONE) {
+                set_smem(attn_bwd_dkdv_bits_kernel<MASK_NONE>, smem);
+                hipLaunchKernelGGL((attn_bwd_dkdv_bits_kernel<MASK_NONE>), grid_d, block_d, smem, st, p);
+            } else {
+                set_smem(attn_bwd_dkdv_bits_kernel<MASK_RANGES>, smem);
+                hipLaunchKernelGGL((attn_bwd_dkdv_bits_kernel<MASK_RANGES>), grid_d, block_d, smem, st, p);
+            }
+        } else {
 #define GO(M)                                                                                      \
     do {                                                                                           \
         if (p.drop.thresh16) {                                                                     \
@@ -857,6 +922,7 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
     } while (0)
         if (mode == MASK_NONE) GO(MASK_NONE); else if (mode == MASK_RANGES) GO(MASK_RANGES); else GO(MASK_DENSE);
 #undef GO
+        }
         OBTE_CHECK_LAUNCH("obte_attn_bwd(dkdv)");
 #ifdef OBTE_DEBUG_HOOKS
         if (p.dbg_times) debug_report_times("dkdv", p.dbg_times, (int)(p.drop.thresh16 ? grid_d.x : grid.x), st);
@@ -978,6 +1044,10 @@ int launch_bwd_gated(AttnParams p, const int32_t* flag, hipStream_t st) {
     return OBTE_OK;
 }
 
+extern "C" int64_t obte_attn_drop_bits_bytes(int64_t B, int64_t T, int32_t n_head) {
+    return B * n_head * ((T + 31) / 32) * T * 4;
+}
+
 extern "C" int obte_attn_fwd(const obte_attn_fwd_args* a, obte_stream s) {
     OBTE_REQUIRE(a, "obte_attn_fwd: null args");
     int rc = check_common("obte_attn_fwd", a->qkv, a->B, a->T, a->n_head, a->head_dim, a->key_ranges, a->mask);
@@ -991,6 +1061,7 @@ extern "C" int obte_attn_fwd(const obte_attn_fwd_args* a, obte_stream s) {
     p.drop = make_drop(a->dropout_p, a->dropout_seed, OBTE_SITE_ATTN);
     p.max_tiles = debug_max_tiles(); p.no_wait = debug_no_wait();
     const int mode = mask_mode(a->key_ranges, a->mask);
+    p.drop_bits_out = (p.drop.thresh16 != 0 && a->head_dim == 128 && mode != MASK_DENSE) ? a->drop_bits : nullptr;
     const int prof = obte_prof_begin((hipStream_t)s, 100, a->B * a->n_head, a->T, a->head_dim);
     if (mode == MASK_DENSE && a->key_ranges && a->ranges_exact)
         rc = a->head_dim == 128 ? launch_fwd_gated<128>(p, a->ranges_exact, (hipStream_t)s) : launch_fwd_gated<64>(p, a->ranges_exact, (hipStream_t)s);
@@ -1028,6 +1099,7 @@ extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
     p.max_tiles = debug_max_tiles(); p.no_wait = debug_no_wait(); p.dbg_skip = debug_skip();
     p.dbg_times = debug_times_buffer(a->B * a->n_head * ((a->T + 127) / 128));
     const int mode = mask_mode(a->key_ranges, a->mask);
+    p.drop_bits_in = (p.drop.thresh16 != 0 && a->head_dim == 128 && mode != MASK_DENSE) ? a->drop_bits : nullptr;
     const int prof = obte_prof_begin((hipStream_t)s, 101, a->B * a->n_head, a->T, a->head_dim);
     if (mode != MASK_DENSE && a->head_dim == 128 && p.drop.thresh16 == 0 && a->ws && attn_bwd_mode() == 0 &&
         a->ws_bytes >= fused_bwd_ws_bytes(a->B, a->T, a->n_head) && a->T * 3 * a->n_head * 128 * 2 < (1ll << 31)) {   // (its per-lane byte offsets are 32-bit)

@@ -11,7 +11,7 @@ namespace {
 inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 struct ActLayout {
-    int64_t mean1, rstd1, h1, qkv, lse, y, x1, mean2, rstd2, h2, hpre, hact, x1r, total;
+    int64_t mean1, rstd1, h1, qkv, lse, y, x1, mean2, rstd2, h2, hpre, hact, x1r, dropbits, total;
     ActLayout(int64_t B, int64_t T, int C, int H) {
         const int64_t M = B * T;
         int64_t o = 0;
@@ -27,6 +27,7 @@ struct ActLayout {
         hpre = take(M * 4 * C * 2);
         hact = take(M * 4 * C * 2);
         x1r = take(M * C * 2);      // rows form (obte_block_desc::out_rows): x1 at the wanted positions
+        dropbits = take(obte_attn_drop_bits_bytes(B, T, H));   // attention dropout: the forward's keep bits for the backward (touched only with dropout on)
         total = o;
     }
 };
@@ -139,6 +140,7 @@ extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte
     af.mask_sb = d->mask_sb; af.mask_sh = d->mask_sh; af.mask_sq = d->mask_sq;
     af.B = d->B; af.T = d->T; af.n_head = H; af.head_dim = hs; af.scale = 8.0f / (float)C;  // model.py:119
     af.dropout_p = d->dropout_p; af.dropout_seed = d->dropout_seed;
+    af.drop_bits = d->dropout_p > 0.f ? (uint32_t*)(A + L.dropbits) : nullptr;
     af.ranges_exact = d->ranges_exact;
     TRY(obte_attn_fwd(&af, s));
     TRY(gemm(yat, d->proj_w, x1, M, C, C, C, C, 1, 1, OBTE_EPI_ADD, x, nullptr, s, nullptr, 0, d->dropout_p, d->dropout_seed, SITE_RESID));
@@ -269,6 +271,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     ab.ranges_exact = d->ranges_exact;
     ab.B = d->B; ab.T = d->T; ab.n_head = H; ab.head_dim = hs; ab.scale = 8.0f / (float)C;
     ab.dropout_p = d->dropout_p; ab.dropout_seed = d->dropout_seed;
+    ab.drop_bits = d->dropout_p > 0.f ? (const uint32_t*)(A + L.dropbits) : nullptr;
     if (W.attnws_bytes > 0) { ab.ws = (void*)(S + W.attnws); ab.ws_bytes = W.attnws_bytes; }
     TRY(obte_attn_bwd(&ab, s));
     // OBTE_GROUPED_DGRAD=0 keeps dh1 = dqkv W_attn as its own launch (A/B timing)

@@ -297,19 +297,24 @@ class MaskSpec:
         return MaskSpec.dense_with_bounds(m)
 
 
-def attn_fwd(qkv, B, T, H, hs, scale, mask: Optional[MaskSpec] = None, dropout_p=0.0, dropout_seed=0):
+def attn_fwd(qkv, B, T, H, hs, scale, mask: Optional[MaskSpec] = None, dropout_p=0.0, dropout_seed=0, keep_bits=False):
+    """keep_bits (dropout only): also return the forward's keep decisions in key-major order (include/omnibiote_hip.h,
+    obte_attn_fwd_args::drop_bits) for attn_bwd(drop_bits=...): (o, lse, bits)."""
     _need(qkv, "qkv"); assert qkv.numel() == B * T * 3 * H * hs
     mask = mask or MaskSpec()
     o = torch.empty((B, T, H * hs), dtype=bf16, device=qkv.device)
     lse = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
+    bits = None
+    if keep_bits and dropout_p > 0.0:   # (zeroed: words of key tiles the forward skips stay defined; they belong to masked pairs)
+        bits = torch.zeros(int(L.lib().obte_attn_drop_bits_bytes(B, T, H)) // 4, dtype=torch.int32, device=qkv.device)
     a = L.AttnFwdArgs(_ptr(qkv), _ptr(o), _ptr(lse), _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq,
-                      B, T, H, hs, float(scale), float(dropout_p), int(dropout_seed), _ptr(mask.exact))
+                      B, T, H, hs, float(scale), float(dropout_p), int(dropout_seed), _ptr(mask.exact), _ptr(bits))
     L.check(L.lib().obte_attn_fwd(C.byref(a), _stream()), "obte_attn_fwd")
-    return o, lse
+    return (o, lse, bits) if keep_bits else (o, lse)
 
 
 def attn_bwd(qkv, o, d_o, lse, B, T, H, hs, scale, mask: Optional[MaskSpec] = None, rope=None, dropout_p=0.0, dropout_seed=0,
-             one_kernel: bool = True):
+             one_kernel: bool = True, drop_bits=None):
     """one_kernel: hand the library the scratch that lets it run the one-kernel backward where that form applies (head size
     128, no dense mask, no dropout: include/omnibiote_hip.h, obte_attn_bwd_args::ws); False: the dQ + dK/dV kernel pair."""
     _need(qkv, "qkv"); _need(o, "o"); _need(d_o, "d_o"); _need(lse, "lse", torch.float32)
@@ -321,7 +326,7 @@ def attn_bwd(qkv, o, d_o, lse, B, T, H, hs, scale, mask: Optional[MaskSpec] = No
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device) if ws_bytes > 0 else None
     a = L.AttnBwdArgs(_ptr(qkv), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(delta), _ptr(dqkv), _ptr(cos), _ptr(sin),
                       _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq, B, T, H, hs, float(scale),
-                      float(dropout_p), int(dropout_seed), _ptr(mask.qbounds), _ptr(mask.exact), _ptr(ws), ws_bytes)
+                      float(dropout_p), int(dropout_seed), _ptr(mask.qbounds), _ptr(mask.exact), _ptr(ws), ws_bytes, _ptr(drop_bits))
     L.check(L.lib().obte_attn_bwd(C.byref(a), _stream()), "obte_attn_bwd")
     return dqkv
 

@@ -304,6 +304,44 @@ def test_attention_backward_one_kernel_form(T, mode):
     close(one_r, two_r.float().cpu(), atol=4e-3, rtol=2.0 ** -7, what="one-kernel vs kernel pair, inverse RoPE")
 
 
+@pytest.mark.parametrize("T,mode", [(600, "ranges"), (333, "none"), (1024, "ranges")])
+def test_attention_dropout_keep_bits_from_the_forward(T, mode):
+    """With dropout on, the forward can leave its keep decisions behind in key-major order (one word per key and 32-query
+    slice); the key-major backward kernel then reads them instead of hashing every (query, key) pair again.  Same decisions,
+    same arithmetic: the backward with the bits equals the backward that hashes bit for bit, and the forward's outputs do not
+    depend on whether the bits are written."""
+    B, H, hs, p, seed = 2, 3, 128, 0.1, 0x5EED
+    C = H * hs
+    scale = 8.0 / C
+    qkv, _, _, _ = _attn_case(B, T, H, hs, seed=T + 1)
+    tokens = np.random.default_rng(T).integers(20, 100, size=(B, T))
+    tokens[0, [T // 5, T // 2]] = R.EOS_TOKEN
+    tokens[1, [7, T - 9]] = R.EOS_TOKEN
+    _, ranges = _blocks_to_masks(tokens, T)
+    o = ops()
+    spec = o.MaskSpec(ranges=ranges.to(DEV)) if mode == "ranges" else None
+    d_o = rnd(B, T, C, seed=6).to(DEV)
+    qd = qkv.to(DEV)
+    out0, lse0 = o.attn_fwd(qd, B, T, H, hs, scale, spec, dropout_p=p, dropout_seed=seed)
+    out1, lse1, bits = o.attn_fwd(qd, B, T, H, hs, scale, spec, dropout_p=p, dropout_seed=seed, keep_bits=True)
+    assert torch.equal(out0, out1) and torch.equal(lse0, lse1) and bits is not None
+    hashed = o.attn_bwd(qd, out0, d_o, lse0, B, T, H, hs, scale, spec, dropout_p=p, dropout_seed=seed)
+    from_bits = o.attn_bwd(qd, out0, d_o, lse0, B, T, H, hs, scale, spec, dropout_p=p, dropout_seed=seed, drop_bits=bits)
+    assert torch.equal(hashed, from_bits)
+    # the bits are the oracle's mask: word (b*H + h, t, key) bit i = keep(row (b, h, 32 t + i), key)
+    nsl = (T + 31) // 32
+    w = bits.reshape(B * H, nsl, T).cpu().numpy().astype(np.uint32)
+    rows = (np.arange(B * H, dtype=np.uint64)[:, None] * np.uint64(T) + np.arange(T, dtype=np.uint64)[None, :]).reshape(-1)
+    keep = R.dropout_keep(rows[:, None], np.arange(T, dtype=np.uint64)[None, :], p, seed, 1).reshape(B * H, T, T)   # [bh, q, key]
+    got = ((w[:, np.arange(T) // 32, :] >> (np.arange(T) % 32).astype(np.uint32)[None, :, None]) & 1).astype(bool)  # [bh, q, key]
+    lo, hi = ranges.numpy()[..., 0], ranges.numpy()[..., 1]
+    for b in range(B):
+        for q in range(0, T, 37):
+            ks, ke = (int(lo[b, q]), int(hi[b, q])) if mode == "ranges" else (0, T)
+            for hh in range(H):
+                assert np.array_equal(got[b * H + hh, q, ks:ke], keep[b * H + hh, q, ks:ke]), (b, hh, q)
+
+
 def test_attention_backward_one_kernel_beside_another_stream():
     """The one-kernel backward at the benchmark's shape (B = 8, H = 8, T = 1024, multi-document rows) repeated while a second
     stream keeps the memory system busy with GEMMs: every repeat equals the quiet result bit for bit.  (Round 4: the loop's

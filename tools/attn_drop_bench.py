@@ -23,3 +23,8 @@ for pp in (0.0, p):
     tf = timeit(lambda: ops.attn_fwd(qkv, B, T, H, hs, scale, spec, pp, 1234))
     tb = timeit(lambda: ops.attn_bwd(qkv, o, d_o, lse, B, T, H, hs, scale, spec, dropout_p=pp, dropout_seed=1234))
     print(f"dropout {pp:g}: attn fwd {tf:7.1f} us | bwd {tb:7.1f} us", flush=True)
+    if pp > 0:   # the forward leaving its keep bits for the key-major backward kernel
+        o2, lse2, bits = ops.attn_fwd(qkv, B, T, H, hs, scale, spec, pp, 1234, keep_bits=True)
+        tf2 = timeit(lambda: ops.attn_fwd(qkv, B, T, H, hs, scale, spec, pp, 1234, keep_bits=True))
+        tb2 = timeit(lambda: ops.attn_bwd(qkv, o, d_o, lse, B, T, H, hs, scale, spec, dropout_p=pp, dropout_seed=1234, drop_bits=bits))
+        print(f"dropout {pp:g} with keep bits: attn fwd {tf2:7.1f} us | bwd {tb2:7.1f} us", flush=True)
