@@ -258,6 +258,53 @@ def test_tuner_ranking_breaks_ties_towards_the_deeper_ring_and_lists_the_masked_
         (1024, 4096, 1232, False, False), (4096, 1024, 1232, False, False)])                                         # the last block's MLP half
 
 
+def test_tuner_lists_the_192_wide_and_the_persistent_structure_only_where_they_apply():
+    """tune.candidates: the 256 x 192 tile (structure 2) for x W^T products whose N is a multiple of 192 and whose epilogue it
+    implements; the persistent structure 5 for whole 256 x 128 tiles of k-contiguous operands, >= 2 tiles per workgroup, K >= 640."""
+    from omnibiote_amd import tune
+    L = _lib
+    c = tune.candidates(8192, 3072, 1024, L.EPI_ROPE_QK, True, True)
+    assert (2, 192, 1) in c and (5, 128, 1) not in c                      # RoPE epilogue: no persistent form
+    c = tune.candidates(8192, 3072, 1024, L.EPI_NONE, True, True)
+    assert (2, 192, 1) in c and (5, 128, 1) in c
+    assert (2, 192, 1) not in tune.candidates(8192, 3072, 1024, L.EPI_NONE, True, False)       # x W layouts only
+    assert (2, 192, 1) not in tune.candidates(8192, 3072, 1024, L.EPI_GELU_BWD, True, True)
+    assert (2, 192, 1) not in tune.candidates(8192, 4096, 1024, L.EPI_GELU, True, True)        # 4096 is not a multiple of 192
+    assert (5, 128, 1) in tune.candidates(8192, 4096, 1024, L.EPI_GELU, True, True)
+    assert (5, 128, 1) not in tune.candidates(8192, 1024, 1024, L.EPI_ADD, True, True)         # 256 tiles: one per workgroup
+    assert (5, 128, 1) in tune.candidates(32768, 1024, 1024, L.EPI_ADD, True, True)
+    assert (5, 128, 1) not in tune.candidates(8192, 4096, 576, L.EPI_NONE, True, True)         # nine K-tiles: too short
+    assert (5, 128, 1) not in tune.candidates(8200, 4096, 1024, L.EPI_NONE, True, True)        # ragged rows
+
+
+def test_masked_gradient_handoff_table_checks_storage_shape_probability_and_seed(monkeypatch):
+    """model._masked_grad_put / _take (dropout: a block's dx under the mask of the block below): the entry is taken only by the
+    gradient tensor it was stored for, with the taker's own probability and seed; anything else gets None (and the block masks
+    its own gradient); the switch OBTE_DROPOUT_HANDOFF=0 turns the hand-off off; the table stays small."""
+    from omnibiote_amd import model as M
+    M._masked_grad.clear()
+    dx, dxm = torch.zeros(4, 8), torch.ones(4, 8)
+    M._masked_grad_put(dx, dxm, 0.1, 77)
+    assert M._masked_grad_take(torch.zeros(4, 8), (0.1, 77)) is None        # another tensor
+    assert M._masked_grad_take(dx, (0.1, 78)) is None                       # (taken out by the mismatch: the block masks dy itself)
+    M._masked_grad_put(dx, dxm, 0.1, 77)
+    assert M._masked_grad_take(dx, (0.2, 77)) is None
+    M._masked_grad_put(dx, dxm, 0.1, 77)
+    assert M._masked_grad_take(dx.view(8, 4), (0.1, 77)) is None            # same storage, another shape
+    M._masked_grad_put(dx, dxm, 0.1, 77)
+    assert M._masked_grad_take(dx, (0.1, 77)) is dxm and M._masked_grad_take(dx, (0.1, 77)) is None   # consumed once
+    M._masked_grad_put(dx, None, 0.1, 77)
+    assert not M._masked_grad
+    keep = [torch.zeros(2, 2) for _ in range(20)]
+    for t in keep:
+        M._masked_grad_put(t, torch.ones(2, 2), 0.1, 1)
+    assert len(M._masked_grad) <= 8
+    monkeypatch.setenv("OBTE_DROPOUT_HANDOFF", "0")
+    M._masked_grad_put(dx, dxm, 0.1, 77)
+    assert M._masked_grad_take(dx, (0.1, 77)) is None
+    M._masked_grad.clear()
+
+
 def test_forward_rows_contract_is_checked_on_the_host():
     """OmniBioTA.forward(rows=) / Block.forward(out_rows=): shape, dtype, device and count of the list are refused on the host
     before anything is launched (the values — ascending, distinct, in range — are the caller's contract, verified only under
