@@ -128,6 +128,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
                                               int64_t m0, int64_t n0, int wm, int wn, int split, int tile_n = BN) {
     constexpr int NJ = BN / 32, NW = BN / 2;
     __syncthreads();  // all fragment reads done (and no DMA outstanding): LDS becomes the epilogue staging area
+    OBTE_GSTAMP(p, 5);
 
     const int em = lane & 15, en = (lane >> 4) * 4;
     if (SPLIT) {
@@ -170,12 +171,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
     for (int ni = 0; ni < NJ; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            bf16x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = f2bf(acc[ni][mi][r] * p.alpha);
-            *reinterpret_cast<bf16x4*>(stg + (mi * 16 + em) * LDE + (ni * 16 + en) * 2) = v;
-        }
+        for (int mi = 0; mi < 4; ++mi)   // (as one vector conversion: two v_pk_mul + two v_cvt_pk per quad; element by element hipcc emitted ten instructions)
+            *reinterpret_cast<bf16x4*>(stg + (mi * 16 + em) * LDE + (ni * 16 + en) * 2) = __builtin_convertvector(acc[ni][mi] * p.alpha, bf16x4);
     // Interior tiles whose epilogue READS global memory (residual / gradient accumulation, GELU', dropout + residual, RoPE
     // tables) take a branch-free path that issues every one of those loads BEFORE the first store.  In the guarded loop below
     // each iteration is load -> s_waitcnt vmcnt(0) -> arithmetic -> store behind a bounds branch hipcc does not schedule
@@ -185,11 +182,21 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     const bool interior = m0 + BM <= p.store_rows && n0 + tile_n <= p.N && (EPI != OBTE_EPI_ADD || p.aux != nullptr);
     if (interior) {   // (the epilogues without loads take it too: no bounds branches, so the staged reads are issued ahead of the arithmetic)
         // output offset and column of chunk `it`: for a power-of-two CPRE the lane keeps its column and steps 64 / CPRE rows
+        // Addresses: ONE 64-bit tile origin per workgroup (scalar) and 32-bit element offsets inside the tile (< 256 rows x ldd) — the
+        // 64-bit per-chunk products this replaced were v_mad_u64_u32 / v_mul_lo_u32 at quarter rate, 66 of them per wave and tile
+        // (a CU stores a 128-KB tile in ~0.8 us when it does nothing else, tools/micro/store_path.hip; this epilogue takes 4.1 us,
+        // most of it latency chains between its phases — trimming its instructions did not change that: DESIGN 10.2)
         constexpr bool POW2 = (CPRE & (CPRE - 1)) == 0;
-        const int64_t n_l = n0 + wn * NW + (lane % CPRE) * 8;
-        const int64_t o_l = (m0 + wm * 64 + lane / CPRE) * p.ldd + n_l;
-        auto nn_of = [&](int it) { return POW2 ? n_l : n0 + wn * NW + chunk_c8(it) * 8; };
-        auto oo_of = [&](int it) { return POW2 ? o_l + (int64_t)it * (64 / CPRE) * p.ldd : (m0 + wm * 64 + chunk_row(it)) * p.ldd + nn_of(it); };
+        const int64_t tile_o = m0 * p.ldd + n0;
+        const uint32_t ldd32 = (uint32_t)p.ldd;
+        const uint32_t nc_l = (uint32_t)(wn * NW + (lane % CPRE) * 8);                 // column inside the tile
+        const uint32_t off_l = (uint32_t)(wm * 64 + lane / CPRE) * ldd32 + nc_l;
+        auto nn_of = [&](int it) { return n0 + (POW2 ? nc_l : (uint32_t)(wn * NW + chunk_c8(it) * 8)); };
+        auto oo_of = [&](int it) {
+            const uint32_t off = POW2 ? off_l + (uint32_t)(it * (64 / CPRE)) * ldd32
+                                      : (uint32_t)(wm * 64 + chunk_row(it)) * ldd32 + (uint32_t)(wn * NW + chunk_c8(it) * 8);
+            return tile_o + (int64_t)off;
+        };
         bf16x8 r[NIT];
         f32x4 rc[NIT], rs[NIT];
         if (EPI == OBTE_EPI_ROPE_QK) {
@@ -208,9 +215,19 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
             for (int it = 0; it < NIT; ++it) r[it] = *reinterpret_cast<const bf16x8*>(p.aux + oo_of(it));
         }
         __syncthreads();   // the staged tile is complete
+        OBTE_GSTAMP(p, 6);
+        // every staged chunk into registers first (the accumulators' registers are free now): the non-temporal store below is an asm
+        // statement with a memory clobber, and with the LDS read inside its loop hipcc kept each read behind the previous store —
+        // sixteen LDS round trips in a row per wave
+        bf16x8 staged[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) staged[it] = *reinterpret_cast<const bf16x8*>(stg + chunk_row(it) * LDE + chunk_c8(it) * 16);
+#ifdef OBTE_DEBUG_HOOKS
+        if (p.dbg_times) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); OBTE_GSTAMP(p, 7); }
+#endif
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + chunk_row(it) * LDE + chunk_c8(it) * 16);
+            bf16x8 v = staged[it];
             const int64_t o = oo_of(it);
             const int64_t n = nn_of(it);
             const bool rot = n < 2 * (p.N / 3);
@@ -446,9 +463,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
 }
 
 // ---- structure 5: the K-tile ring (256 x 128, three stages) as a PERSISTENT kernel whose stores leave under the next tile ----------
-// What bounds the epilogue of every structure above is the CU's own store path: a tile's output leaves at ~14-16 bytes per clock
-// per CU whether 32 or 256 workgroups store at the same time (round 4, tools/gemm_bench.py under OBTE_GEMM_TIMES with 32 / 64 /
-// 128 / 256 tiles in the grid: 4.1 us for a 128-KB tile, 7.7 us for the GELU pair, the memory system nearly idle) — and that path
+// The epilogue of every structure above is ~4 us of serial latency per tile with the matrix pipe idle (the slowest wave leaves
+// the loop, conversion + staging + barrier, read back, per-chunk addressing + stores; 7.5 us with the GELU arithmetic) — the same
+// with 32 or 256 workgroups in the grid, so neither the fabric nor the CU's store path (which moves a 128-KB tile in 0.75 us:
+// tools/micro/store_path.hip); DESIGN 10.2 — and nothing of it needs the matrix pipe, which
 // is idle during the main loop.  Here one workgroup per CU walks tiles q = blockIdx.x, + gridDim.x, ...; at the end of a tile the
 // accumulators go through the LDS staging as before, but the 16-byte output chunks come back into REGISTERS (8 per lane: the
 // 256 x 128 tile is what leaves room for them) and are stored one per K-step from inside the NEXT tile's main loop, where they
@@ -1606,18 +1624,19 @@ static void debug_gemm_report(const GemmParams& p, int variant, int epi, hipStre
     unsigned long long t0 = ~0ull, tend = 0;
     for (int i = 0; i < n; ++i) { if (h[(size_t)i * 8] && h[(size_t)i * 8] < t0) t0 = h[(size_t)i * 8]; if (h[(size_t)i * 8 + 4] > tend) tend = h[(size_t)i * 8 + 4]; }
     // workgroups of the first wave of residents (entered within 2 us of the first) and the rest (later rounds)
-    double seg[2][4] = {{0}}, entry[2] = {0, 0}, done[2] = {0, 0}; int cnt[2] = {0, 0};
+    double seg[2][4] = {{0}}, entry[2] = {0, 0}, done[2] = {0, 0}, ep1[2] = {0, 0}, ep2[2] = {0, 0}, ep3[2] = {0, 0}; int cnt[2] = {0, 0};
     for (int i = 0; i < n; ++i) {
         const unsigned long long* r = &h[(size_t)i * 8];
         if (!r[0]) continue;
         const int c = (r[0] - t0) > 200 ? 1 : 0;
         cnt[c]++; entry[c] += (double)(r[0] - t0); done[c] += (double)(r[4] - t0);
         for (int k = 0; k < 4; ++k) seg[c][k] += (double)(r[k + 1] - r[k]);
+        if (r[5] && r[6]) { ep1[c] += (double)(r[5] - r[2]); ep2[c] += (double)(r[6] - r[5]); ep3[c] += (double)(r[7] - r[6]); }   // epilogue: until every wave is out of the loop / staging written and published
     }
     fprintf(stderr, "[gemm v%d epi %d %lldx%lldx%lld, %d workgroups, us] span %.2f", variant, epi, (long long)p.M, (long long)p.N, (long long)p.K, n, (tend - t0) * 0.01);
     for (int c = 0; c < 2; ++c)
-        if (cnt[c]) fprintf(stderr, " | %s %d: entry +%.2f, prologue %.2f, loop %.2f, epilogue issue %.2f, drain %.2f, done +%.2f", c ? "later" : "first", cnt[c], entry[c] / cnt[c] * 0.01,
-                            seg[c][0] / cnt[c] * 0.01, seg[c][1] / cnt[c] * 0.01, seg[c][2] / cnt[c] * 0.01, seg[c][3] / cnt[c] * 0.01, done[c] / cnt[c] * 0.01);
+        if (cnt[c]) fprintf(stderr, " | %s %d: entry +%.2f, prologue %.2f, loop %.2f, epilogue issue %.2f (all waves out of the loop %.2f + staging %.2f + read back %.2f + arithmetic, stores), drain %.2f, done +%.2f", c ? "later" : "first", cnt[c], entry[c] / cnt[c] * 0.01,
+                            seg[c][0] / cnt[c] * 0.01, seg[c][1] / cnt[c] * 0.01, seg[c][2] / cnt[c] * 0.01, ep1[c] / cnt[c] * 0.01, ep2[c] / cnt[c] * 0.01, ep3[c] / cnt[c] * 0.01, seg[c][3] / cnt[c] * 0.01, done[c] / cnt[c] * 0.01);
     fprintf(stderr, "\n");
 }
 #endif
