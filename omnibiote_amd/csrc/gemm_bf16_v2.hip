@@ -466,8 +466,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
 // The epilogue of every structure above is ~4 us of serial latency per tile with the matrix pipe idle (the slowest wave leaves
 // the loop, conversion + staging + barrier, read back, per-chunk addressing + stores; 7.5 us with the GELU arithmetic) — the same
 // with 32 or 256 workgroups in the grid, so neither the fabric nor the CU's store path (which moves a 128-KB tile in 0.75 us:
-// tools/micro/store_path.hip); DESIGN 10.2 — and nothing of it needs the matrix pipe, which
-// is idle during the main loop.  Here one workgroup per CU walks tiles q = blockIdx.x, + gridDim.x, ...; at the end of a tile the
+// tools/micro/store_path.hip); DESIGN 10.2 — and nothing of it needs the matrix pipe, so it can run under the NEXT tile's
+// main loop.  Here one workgroup per CU walks tiles q = blockIdx.x, + gridDim.x, ...; at the end of a tile the
 // accumulators go through the LDS staging as before, but the 16-byte output chunks come back into REGISTERS (8 per lane: the
 // 256 x 128 tile is what leaves room for them) and are stored one per K-step from inside the NEXT tile's main loop, where they
 // cost an issue slot each; the epilogue arithmetic (GELU and its derivative) moves with them.  The last tile of a workgroup drains
