@@ -214,7 +214,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
             for (int it = 0; it < NIT; ++it) r[it] = *reinterpret_cast<const bf16x8*>(p.aux + oo_of(it));
         }
-        __syncthreads();   // the staged tile is complete
+        // (no barrier here: a wave reads back exactly the 64 x NW region it staged itself, and one wave's LDS operations execute
+        //  in order — the barrier at the top, which keeps the staging off ring stages other waves may still be reading, is the only
+        //  one the epilogue needs)
         OBTE_GSTAMP(p, 6);
         // every staged chunk into registers first (the accumulators' registers are free now): the non-temporal store below is an asm
         // statement with a memory clobber, and with the LDS read inside its loop hipcc kept each read behind the previous store —
