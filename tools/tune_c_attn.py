@@ -1,5 +1,5 @@
 """Verbose tuning of a few block GEMM shapes (which structure wins and by how much).   python tools/tune_c_attn.py [rows]"""
-import sys; sys.path.insert(0, '/root/repo')
+import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omnibiote_amd import tune, _lib as L
