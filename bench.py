@@ -89,6 +89,9 @@ def parse():
                    help="k micro-batches per forward/backward pass (k * mini_batch_size rows per launch; masks and the loss normalisation stay "
                         "per micro-batch, so --mini_batch_size keeps the reference's meaning and loss / gradients are those of separate passes). "
                         "An execution option like the GEMM plans.  0 (default): k in {1, 2, 4} timed at start-up over two steps each, the fastest kept")
+    p.add_argument("--grad_exchange", default="allreduce", choices=["allreduce", "all_links"],
+                   help="N > 1: DDP's bucketed all-reduce (the reference's), or the direct reduce-scatter + all-gather over all xGMI links "
+                        "(omnibiote_amd/comm.py); either way per-bucket device events are recorded and reported in config.collectives")
     p.add_argument("--plan_cache", default="", help="JSON file of tuned GEMM plans: loaded if present (no tuning launches), else tuned and written")
     p.add_argument("--shapes_out", default="", help="write the per-shape launch table (from the profiler step) to this file")
     return p.parse_args()
@@ -114,8 +117,8 @@ HBM_KINDS = {110: lambda d0, d1, d2: 4.0 * d0 * d1, 111: lambda d0, d1, d2: (6.0
              112: lambda d0, d1, d2: 4.0 * d0 * d1, 113: lambda d0, d1, d2: 14.0 * d0}   # algorithmic bytes per launch
 PEAK_HBM_TBS = 8.0   # MI355X HBM3E (MI355X_MICROARCH.md)
 # profiler kind = code above + 1000 * kernel structure: the name rocprofv3 --kernel-trace shows for that launch
-STRUCT_NAMES = {1: "gemm_bf16_kernel", 2: "gemm_v2_kernel", 3: "gemm_v3_kernel", 4: "gemm_v4_kernel", 5: "gemm_v5_kernel"}
-GEMM_FAMILY = "bf16 MFMA GEMM family: gemm_bf16_kernel, gemm_v2_kernel, gemm_v3_kernel, gemm_v4_kernel, gemm_v5_kernel, gemm_v3_group_kernel"
+STRUCT_NAMES = {1: "gemm_bf16_kernel", 2: "gemm_v2_kernel", 3: "gemm_v3_kernel", 4: "gemm_v4_kernel", 5: "gemm_v5_kernel", 7: "gemm_v7_kernel"}
+GEMM_FAMILY = "bf16 MFMA GEMM family: " + ", ".join(sorted(set(STRUCT_NAMES.values()))) + ", gemm_v3_group_kernel"
 
 
 def rocprof_name(k: int) -> str:
@@ -178,7 +181,12 @@ def roofline_from_profile(ms, dims, kind, n_steps):
             "avg_launch_ms": round(f["time_ms"] / f["launches"], 4),
             "avg_launch_gflop": round(f["flops"] / f["launches"] / 1e9, 3),
             "share_of_profiled_time": round(f["time_ms"] / sum(x["time_ms"] for x in fam.values()), 3),
+            # demangled BASE name (template arguments dropped): every instantiation of a kernel template — one per operand layout and
+            # epilogue — is summed under it, here and in profiles/rNN_bench_small_families.txt (tools/ktrace_summary.py).  rocprofv3's
+            # own kernel_stats.csv lists instantiations separately, so its top single ROW can be another kernel (e.g. the
+            # non-template gemm_v3_group_kernel): compare like with like.
             "dominant_kernel_by_rocprof_name": gemm_kernels[0] if (dom == GEMM_FAMILY and gemm_kernels) else dom,
+            "dominant_kernel_naming": "demangled base name, template instantiations summed (kernel_stats.csv rows are per instantiation)",
             "by_rocprof_kernel": kernels,
             "breakdown": {n: row(e) for n, e in sorted(by_kind.items())},
             "hbm_bound_kernels": {n: {"ms_per_step": round(e["time_ms"] / n_steps, 3), "launches_per_step": e["launches"] // n_steps,
@@ -188,7 +196,7 @@ def roofline_from_profile(ms, dims, kind, n_steps):
     return roof
 
 
-def oracle_step_rate(cfg, mini_rows, steps, warmup, device, rows, dtype, threads, budget_s=45.0):
+def oracle_step_rate(cfg, mini_rows, steps, warmup, device, rows, dtype, threads, budget_s=45.0, dropout=0.0):
     """tokens/s of the oracle's train step (fwd + masked CE + bwd + clip + AdamW) on ``device``; median of the timed steps.
     ``budget_s`` bounds the sample: timing stops early (never below 3 timed steps) once that much wall time is spent."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -200,6 +208,8 @@ def oracle_step_rate(cfg, mini_rows, steps, warmup, device, rows, dtype, threads
     shapes = R.param_shapes(rc)
     w = {k: (torch.randn(s) * (1.0 if "wte" in k else 0.02) + (1.0 if "ln_" in k else 0.0)).to(dtype).to(device) for k, s in shapes.items()}
     enc = R.OracleEncoder(rc, w)
+    enc.torch_dropout_p = float(dropout)   # > 0: the reference's four dropout sites with torch's generator (its default regime)
+    enc.train()
     enc.rope = R.cast_rope_table(R.rope_table(rc.n_embd // rc.n_head, rc.block_size), dtype).to(device)
     opt = torch.optim.AdamW(enc.parameters(), lr=1e-3)
     step = TE.TrainStep(enc, opt, None, mini_batch_size=mini_rows, n_head=rc.n_head, loss_impl="torch", mask_impl="dense")
@@ -218,6 +228,33 @@ def oracle_step_rate(cfg, mini_rows, steps, warmup, device, rows, dtype, threads
             break
     timed = times[warmup:]
     return rows * cfg["ctx_len"] / float(np.median(timed)), len(timed)
+
+
+def attention_work_fraction(ids_host, mini: int) -> dict:
+    """What share of the full T x T attention a batch of packed rows needs: `pair_fraction` = allowed (query, key) pairs / T^2 (the
+    algorithmic share), `tile_fraction` = the share of tiles the kernels visit — forward: per block of 256 queries the 64-key tiles
+    that meet the union of its rows' key ranges; backward: per block of 256 keys the 32-query slices inside the union of its keys'
+    query ranges (symmetric masks: a key's queries are its own range); weighted 1 : 2 like the 4 L C T + 8 L C T of the reference's
+    formula.  Key ranges from the product's own mask builder (the reference's quirk per mini-batch group)."""
+    from omnibiote_amd import masks
+    kr = masks.RangeMask.from_tokens(torch.from_numpy(np.asarray(ids_host)), group=mini).key_ranges.numpy().astype(np.int64)
+    rows, T, _ = kr.shape
+    s, e = kr[..., 0], kr[..., 1]
+    pair = float((e - s).clip(min=0).sum()) / (rows * T * T)
+    fwd_tiles = bwd_tiles = 0
+    nq, nk = (T + 255) // 256, (T + 63) // 64
+    for b0 in range(nq):
+        lo = s[:, b0 * 256:(b0 + 1) * 256].min(axis=1)
+        hi = e[:, b0 * 256:(b0 + 1) * 256].max(axis=1)
+        fwd_tiles += int(((hi + 63) // 64 - lo // 64).clip(min=0).sum())
+    for k0 in range((T + 255) // 256):
+        lo = s[:, k0 * 256:(k0 + 1) * 256].min(axis=1)
+        hi = e[:, k0 * 256:(k0 + 1) * 256].max(axis=1)
+        bwd_tiles += int(((hi + 31) // 32 - lo // 32).clip(min=0).sum())
+    f_fwd = fwd_tiles / float(rows * nq * nk)
+    f_bwd = bwd_tiles / float(rows * ((T + 255) // 256) * ((T + 31) // 32))
+    return {"pair_fraction": round(pair, 4), "forward_tile_fraction": round(f_fwd, 4), "backward_tile_fraction": round(f_bwd, 4),
+            "tile_fraction": round((f_fwd + 2.0 * f_bwd) / 3.0, 4)}
 
 
 def usable_cores() -> int:
@@ -266,9 +303,13 @@ def cpu_baseline(cfg, mini_rows=8, steps=5, warmup=2, device="cpu", rows=None):
     usable = usable_cores()
     threads = max(1, usable)
     v16, n16 = oracle_step_rate(cfg, mini_rows, steps, warmup, "cpu", rows, torch.bfloat16, threads)
-    v32, n32 = oracle_step_rate(cfg, mini_rows, steps, warmup, "cpu", rows, torch.float32, threads)
+    v32, n32 = oracle_step_rate(cfg, mini_rows, steps, warmup, "cpu", rows, torch.float32, threads, budget_s=30.0)
+    vd, nd = oracle_step_rate(cfg, mini_rows, 3, 1, "cpu", rows, torch.bfloat16, threads, budget_s=25.0, dropout=0.1)
     return {"value": round(v16, 1), "unit": "tokens/s", "cores": threads, "kind": "port", "dtype": "bf16",
             "fp32": {"value": round(v32, 1), "unit": "tokens/s", "steps": n32},
+            # "dropout 0 and 0.1" — the reference's default regime (train_encoder.py:445): Bernoulli masks from torch's
+            # generator at its four sites (23 % of the reference's own CPU step)
+            "dropout_0.1": {"value": round(vd, 1), "unit": "tokens/s", "dtype": "bf16", "steps": nd},
             "host": {"logical_cpus": os.cpu_count(), "usable_by_this_process": usable, "torch_threads": threads},
             "sample": f"oracle (oracle/omnibiote_ref.py) train step fwd+masked CE+bwd+clip+AdamW on the host cores, one micro-batch of "
                       f"{mini_rows} rows x {cfg['ctx_len']} tokens per step, dense additive masks, dropout 0; bf16: median of {n16} steps, "
@@ -459,7 +500,7 @@ def main():
     if force_ddp and world == 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1)
-    model = TE.wrap_ddp(m, local) if (world > 1 or force_ddp) else m
+    model = TE.wrap_ddp(m, local, grad_exchange=a.grad_exchange, timed=True) if (world > 1 or force_ddp) else m
     total_iters = 1000
     opt, sched = TE.build_optimizer(m, h, total_iters)
     step = TE.TrainStep(model, opt, sched, mini_batch_size=a.mini_batch_size, n_head=cfg["n_head"],
@@ -538,6 +579,17 @@ def main():
             losses.append(step(batches[(a.warmup + i) % len(batches)])["loss"])
         sync()
         elapsed = time.perf_counter() - t0
+    _lib.check_device_status("timed steps")   # a kernel that found its own results invalid (device status word): a failed run, not a number
+    exchange = None
+    th = getattr(model, "_obte_timed_hook", None)
+    if th is not None:   # per-bucket device events of the gradient exchange; the LAST timed step's buckets are reported
+        ex = th.collect(getattr(_step, "backward_end_event", None))
+        if ex:
+            nb = max(1, len(ex["buckets"]) // (a.warmup + a.steps + (3 * len(per_pass_selection) if per_pass_selection and len(per_pass_selection) > 1 else 0)))
+            ex["buckets"] = ex["buckets"][-nb:]
+            ex["note"] = ("milliseconds from a bucket's gradients being complete on the backward's stream to its exchange having finished; "
+                          "ms_exposed_after_backward = how long the exchange ran past the end of the step's last backward pass")
+            exchange = ex
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -561,6 +613,7 @@ def main():
             _lib.lib().obte_profile_enable(1)
         step(batches[0])
         torch.cuda.synchronize()
+        _lib.check_device_status("profiled step")
         ms, dims, kind = collect_profile() if rank == 0 else ([], [], [])
         if rank == 0:
             _lib.lib().obte_profile_enable(0)
@@ -610,15 +663,17 @@ def main():
     #                        (train_encoder.py:290-292) instead of key ranges.
     variants = None
 
-    def timed_variant(n=10, w=2):
+    def timed_variant(n=10, w=2, bs=None):
+        bs = bs or batches
         for i in range(w):
-            step(batches[i % len(batches)])
+            step(bs[i % len(bs)])
         sync()
         t0 = time.perf_counter()
         for i in range(n):
-            step(batches[i % len(batches)])
+            step(bs[i % len(bs)])
         sync()
         el = time.perf_counter() - t0
+        _lib.check_device_status("variant")
         if world > 1:
             te = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -676,6 +731,25 @@ def main():
             variants["dropout_0.1"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 10,
                                        "note": "the reference's default --dropout 0.1 (fused counter-based masks at all four sites)"}
             TE.set_dropout(m, 0.0)
+        if not a.multi_document:
+            # "the multi-document variant is reported second" — rows that pack several documents (loader.py:118-163), masked
+            # block-diagonally (train_encoder.py:25-57, its row >= 1 merge quirk per mini-batch): the attention kernels skip the key
+            # tiles no query of a workgroup may see.  The FLOP figure counts only the tiles the kernels visit.
+            md_host = [TE.synthetic_rows(a.rows_per_rank, T, 2 ** 16, rng, single_document=False) for _ in range(2)]
+            md = [torch.from_numpy(hb).to(dev) for hb in md_host]
+            for b_, hb in zip(md, md_host):
+                host_of[id(b_)] = hb
+            work = attention_work_fraction(md_host[0], a.mini_batch_size)
+            v = timed_variant(bs=md)
+            fpt_md = TE.flops_per_token_executed(n_params, cfg["n_layer"], cfg["n_embd"], T, a.readout, not a.full_last_block,
+                                                 attention_fraction=work["tile_fraction"])
+            variants["multi_document"] = {"value": v, "unit": "tokens/s", "steps": 10,
+                                          "attention_work": work, "flops_per_token_executed": fpt_md,
+                                          "mfma_fraction_whole_step_executed": round(v * fpt_md / (PEAK_BF16_TFLOPS * 1e12 * world), 4),
+                                          "note": "rows packing several documents (80 % nucleotide / 20 % peptide length mix), block-diagonal key ranges with the "
+                                                  "reference builder's row >= 1 quirk; executed FLOP = the headline's minus the attention tiles outside every "
+                                                  "workgroup's key range (tile_fraction of 12 L C T: forward 256 queries x 64 keys, backward 256 keys x 32 queries)"}
+            del md
         if not a.dense_mask:
             _step.mask_impl = "dense"
             variants["dense_mask_calling_convention"] = {"value": timed_variant(), "unit": "tokens/s", "steps": 10,
@@ -716,8 +790,11 @@ def main():
                     rccl = "unknown (" + type(e).__name__ + ")"
             collectives = {"backend": "RCCL (torch.distributed backend nccl)" if dist.get_backend() == "nccl" else dist.get_backend(),
                            "rccl_version": rccl, "world_size": dist.get_world_size(), "ranks_in_first_all_reduce": world,
-                           "pattern": "one bucketed gradient all-reduce per optimizer step (DDP no_sync on all but the last micro-batch, "
-                                      "100-MB buckets) + one scalar all-reduce"}
+                           "grad_exchange": a.grad_exchange,
+                           "pattern": ("one bucketed gradient all-reduce" if a.grad_exchange == "allreduce" else
+                                       "one all_to_all + one all_gather per bucket (direct reduce-scatter + all-gather over all links, fp32 fixed-order reduction)")
+                                      + " per optimizer step (DDP no_sync on all but the last micro-batch, 100-MB buckets) + one scalar all-reduce",
+                           "exchange_timing_last_step": exchange}
         else:
             collectives = "none (single rank)"
         out = {

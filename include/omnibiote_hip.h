@@ -12,7 +12,7 @@
  *   - re-entrant: callable from any thread (autograd's backward workers call in without the GIL).  Process-wide state is
  *     the thread-local error string plus two mutex-protected tables: the tuned GEMM plan table (obte_gemm_plan_set /
  *     _clear; read by every GEMM launch) and the opt-in launch profiler's records (obte_profile_*).  Nothing else persists
- *     between calls.
+ *     between calls — except the device status word below, which is sticky until read.
  */
 #ifndef OMNIBIOTE_HIP_H
 #define OMNIBIOTE_HIP_H
@@ -37,6 +37,22 @@ const char* obte_last_error(void);
 /* sizeof of the public argument structs in declaration order (gemm, attn_fwd, attn_bwd, mt, block_desc): lets a
  * binding written in another language verify its struct layout at load time.  Returns the number of structs. */
 int obte_struct_sizes(int64_t* out, int cap);
+
+/* ---- device status (failures a kernel detects after it was launched) --------------------------------------------
+ * A kernel cannot return an error code.  The ones that can detect an unrecoverable condition at run time OR a bit into one
+ * word of pinned host memory; obte_device_status() returns that word (0 = nothing happened) and, with clear != 0, resets the
+ * bits it returned.  It is a plain host read: call it where the work in question has already been synchronised with (after
+ * the loss has been copied back, after a stream / device synchronise) — a set bit means the results of the launch that set it
+ * are INVALID, and obte_last_error() then says which condition it was.  Negative: the word could not be allocated.
+ * Replaces nothing in the reference (PyTorch raises from its own kernels' asserts the same way: at the next synchronise). */
+enum {
+    OBTE_STATUS_ATTN_BWD_HANDOFF = 1   /* obte_attn_bwd, one-kernel form: a bounded wait of the dQ hand-off chain gave up */
+};
+int obte_device_status(int clear);
+/* Test hook (never set by the product): make the next launches of a kernel fail in a chosen way so that the reporting above can
+ * be exercised.  what = 0: off; 1: the one-kernel attention backward never signals ONE hand-off counter and bounds its waits
+ * at 2^10 polls instead of 2^20.  Process-wide; returns the previous value. */
+int obte_fault_inject(int what);
 
 /* ---- opt-in launch profiler (measurement only; off by default) ----------------------------------------------
  * While enabled, every obte_gemm_bf16 / obte_attn_fwd / obte_attn_bwd call is bracketed by two hipEvents on the
@@ -350,6 +366,9 @@ typedef struct {
     const obte_bf16* dy_masked; obte_bf16* dx_masked; uint64_t dx_mask_seed;
 } obte_block_desc;
 int64_t obte_block_act_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head);
+/* the same for a known dropout probability: with p = 0 the buffer ends before the attention dropout's keep bits (the largest
+ * single region at long T); the other offsets do not move, so a buffer of obte_block_act_bytes() serves any p */
+int64_t obte_block_act_bytes_p(int64_t B, int64_t T, int32_t n_embd, int32_t n_head, float dropout_p);
 int64_t obte_block_bwd_ws_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head);
 int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte_bf16* y, void* act, obte_stream s);
 /* grads of the six parameters are written (not accumulated) to d*_w; dx to dx. */

@@ -75,6 +75,8 @@ SYMBOLS = {
     "obte_abi_version": (C.c_int, []),
     "obte_last_error": (C.c_char_p, []),
     "obte_struct_sizes": (C.c_int, [C.c_void_p, C.c_int]),
+    "obte_device_status": (C.c_int, [C.c_int]),
+    "obte_fault_inject": (C.c_int, [C.c_int]),
     "obte_profile_enable": (C.c_int, [C.c_int]),
     "obte_profile_collect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "obte_layernorm_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_float, c_stream]),
@@ -117,6 +119,7 @@ SYMBOLS = {
     "obte_sumsq_multi_bf16_each": (C.c_int, [C.POINTER(MtArgs), C.c_void_p, c_stream]),
     "obte_adamw_multi_bf16_ref": (C.c_int, [C.POINTER(MtArgs), C.c_double, C.c_double, C.c_double, C.c_void_p, c_stream]),
     "obte_block_act_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "obte_block_act_bytes_p": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_float]),
     "obte_block_bwd_ws_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "obte_block_fwd": (C.c_int, [C.POINTER(BlockDesc), C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
     "obte_block_bwd": (C.c_int, [C.POINTER(BlockDesc)] + [C.c_void_p] * 11 + [c_stream]),
@@ -170,3 +173,20 @@ def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib().obte_last_error()
         raise RuntimeError(f"{what or 'libomnibiote_hip'} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+STATUS_ATTN_BWD_HANDOFF = 1
+
+
+class DeviceStatusError(RuntimeError):
+    """A kernel reported, through the library's device status word, that a launch's results are invalid."""
+
+
+def check_device_status(what: str = "") -> None:
+    """Raise if any kernel has reported a failure since the last check (include/omnibiote_hip.h, obte_device_status).  A plain host
+    read of pinned memory: meaningful for work the caller has already synchronised with — call it right after a `.item()`, a
+    stream / device synchronise or an event wait.  The bits are cleared, so one failure is raised once."""
+    v = lib().obte_device_status(1)
+    if v != 0:
+        msg = lib().obte_last_error()
+        raise DeviceStatusError(f"{what + ': ' if what else ''}{msg.decode() if msg else f'device status {v}'}")

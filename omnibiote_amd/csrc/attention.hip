@@ -1078,8 +1078,10 @@ static std::atomic<int>& attn_bwd_mode_ref() {
 }
 static int attn_bwd_mode() { return attn_bwd_mode_ref().load(std::memory_order_relaxed); }
 extern "C" int obte_attn_bwd_select(int mode) { return attn_bwd_mode_ref().exchange(mode == 1 ? 1 : 0); }
+// 0 wherever the one-kernel form does not apply (head size, T > 8192, T whose packed rows exceed 32-bit byte offsets): the caller then
+// allocates nothing and obte_attn_bwd takes the two-kernel form
 extern "C" int64_t obte_attn_bwd_ws_bytes(int64_t B, int64_t T, int32_t n_head, int32_t head_dim) {
-    if (B <= 0 || T <= 0 || n_head <= 0 || head_dim != 128) return 0;
+    if (B <= 0 || T <= 0 || n_head <= 0 || head_dim != 128 || T * 3 * n_head * 128 * 2 >= (1ll << 31)) return 0;
     return fused_bwd_ws_bytes(B, T, n_head);
 }
 
@@ -1101,8 +1103,9 @@ extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
     const int mode = mask_mode(a->key_ranges, a->mask);
     p.drop_bits_in = (p.drop.thresh16 != 0 && a->head_dim == 128 && mode != MASK_DENSE) ? a->drop_bits : nullptr;
     const int prof = obte_prof_begin((hipStream_t)s, 101, a->B * a->n_head, a->T, a->head_dim);
-    if (mode != MASK_DENSE && a->head_dim == 128 && p.drop.thresh16 == 0 && a->ws && attn_bwd_mode() == 0 &&
-        a->ws_bytes >= fused_bwd_ws_bytes(a->B, a->T, a->n_head) && a->T * 3 * a->n_head * 128 * 2 < (1ll << 31)) {   // (its per-lane byte offsets are 32-bit)
+    const int64_t fused_ws = a->head_dim == 128 ? fused_bwd_ws_bytes(a->B, a->T, a->n_head) : 0;   // 0: the one-kernel form does not apply
+    if (mode != MASK_DENSE && a->head_dim == 128 && p.drop.thresh16 == 0 && a->ws && attn_bwd_mode() == 0 && fused_ws > 0 &&
+        a->ws_bytes >= fused_ws && a->T * 3 * a->n_head * 128 * 2 < (1ll << 31)) {   // (its per-lane byte offsets are 32-bit)
         if (mode == MASK_RANGES) p.query_bounds = nullptr;   // a range mask without a dense tensor: symmetric (the key's own range)
         rc = launch_bwd_fused(p, mode, a->ws, (hipStream_t)s);
     } else if (mode == MASK_DENSE && a->key_ranges && a->query_bounds && a->ranges_exact)

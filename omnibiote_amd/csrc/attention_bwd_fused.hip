@@ -55,7 +55,11 @@ struct FusedParams {
     float* dq_acc;         // fp32 [B*H][nsl][4 waves][4][64 lanes][4]: the running dQ^T tile of every slice
     int32_t* flags;        // int32 [B*H][nsl]: contributions completed per slice (zeroed by the prep kernel, every call)
     int32_t* kb_bounds;    // int32 [B][nkb][2]: the slices [t_begin, t_end) each key block sweeps (prep kernel)
-    int32_t* err;          // int32 [1]: set when a bounded spin gave up (a protocol bug or a workgroup that never ran)
+    int32_t* status;       // the library's device status word (pinned host memory, common.h): OBTE_STATUS_ATTN_BWD_HANDOFF is OR-ed into it
+                           // when a bounded spin gives up (a protocol bug or a workgroup that never ran); the host checks it at its next
+                           // synchronising point (obte_device_status) and treats the launch's gradients as invalid
+    int spin_limit;        // polls before a wait gives up (2^20: ~2 s; the fault-injection hook of the tests shortens it)
+    int no_signal_slice;   // fault injection (tests): the counter of this slice of (batch 0, head 0) is never added to (-1: off)
     int nkb, nsl;
 };
 
@@ -93,7 +97,7 @@ __device__ __forceinline__ uint32_t opaque(uint32_t x) { asm volatile("" : "+v"(
 // Prep launch, three jobs by block range:
 //  [0, nb_delta)   delta[b,h,q] = sum_d O[b,q,h,d] dO[b,q,h,d] (the softmax backward's row constant): one wave per (b, q) row of the
 //                  [M, C] activations, 16 lanes hold one head's 128 values;
-//  next nb_flags   zero the slices' hand-off counters (every call: the protocol counts from zero) and the error word;
+//  next nb_flags   zero the slices' hand-off counters (every call: the protocol counts from zero);
 //  next B * nkb    the slice range [t_begin, t_end) of key block (b, kb): the union of the query ranges of its keys.
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(FusedParams fp, int mode, int nb_delta, int nb_flags) {
     const AttnParams& p = fp.a;
@@ -124,7 +128,6 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(FusedParams fp, int 
     if (blk < nb_flags) {
         const int64_t i = (int64_t)blk * 256 + tid;
         if (i < p.B * H * fp.nsl) fp.flags[i] = 0;
-        if (i == 0) *fp.err = 0;
         return;
     }
     blk -= nb_flags;
@@ -315,6 +318,7 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     // (4 wave + i) * 1 KiB + 16 lane
     const __amdgpu_buffer_rsrc_t rs_acc = make_rsrc(fp.dq_acc + bh * fp.nsl * 4096, (int64_t)fp.nsl * 16384);
     int32_t* const flag_b = fp.flags + bh * fp.nsl;
+    const int mute = (fp.no_signal_slice >= 0 && bh == 0) ? fp.no_signal_slice : -2;   // fault injection (tests): this slice's counter is never added to
     const int acc_lane = wave * 4096 + lane * 16;
     // The loads of the hand-off are issued through inline asm: hipcc would otherwise put its own s_waitcnt vmcnt(0) in front of
     // their first use (and of unrelated instructions that reuse a register), which in this in-order queue also drains the LDS-DMA
@@ -326,13 +330,25 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     };
     // the counter of slice t has reached `place` (every wave polls for itself: its own tile loads follow its own poll); `have` is
     // the value polled an iteration ago — in steady state it already suffices and nothing is loaded here
+    // A wait that gives up is a hard failure of the launch, reported through the device status word: the wave goes on (with a tile
+    // that is not the chain's: this launch's gradients are invalid and the host says so at its next synchronising point), and so that
+    // one failure does not become nsl timeouts in a row, every later wait of this wave is cut short (`gave_up`) and the other waves
+    // look at the word every 1024 polls.
+    bool gave_up = false;
     auto wait_turn = [&](int t, int place, int have) {
         int spins = 0;
         while (have < place) {
             __builtin_amdgcn_s_sleep(8);
             const int off = t * 4;
             asm volatile("global_load_dword %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(have) : "v"(off), "s"(flag_s) : "memory");
-            if (++spins > (1 << 20)) { if (lane == 0) *fp.err = 1; break; }
+            ++spins;
+            if ((spins & 1023) == 0 && !gave_up)
+                gave_up = (__hip_atomic_load(fp.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) & OBTE_STATUS_ATTN_BWD_HANDOFF) != 0;
+            if (gave_up || spins > fp.spin_limit) {
+                if (lane == 0 && !gave_up) __hip_atomic_fetch_or(fp.status, OBTE_STATUS_ATTN_BWD_HANDOFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                gave_up = true;
+                break;
+            }
         }
     };
     // The tile so far is requested by LDS-DMA into this wave's own 4 KiB of a staging area (no VGPR destination: hipcc counts an
@@ -672,7 +688,7 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         have_cur = *raw_poll;
         if (more) store_stats(stage_of(it + 1), t_next * 32);
         if (!OBTE_SKIP(8)) __syncthreads();
-        if (tid == 0 && t_sig >= 0) __hip_atomic_fetch_add(flag_b + t_sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && t_sig >= 0 && t_sig != mute) __hip_atomic_fetch_add(flag_b + t_sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         OBTE_PHASE(5);
         t_sig = (!first_it && !last_p) ? t_prev : -1;   // (nobody follows a chain's last member)
         t_prev = t; info_prev = info; have_prev = have_cur;
@@ -702,8 +718,8 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // every wave's tiles have left; and every wave is done with the K rows (all 256 feed each wave's dQ tiles): they now carry rows out
     if (tid == 0) {
-        if (t_sig >= 0) __hip_atomic_fetch_add(flag_b + t_sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (n_sl > 0 && !(info_prev & 0x80)) __hip_atomic_fetch_add(flag_b + t_prev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t_sig >= 0 && t_sig != mute) __hip_atomic_fetch_add(flag_b + t_sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n_sl > 0 && !(info_prev & 0x80) && t_prev != mute) __hip_atomic_fetch_add(flag_b + t_prev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #ifdef OBTE_DEBUG_HOOKS
     unsigned long long t_a = 0, t_b = 0;   // (OBTE_ATTN_SKIP=1 / 2 / 3 with the stamps: slot 6 = prologue / + last slice and signals / + dK, dV rows)
@@ -812,35 +828,39 @@ OBTE_FUSED_SKIPS(X)
 
 namespace obte_attn {
 
-// scratch: the running dQ^T tiles, the slices' counters, the key blocks' slice ranges, the error word
-static void ws_layout(int64_t B, int64_t T, int H, int64_t& nkb, int64_t& nsl, int64_t& o_flags, int64_t& o_bounds, int64_t& o_err, int64_t& total) {
+// scratch: the running dQ^T tiles, the slices' counters, the key blocks' slice ranges
+static void ws_layout(int64_t B, int64_t T, int H, int64_t& nkb, int64_t& nsl, int64_t& o_flags, int64_t& o_bounds, int64_t& total) {
     nkb = (T + FB_KEYS - 1) / FB_KEYS; nsl = (T + 31) / 32;
     auto up = [](int64_t x) { return (x + 255) & ~int64_t(255); };
     o_flags = up(B * H * nsl * (32 * 128 * 4));
     o_bounds = o_flags + up(B * H * nsl * 4);
-    o_err = o_bounds + up(B * nkb * 2 * 4);
-    total = o_err + 256;
+    total = o_bounds + up(B * nkb * 2 * 4) + 256;
 }
+// 0: the one-kernel form does not apply to this shape — longer sequences take the two-kernel form.  (256 slices = T <= 8192: the list
+// of the slices a workgroup finishes is kept in the 1 KiB of LDS the key blocks' ranges occupied, one int per slice, and a mask can
+// make one key block finish all of its slices)
 int64_t fused_bwd_ws_bytes(int64_t B, int64_t T, int H) {
-    int64_t nkb, nsl, a, b2, c, total;
-    ws_layout(B, T, H, nkb, nsl, a, b2, c, total);
-    // longer sequences: the two-kernel form.  (256 slices = T <= 8192: the list of the slices a workgroup finishes is kept in the
-    //  1 KiB of LDS the key blocks' ranges occupied, one int per slice, and a mask can make one key block finish all of its slices)
-    return (nsl <= 256 && nsl <= FusedShape<128>::TAB && nkb <= 120) ? total : (int64_t)1 << 62;
+    int64_t nkb, nsl, a, b2, total;
+    ws_layout(B, T, H, nkb, nsl, a, b2, total);
+    return (nsl <= 256 && nsl <= FusedShape<128>::TAB && nkb <= 120) ? total : 0;
 }
 
 // mode: MASK_NONE or MASK_RANGES.  ws: fused_bwd_ws_bytes() bytes.
 int launch_bwd_fused(const AttnParams& p, int mode, void* ws, hipStream_t st) {
     FusedParams fp;
     fp.a = p;
-    int64_t nkb, nsl, o_flags, o_bounds, o_err, total;
-    ws_layout(p.B, p.T, p.H, nkb, nsl, o_flags, o_bounds, o_err, total);
+    int64_t nkb, nsl, o_flags, o_bounds, total;
+    ws_layout(p.B, p.T, p.H, nkb, nsl, o_flags, o_bounds, total);
     fp.nkb = (int)nkb; fp.nsl = (int)nsl;
     char* w = reinterpret_cast<char*>(ws);
     fp.dq_acc = reinterpret_cast<float*>(w);
     fp.flags = reinterpret_cast<int32_t*>(w + o_flags);
     fp.kb_bounds = reinterpret_cast<int32_t*>(w + o_bounds);
-    fp.err = reinterpret_cast<int32_t*>(w + o_err);
+    fp.status = obte_status_word();
+    if (!fp.status) { obte_set_error("obte_attn_bwd: the device status word could not be allocated"); return OBTE_ELAUNCH; }
+    const bool inject = obte_fault_injection() == 1;
+    fp.spin_limit = inject ? (1 << 10) : (1 << 20);
+    fp.no_signal_slice = inject ? 0 : -1;
     const int nb_delta = (int)cdiv64(p.B * p.T, 4), nb_flags = (int)cdiv64(p.B * p.H * nsl, 256);
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)(nb_delta + nb_flags + p.B * nkb)), dim3(256), 0, st, fp, mode, nb_delta, nb_flags);
     OBTE_CHECK_LAUNCH("obte_attn_bwd(prep)");

@@ -12,7 +12,9 @@ inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 struct ActLayout {
     int64_t mean1, rstd1, h1, qkv, lse, y, x1, mean2, rstd2, h2, hpre, hact, x1r, dropbits, total;
-    ActLayout(int64_t B, int64_t T, int C, int H) {
+    // with_bits: the attention dropout's keep bits (B H ceil(T/32) T words: 134 MB per block at B = 8, T = 4096) are part of the
+    // buffer only when dropout is on; they are the LAST region, so every other offset is the same either way
+    ActLayout(int64_t B, int64_t T, int C, int H, bool with_bits = true) {
         const int64_t M = B * T;
         int64_t o = 0;
         auto take = [&](int64_t bytes) { int64_t r = o; o += align256(bytes); return r; };
@@ -27,7 +29,7 @@ struct ActLayout {
         hpre = take(M * 4 * C * 2);
         hact = take(M * 4 * C * 2);
         x1r = take(M * C * 2);      // rows form (obte_block_desc::out_rows): x1 at the wanted positions
-        dropbits = take(obte_attn_drop_bits_bytes(B, T, H));   // attention dropout: the forward's keep bits for the backward (touched only with dropout on)
+        dropbits = take(with_bits ? obte_attn_drop_bits_bytes(B, T, H) : 0);   // attention dropout: the forward's keep bits for the backward
         total = o;
     }
 };
@@ -110,6 +112,9 @@ int check_desc(const char* who, const obte_block_desc* d) {
 extern "C" int64_t obte_block_act_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head) {
     return ActLayout(B, T, n_embd, n_head).total;
 }
+extern "C" int64_t obte_block_act_bytes_p(int64_t B, int64_t T, int32_t n_embd, int32_t n_head, float dropout_p) {
+    return ActLayout(B, T, n_embd, n_head, dropout_p > 0.f).total;
+}
 extern "C" int64_t obte_block_bwd_ws_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head) {
     return WsLayout(B, T, n_embd, n_head).total;
 }
@@ -141,6 +146,12 @@ extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte
     af.B = d->B; af.T = d->T; af.n_head = H; af.head_dim = hs; af.scale = 8.0f / (float)C;  // model.py:119
     af.dropout_p = d->dropout_p; af.dropout_seed = d->dropout_seed;
     af.drop_bits = d->dropout_p > 0.f ? (uint32_t*)(A + L.dropbits) : nullptr;
+    if (af.drop_bits) {   // words of key tiles the forward skips (pairs the mask excludes) stay defined whoever reads them
+        if (hipMemsetAsync(af.drop_bits, 0, (size_t)obte_attn_drop_bits_bytes(d->B, d->T, H), (hipStream_t)s) != hipSuccess) {
+            obte_set_error("obte_block_fwd: memset of the dropout keep bits failed");
+            return OBTE_ELAUNCH;
+        }
+    }
     af.ranges_exact = d->ranges_exact;
     TRY(obte_attn_fwd(&af, s));
     TRY(gemm(yat, d->proj_w, x1, M, C, C, C, C, 1, 1, OBTE_EPI_ADD, x, nullptr, s, nullptr, 0, d->dropout_p, d->dropout_seed, SITE_RESID));

@@ -37,6 +37,10 @@ void obte_set_error(const char* fmt, ...);
         }                                                                                 \
     } while (0)
 
+// device status word (lib.cpp): pinned host memory kernels OR failure bits into; null if it could not be allocated
+int32_t* obte_status_word();
+int obte_fault_injection();   // the tests' fault-injection request (obte_fault_inject), 0 = none
+
 // opt-in launch profiler (lib.cpp); idx < 0 = profiling off
 int obte_prof_begin(hipStream_t st, int kind, int64_t d0, int64_t d1, int64_t d2);
 void obte_prof_end(int idx, hipStream_t st);

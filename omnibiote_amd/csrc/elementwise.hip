@@ -751,15 +751,20 @@ extern "C" int obte_masked_ce_rows(const obte_bf16* logits, const int64_t* targe
     OBTE_REQUIRE(row_index || n_rows == total_rows, "obte_masked_ce_rows: without a row list, logits and target hold exactly the n_rows listed rows");
     OBTE_REQUIRE((const void*)logits != (const void*)dlogits_rows, "obte_masked_ce_rows: dlogits_rows must not alias logits");
     const int prof = obte_prof_begin((hipStream_t)s, 112, n_rows, vocab, 1);   // algorithmic bytes = 4 * n_rows * vocab (read + write)
-    static int regs_on = -1;   // OBTE_CE_REGS=0: the two-pass kernel (A/B timing; bitwise the same results)
-    if (regs_on < 0) { const char* e = getenv("OBTE_CE_REGS"); regs_on = (e && e[0] == '0') ? 0 : 1; }
-    static int pipe_on = -1, nt_on = -1, pipe_grid = 0;   // OBTE_CE_PIPE=0: one workgroup per row (A/B timing; bitwise the same results)
-    if (pipe_on < 0) {
-        const char* e = getenv("OBTE_CE_PIPE"); pipe_on = (e && e[0] == '0') ? 0 : 1;
-        e = getenv("OBTE_CE_NT"); nt_on = (e && e[0] == '1') ? 1 : 0;
-        e = getenv("OBTE_CE_GRID"); pipe_grid = e ? atoi(e) : 256;
-        if (pipe_grid < 1 || pipe_grid > 4096) pipe_grid = 256;
-    }
+    // A/B switches, read once: ONE thread-safe static holds them all (this entry point is called from autograd's worker threads; with
+    // several lazily set ints a second thread could see one of them set and another still at its placeholder — a grid of 0).
+    // OBTE_CE_REGS=0: the two-pass kernel; OBTE_CE_PIPE=0: one workgroup per row (both bitwise the same results)
+    struct CeCfg { int regs_on, pipe_on, nt_on, pipe_grid; };
+    static const CeCfg cfg = [] {
+        CeCfg c;
+        const char* e = getenv("OBTE_CE_REGS"); c.regs_on = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("OBTE_CE_PIPE"); c.pipe_on = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("OBTE_CE_NT"); c.nt_on = (e && e[0] == '1') ? 1 : 0;
+        e = getenv("OBTE_CE_GRID"); c.pipe_grid = e ? atoi(e) : 256;
+        if (c.pipe_grid < 1 || c.pipe_grid > 4096) c.pipe_grid = 256;
+        return c;
+    }();
+    const int regs_on = cfg.regs_on, pipe_on = cfg.pipe_on, nt_on = cfg.nt_on, pipe_grid = cfg.pipe_grid;
     if (regs_on && pipe_on && vocab == 256 * 32 * 8 && n_rows > pipe_grid) {
         const dim3 grid((unsigned)pipe_grid);
         const int smem = (int)(vocab * 2 + 128);

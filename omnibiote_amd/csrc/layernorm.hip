@@ -362,12 +362,18 @@ static int ln_bwd_impl(const obte_bf16* dy, const obte_bf16* x, const obte_bf16*
                        int ws_acc, bool reduce, bool clear_tail, obte_stream s, obte_bf16* dx_drop = nullptr, DropCfg dc = DropCfg{0, 0, 0, 1.0f}) {
     OBTE_REQUIRE(dy && x && w && mean && rstd && dx && ws && (dw || !reduce), "obte_layernorm_bwd: null pointer");
     OBTE_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 4096, "obte_layernorm_bwd: bad shape rows=%lld cols=%d", (long long)rows, cols);
-    static int blocks_cap = 0;
-    if (!blocks_cap) {
+    // (one thread-safe static for the two A/B switches: the backward runs on autograd's worker threads)
+    struct LnCfg { int blocks_cap, pipe_on; };
+    static const LnCfg lcfg = [] {
+        LnCfg c;
         const char* e = getenv("OBTE_LN_BLOCKS");   // timing experiments; the workspace admits up to LN_BWD_MAX_BLOCKS
-        blocks_cap = e ? atoi(e) : 256;
-        if (blocks_cap < 1 || blocks_cap > LN_BWD_MAX_BLOCKS) blocks_cap = 256;
-    }
+        c.blocks_cap = e ? atoi(e) : 256;
+        if (c.blocks_cap < 1 || c.blocks_cap > LN_BWD_MAX_BLOCKS) c.blocks_cap = 256;
+        e = getenv("OBTE_LN_PIPE");                 // 0: the un-pipelined kernel (bitwise the same results)
+        c.pipe_on = (e && e[0] == '0') ? 0 : 1;
+        return c;
+    }();
+    const int blocks_cap = lcfg.blocks_cap;
     const int nblk = (int)(cdiv64(rows, 4) < blocks_cap ? cdiv64(rows, 4) : blocks_cap);
     const dim3 grid(nblk), block(256);
     const size_t smem = (size_t)4 * cols * sizeof(float);
@@ -378,8 +384,7 @@ static int ln_bwd_impl(const obte_bf16* dy, const obte_bf16* x, const obte_bf16*
         return OBTE_ELAUNCH;
     }
     const int prof = obte_prof_begin(st, 111, rows, cols, dresid ? 1 : 0);   // algorithmic bytes = (6 + 2 * has_resid) * rows * cols
-    static int pipe_on = -1;   // OBTE_LN_PIPE=0: the un-pipelined kernel (A/B timing; bitwise the same results)
-    if (pipe_on < 0) { const char* e = getenv("OBTE_LN_PIPE"); pipe_on = (e && e[0] == '0') ? 0 : 1; }
+    const int pipe_on = lcfg.pipe_on;
     const bool drop2 = dx_drop != nullptr && dc.thresh16 != 0;
 #define LN_BWD_GO(K, ...) hipLaunchKernelGGL((K), grid, block, smem, st, (const bf16*)dy, (const bf16*)x, (const bf16*)w, mean, rstd, __VA_ARGS__)
 #define LN_PIPE(N, R, D, F) LN_BWD_GO((ln_bwd_pipe_kernel<N, R, D, F>), (const bf16*)(R ? dresid : nullptr), (bf16*)dx, ws, rows, cols, ws_acc, (bf16*)(D ? dx_drop : nullptr), dc)

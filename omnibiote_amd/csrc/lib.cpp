@@ -22,6 +22,43 @@ extern "C" int obte_struct_sizes(int64_t* out, int cap) {
     return n;
 }
 
+// ---- device status word ---------------------------------------------------------------------------------------
+// Kernels that can detect a failure they cannot recover from (today: a bounded spin of the one-kernel attention backward's
+// hand-off chain that gave up) OR a bit into ONE word of pinned, device-visible host memory, system scope.  The host reads it
+// with a plain load at any point where the work in question has been synchronised with (obte_device_status): no copy, no
+// dependence on which workspace a call used, and a failure is never silent.  A second word is the fault-injection request of
+// the tests (obte_fault_inject): read on the host only and handed to the launches that honour it.
+#include <atomic>
+#include <mutex>
+namespace {
+std::once_flag g_status_once;
+int32_t* g_status = nullptr;          // [0] status bits, kernels OR into it; lives for the life of the process
+std::atomic<int> g_fault_inject{0};
+}
+int32_t* obte_status_word() {
+    std::call_once(g_status_once, [] {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 256, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && h) {
+            memset(h, 0, 256);
+            g_status = (int32_t*)h;
+        }
+    });
+    return g_status;
+}
+int obte_fault_injection() { return g_fault_inject.load(std::memory_order_relaxed); }
+extern "C" int obte_device_status(int clear) {
+    int32_t* w = obte_status_word();
+    if (!w) { obte_set_error("obte_device_status: the status word could not be allocated"); return OBTE_ELAUNCH; }
+    const int v = __atomic_load_n(w, __ATOMIC_ACQUIRE);
+    if (clear && v) __atomic_and_fetch(w, ~v, __ATOMIC_ACQ_REL);
+    if (v & OBTE_STATUS_ATTN_BWD_HANDOFF)
+        obte_set_error("device status 0x%x: the attention backward's dQ hand-off chain timed out (a workgroup of a (batch, head) never signalled): "
+                       "the gradients of that launch are invalid", v);
+    else if (v) obte_set_error("device status 0x%x", v);
+    return v;
+}
+extern "C" int obte_fault_inject(int what) { return g_fault_inject.exchange(what); }
+
 // ---- opt-in launch profiler ---------------------------------------------------------------------------------
 #include <mutex>
 #include <vector>

@@ -373,29 +373,33 @@ class _EmbeddingFn(torch.autograd.Function):
         return None, dw, None, None, None
 
 
-# The hand-off of the dropout-masked gradient between consecutive blocks' backward passes (ops.block_bwd, dy_masked): the dx a
-# block just produced -> dropout(dx) under the mask of the block below, keyed by dx's storage.  The taker checks that the gradient
-# it received IS that tensor (same storage and shape) and that probability and seed are its own; anything else is ignored and the
-# block masks dy itself (the same values either way).  Entries are consumed by the very next block of the same backward; the
-# table is capped so that an interrupted backward cannot leave tensors behind for long.
-_masked_grad = {}
+class _GradHandOff:
+    """The hand-off of the dropout-masked gradient between consecutive blocks' backward passes (ops.block_bwd, dy_masked): block
+    i + 1's backward leaves dropout(dx) under block i's MLP-projection mask here, block i's backward takes it instead of spending
+    a pass on masking dy.  ONE object per forward call (OmniBioTA.forward creates it and every _BlockFn node of that call holds
+    it on its ctx), slots keyed by block index: nothing process-wide, two models or two passes never see each other's entries.
+    The taker uses the entry only if the gradient it received IS the dx the entry was made for and nobody touched it since —
+    same storage and shape, the same version counter (autograd's in-place accumulation of a second contribution, a tensor hook
+    that edits the gradient: both bump it), its own probability and seed; otherwise it masks dy itself."""
 
+    __slots__ = ("slots",)
 
-def _masked_grad_put(dx, dx_masked, p, seed):
-    if dx_masked is None:
-        return
-    while len(_masked_grad) >= 8:
-        _masked_grad.pop(next(iter(_masked_grad)), None)
-    _masked_grad[dx.data_ptr()] = (dx_masked, tuple(dx.shape), float(p), int(seed))
+    def __init__(self):
+        self.slots = {}
 
+    def put(self, index, dx, dx_masked, p, seed):
+        if dx_masked is not None:
+            self.slots[index] = (dx_masked, dx, dx._version, float(p), int(seed))
 
-def _masked_grad_take(dy, drop):
-    if os.environ.get("OBTE_DROPOUT_HANDOFF") == "0":   # A/B and tests: every block masks its own dy
-        return None
-    ent = _masked_grad.pop(dy.data_ptr(), None)
-    if ent is None or ent[1] != tuple(dy.shape) or ent[2] != float(drop[0]) or ent[3] != int(drop[1]):
-        return None
-    return ent[0]
+    def take(self, index, dy, drop):
+        ent = self.slots.pop(index, None)
+        if ent is None or os.environ.get("OBTE_DROPOUT_HANDOFF") == "0":   # (A/B and tests: every block masks its own dy)
+            return None
+        dx_masked, dx, version, p, seed = ent
+        if (dy.data_ptr() != dx.data_ptr() or dy.shape != dx.shape or dy._version != version or p != float(drop[0])
+                or seed != int(drop[1])):
+            return None
+        return dx_masked
 
 
 class _BlockFn(torch.autograd.Function):
@@ -403,9 +407,10 @@ class _BlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ln1, attn_w, proj_w, ln2, fc_w, mlp_w, rope_cos, rope_sin, n_head, mask, dropout_p, dropout_seed, out_rows=None,
-                below_seed=None):
+                below_seed=None, handoff=None, index=0):
         x = x.contiguous()
-        ctx.below_seed = below_seed if dropout_p > 0 else None   # the dropout seed of the block below (None: no block there)
+        ctx.below_seed = below_seed if (dropout_p > 0 and handoff is not None) else None   # the dropout seed of the block below (None: no block there)
+        ctx.handoff, ctx.index = handoff, index   # this forward call's _GradHandOff and the block's place in it
         params = (ln1, attn_w, proj_w, ln2, fc_w, mlp_w)
         y, act = ops.block_fwd(x, params, (rope_cos, rope_sin), n_head, mask, dropout_p, dropout_seed, out_rows=out_rows)
         ctx.save_for_backward(x, act, rope_cos, rope_sin, *params)
@@ -425,15 +430,15 @@ class _BlockFn(torch.autograd.Function):
         lnp = (_ln_partials(ctx.w_params[0], pol), _ln_partials(ctx.w_params[3], pol)) if pol.ln_mode else None
         dy = dy.contiguous()
         # dropout: the block above may have left dropout(dy) under this block's MLP-projection mask (one pass less per block)
-        dy_masked = _masked_grad_take(dy, ctx.drop) if ctx.drop[0] > 0 else None
+        dy_masked = ctx.handoff.take(ctx.index, dy, ctx.drop) if (ctx.drop[0] > 0 and ctx.handoff is not None) else None
         res = ops.block_bwd(x, dy, act, tuple(params), (rope_cos, rope_sin), ctx.n_head, ctx.mask,
                             accumulate_into=slots, dropout_p=ctx.drop[0], dropout_seed=ctx.drop[1], ln_partials=lnp,
                             ln_partial_mode=pol.ln_mode, out_rows=ctx.out_rows, dy_masked=dy_masked, dx_mask_seed=ctx.below_seed)
         dx, grads = res[0], res[1]
         if ctx.below_seed is not None:
-            _masked_grad_put(dx, res[2], ctx.drop[0], ctx.below_seed)
+            ctx.handoff.put(ctx.index - 1, dx, res[2], ctx.drop[0], ctx.below_seed)
         _ord_done(pol, id(ctx.w_params[0]))
-        return (dx, *grads, None, None, None, None, None, None, None, None)
+        return (dx, *grads, None, None, None, None, None, None, None, None, None, None)
 
 
 class _AttnCoreFn(torch.autograd.Function):
@@ -579,9 +584,11 @@ class Block(nn.Module):
         if config.bias:
             raise NotImplementedError("bias=True is not used by the reference (model.py:191) and not implemented")
 
-    def forward(self, x, attn_mask=None, out_rows=None, below_seed=None):
-        """below_seed (internal, OmniBioTA.forward): the dropout seed the block BELOW drew in this forward — this block's
-        backward then also writes its dx under that block's MLP-projection mask (ops.block_bwd).
+    def forward(self, x, attn_mask=None, out_rows=None, below_seed=None, seed=None, handoff=None, index=0):
+        """below_seed, seed, handoff, index (internal, OmniBioTA.forward): the dropout seed the block BELOW uses in this forward —
+        this block's backward then also writes its dx under that block's MLP-projection mask (ops.block_bwd) and leaves it in
+        `handoff` (the forward call's _GradHandOff) for block index - 1; `seed` is this block's own, drawn by the caller so that it
+        can hand it on (None: drawn here).
         out_rows (optional, int64 (n,), ascending distinct rows of the flattened (b*t, n_embd) activation): the caller
         wants the block's output at those positions alone and gets it as (n, n_embd) — the attention half runs on every
         position, the MLP half on the listed ones (per-position arithmetic: the same values there; in training mode the
@@ -597,11 +604,13 @@ class Block(nn.Module):
         cos, sin = self.attn.rope()
         # one dropout probability per block, as in the reference (config.dropout feeds all three nn.Dropout modules)
         p = _active_p(self, self.attn.dropout)
-        seed = _new_seed() if p > 0 else 0
-        self._last_seed = seed if p > 0 else None
+        if p > 0:
+            seed = _new_seed() if seed is None else seed
+        else:
+            seed = 0
         return _BlockFn.apply(x, self.ln_1.weight, self.attn.c_attn.weight, self.attn.c_proj.weight, self.ln_2.weight,
                               self.mlp.c_fc.weight, self.mlp.c_proj.weight, cos, sin, self.attn.n_head, mask, p, seed, out_rows,
-                              below_seed if p > 0 else None)
+                              below_seed if p > 0 else None, handoff if p > 0 else None, index)
 
 
 def _check_rows(rows, total: int, n_blocks: int) -> None:
@@ -697,15 +706,20 @@ class OmniBioTA(nn.Module):
         n_blocks = len(self.transformer.h)
         if rows is not None:
             _check_rows(rows, b * t, n_blocks)
-        below = None   # dropout: the seed of the block just run, handed to the next one (its backward masks dx for the block below)
+        # dropout: the seed of the block just run is handed to the next one, whose backward masks its dx for the block below and
+        # leaves it in this call's hand-off object (nothing of this lives on the modules or in the process)
+        below = None
+        handoff = _GradHandOff()
         for i, block in enumerate(self.transformer.h):
             last_rows = rows if (rows is not None and i == n_blocks - 1) else None
             if self.config.checkpoint_freq > 0 and i % self.config.checkpoint_freq == 0:
                 x = checkpoint(block, x, mask, last_rows, use_reentrant=False)
                 below = None   # (a recomputed block redraws nothing, but keep the hand-off out of checkpointed segments)
             else:
-                x = block(x, attn_mask=mask, out_rows=last_rows, below_seed=below)
-                below = getattr(block, "_last_seed", None)
+                bp = _active_p(block, block.attn.dropout)
+                seed = _new_seed() if bp > 0 else None
+                x = block(x, attn_mask=mask, out_rows=last_rows, below_seed=below, seed=seed, handoff=handoff, index=i)
+                below = seed
         emb = self.transformer.ln_f(x)
         if return_embeddings:
             return emb

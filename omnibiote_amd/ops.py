@@ -470,7 +470,7 @@ def block_fwd(x, params, rope, H, mask: MaskSpec, dropout_p=0.0, dropout_seed=0,
     _need(rope[0], "rope_cos", torch.float32); _need(rope[1], "rope_sin", torch.float32)
     assert rope[0].shape[0] >= T
     y = torch.empty_like(x) if out_rows is None else torch.empty((out_rows.numel(), Cc), dtype=bf16, device=x.device)
-    act = torch.empty(int(L.lib().obte_block_act_bytes(B, T, Cc, H)), dtype=torch.uint8, device=x.device)
+    act = torch.empty(int(L.lib().obte_block_act_bytes_p(B, T, Cc, H, float(dropout_p))), dtype=torch.uint8, device=x.device)
     d = _block_desc(B, T, Cc, H, params, rope, mask, dropout_p, dropout_seed, out_rows=out_rows)
     L.check(L.lib().obte_block_fwd(C.byref(d), _ptr(x), _ptr(y), _ptr(act), _stream()), "obte_block_fwd")
     return y, act

@@ -524,6 +524,9 @@ class TrainStep:
                 if side:
                     self._prev_bwd_done = torch.cuda.current_stream().record_event()
                     self._prev_order_events = self._order.events if self._order is not None else None
+        if input_ids.is_cuda and hasattr(self.model, "_obte_timed_hook"):   # measurement only (comm.TimedHook): the step's last backward ends here
+            self.backward_end_event = torch.cuda.Event(enable_timing=True)
+            self.backward_end_event.record()
         if pipelined:
             for st in self._streams:   # (a no-op after an isolated last pass: that one already waited for them)
                 main.wait_stream(st)
@@ -610,7 +613,8 @@ def flops_per_token(num_model_params: int, n_layer: int, n_embd: int, ctx_len: i
 
 
 def flops_per_token_executed(num_model_params: int, n_layer: int, n_embd: int, ctx_len: int, lm_head_impl: str = "masked",
-                             rows_forward: bool = True, vocab: int = 2 ** 16, masked_fraction: float = 0.15) -> float:
+                             rows_forward: bool = True, vocab: int = 2 ** 16, masked_fraction: float = 0.15,
+                             attention_fraction: float = 1.0) -> float:
     """FLOP per token the step actually EXECUTES: the reference's 6N + 12LCT minus the products the readout form leaves out on
     the (1 - masked_fraction) of the positions the loss multiplies by zero (train_encoder.py:304) — "dense": the two backward
     products of the readout; "masked": all three, and with rows_forward the last block's MLP half (8 C^2 parameters) as well."""
@@ -618,18 +622,31 @@ def flops_per_token_executed(num_model_params: int, n_layer: int, n_embd: int, c
     skipped = {"dense": 4.0 * n_embd * vocab * skip, "dense_full": 0.0, "masked": 6.0 * n_embd * vocab * skip}[lm_head_impl]
     if lm_head_impl == "masked" and rows_forward:
         skipped += 6.0 * 8.0 * n_embd ** 2 * skip
+    # attention_fraction < 1 (rows that pack several documents): the share of the 12 L C T attention term the kernels visit
+    skipped += 12.0 * n_layer * n_embd * ctx_len * (1.0 - attention_fraction)
     return flops_per_token(num_model_params, n_layer, n_embd, ctx_len) - skipped
 
 
-def wrap_ddp(model, device_index: Optional[int], bucket_cap_mb: int = 100):
+def wrap_ddp(model, device_index: Optional[int], bucket_cap_mb: int = 100, grad_exchange: str = "allreduce", timed: bool = False):
     """DDP over RCCL.  Buckets of ~100 MB (a few per all-reduce of small's 470 MB) keep each ring/tree step long
     enough to run at xGMI link rate while still overlapping the tail of backward; gradients are views into the
-    buckets, so the reducer never copies."""
+    buckets, so the reducer never copies.
+    grad_exchange: "allreduce" — DDP's own bucketed all-reduce (train_encoder.py:185 as the reference runs it); "all_links" — the
+    direct reduce-scatter + all-gather of comm.AllLinksHook (every xGMI link of the mesh at once, fp32 fixed-order reduction: SURVEY
+    section 5).  timed: wrap the exchange in comm.TimedHook (per-bucket device events; the wrapper hangs on the returned module as
+    ``_obte_timed_hook``) — measurement only."""
     from torch.nn.parallel import DistributedDataParallel as DDP
+    from . import comm
+    assert grad_exchange in ("allreduce", "all_links"), grad_exchange
     kw = dict(bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, broadcast_buffers=False)
-    if device_index is None:
-        return DDP(model, **kw)
-    return DDP(model, device_ids=[device_index], **kw)
+    ddp = DDP(model, **kw) if device_index is None else DDP(model, device_ids=[device_index], **kw)
+    hook = comm.AllLinksHook() if grad_exchange == "all_links" else (comm.allreduce_mean_hook() if timed else None)
+    if timed and hook is not None:
+        hook = comm.TimedHook(hook)
+        ddp._obte_timed_hook = hook
+    if hook is not None:
+        ddp.register_comm_hook(None, comm.as_ddp_hook(hook, f"obte_{grad_exchange}{'_timed' if timed else ''}_hook"))
+    return ddp
 
 
 def parse_args(argv=None):
@@ -670,6 +687,9 @@ def parse_args(argv=None):
     p.add_argument("--micro_batches_per_pass", type=int, default=1,
                    help="k > 1: k micro-batches of --mini_batch_size rows per forward/backward pass (masks and loss normalisation stay per "
                         "micro-batch: same loss and gradients; +4-6 %% at k = 2-4 on the small config, bench.py chooses it by measurement)")
+    p.add_argument("--grad_exchange", default="allreduce", choices=["allreduce", "all_links"],
+                   help="allreduce: DDP's bucketed all-reduce as the reference runs it; all_links: direct reduce-scatter + all-gather over "
+                        "every xGMI link of the node at once (comm.AllLinksHook; fp32 fixed-order reduction, one rounding)")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="torch.distributed backend: nccl (= RCCL over xGMI, the production path) or gloo (plumbing runs: "
                         "BASELINE config 1; gradients then cross the host)")
@@ -852,7 +872,7 @@ def run(args):
             dist.broadcast_object_list(box, src=0)
             if rank != 0:
                 tune.import_plans(box[0])
-    model = wrap_ddp(m, local if on_gpu else None) if world > 1 else m
+    model = wrap_ddp(m, local if on_gpu else None, grad_exchange=getattr(args, "grad_exchange", "allreduce")) if world > 1 else m
     total_iters = int(args.token_budget / (world * batch_size * args.ctx_len))
     opt, sched = build_optimizer(m, args, total_iters, fused=on_gpu)
     step = TrainStep(model, opt, sched, mini_batch_size=args.mini_batch_size, n_head=args.n_head, use_padding=args.use_padding,
@@ -890,6 +910,8 @@ def run(args):
                 dist.all_reduce(stats)
             if on_gpu:
                 torch.cuda.synchronize()
+                from . import _lib
+                _lib.check_device_status(f"step {i}")   # a kernel that found its own results invalid says so here, not never
             dt = time.time() - t0
             loss, toks = stats[0].item() / world, int(stats[1].item())
             trained += toks

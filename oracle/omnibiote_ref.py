@@ -98,13 +98,17 @@ def apply_rope(x: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
-              mask_add: Optional[torch.Tensor] = None) -> torch.Tensor:
+              mask_add: Optional[torch.Tensor] = None, drop_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(q k^T * scale + mask) v with q,k,v (B, H, T, hs); non-causal
-    (training/model.py:125-145, the 'manual' path; the SDPA path :118-122,134-138 is the same math)."""
+    (training/model.py:125-145, the 'manual' path; the SDPA path :118-122,134-138 is the same math).
+    ``drop_mask`` (optional, (B, H, T, T), 1/(1-p) where kept and 0 where dropped): attn_dropout on the probabilities
+    (model.py:121,129,137,144)."""
     att = (q @ k.transpose(-2, -1)) * scale
     if mask_add is not None:
         att = att + mask_add
     att = torch.softmax(att, dim=-1)
+    if drop_mask is not None:
+        att = att * drop_mask
     return att @ v
 
 
@@ -301,10 +305,22 @@ def hash_weights(cfg: RefConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
 
 
 def block_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], prefix: str, cfg: RefConfig,
-                  rope: torch.Tensor, mask_add: Optional[torch.Tensor]) -> torch.Tensor:
-    """Pre-LN residual block (training/model.py:170-181) with SelfAttention (:98-152) and MLP (:162-168);
-    dropout omitted (parity is stated at dropout 0)."""
+                  rope: torch.Tensor, mask_add: Optional[torch.Tensor], drop: Optional[Tuple[float, int]] = None,
+                  drop_masks=None) -> torch.Tensor:
+    """Pre-LN residual block (training/model.py:170-181) with SelfAttention (:98-152) and MLP (:162-168).
+    Dropout (model.py:83-84,121,151,160,167) is off unless asked for: ``drop = (p, seed)`` applies the product's restated
+    counter-based masks of this block (dropout_scale_mask: sites 1 attention probabilities, 2 attention projection, 3 MLP
+    projection) — PyTorch's own generator stream cannot be reproduced by anybody, so dropout-on parity is stated against the
+    same masks; ``drop_masks = (attn, resid, mlp)`` hands ready-made scale masks over instead (any of them None = none;
+    the CPU baseline of the dropout regime draws them with torch's generator, as the reference does)."""
     B, T, C = x.shape
+    m_attn = m_res = m_mlp = None
+    if drop is not None and drop[0] > 0:
+        m_attn = dropout_scale_mask((B, cfg.n_head, T, T), drop[0], drop[1], 1)
+        m_res = dropout_scale_mask((B, T, C), drop[0], drop[1], 2)
+        m_mlp = dropout_scale_mask((B, T, C), drop[0], drop[1], 3)
+    elif drop_masks is not None:
+        m_attn, m_res, m_mlp = drop_masks
     H = cfg.n_head
     hs = C // H
     h1 = layer_norm(x, p[prefix + "ln_1.weight"])
@@ -313,21 +329,28 @@ def block_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], prefix: str, cfg:
     q = apply_rope(q.reshape(B, T, H, hs), rope).transpose(1, 2)
     k = apply_rope(k.reshape(B, T, H, hs), rope).transpose(1, 2)
     v = v.reshape(B, T, H, hs).transpose(1, 2)
-    y = attention(q, k, v, 8.0 / C, mask_add)  # scale 8/n_embd: training/model.py:119
+    y = attention(q, k, v, 8.0 / C, mask_add, m_attn)  # scale 8/n_embd: training/model.py:119
     y = y.transpose(1, 2).contiguous().view(B, T, C)
-    x = x + F.linear(y, p[prefix + "attn.c_proj.weight"])
+    yo = F.linear(y, p[prefix + "attn.c_proj.weight"])
+    x = x + (yo if m_res is None else yo * m_res)
     h2 = layer_norm(x, p[prefix + "ln_2.weight"])
     a = gelu_erf(F.linear(h2, p[prefix + "mlp.c_fc.weight"]))
-    x = x + F.linear(a, p[prefix + "mlp.c_proj.weight"])
+    mo = F.linear(a, p[prefix + "mlp.c_proj.weight"])
+    x = x + (mo if m_mlp is None else mo * m_mlp)
     return x
 
 
 def model_forward(p: Dict[str, torch.Tensor], cfg: RefConfig, idx: torch.Tensor,
                   mask_add: Optional[torch.Tensor] = None, return_embeddings: bool = False,
-                  rope: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  rope: Optional[torch.Tensor] = None, dropout: Optional[Tuple[float, List[int]]] = None,
+                  torch_dropout_p: float = 0.0) -> torch.Tensor:
     """OmniBioTA.forward (training/model.py:225-254).  ``mask_add`` is the additive (B, 1|H, T, T) mask.
     ``rope`` defaults to what the reference's module would hold: the complex table for fp32 parameters (the
-    reference never calls ``.to(float32)``), the real cos-only table after ``.to(bfloat16)``/``.to(half)``."""
+    reference never calls ``.to(float32)``), the real cos-only table after ``.to(bfloat16)``/``.to(half)``.
+    ``dropout = (p, [embedding seed, block 0's seed, block 1's seed, ...])``: training-mode dropout under the product's restated
+    masks (block_forward; the embedding's is site 0 of its own seed: model.py:204,242).  ``torch_dropout_p``: training-mode dropout
+    with masks from torch's generator at the reference's four sites — what the reference's own CPU step does; used for timing
+    (bench.py's cpu_baseline at the reference's default --dropout 0.1), not for parity."""
     B, T = idx.shape
     assert T <= cfg.block_size
     wte = p["transformer.wte.weight"]
@@ -336,8 +359,19 @@ def model_forward(p: Dict[str, torch.Tensor], cfg: RefConfig, idx: torch.Tensor,
         if wte.dtype != torch.float32:
             rope = cast_rope_table(rope, wte.dtype)
     x = F.embedding(idx, wte)
+    if dropout is not None and dropout[0] > 0:
+        x = x * dropout_scale_mask(tuple(x.shape), dropout[0], dropout[1][0], 0).to(x.device)
+    elif torch_dropout_p > 0:
+        x = F.dropout(x, torch_dropout_p, True)
     for i in range(cfg.n_layer):
-        x = block_forward(x, p, f"transformer.h.{i}.", cfg, rope, mask_add)
+        if torch_dropout_p > 0:   # the reference's bernoulli_ calls (23 % of its CPU step), scale masks of the same shapes
+            keep = 1.0 - torch_dropout_p
+            mk = lambda shape: (torch.empty(shape, dtype=x.dtype, device=x.device).bernoulli_(keep) / keep)   # noqa: E731
+            x = block_forward(x, p, f"transformer.h.{i}.", cfg, rope, mask_add,
+                              drop_masks=(mk((B, cfg.n_head, T, T)), mk(tuple(x.shape)), mk(tuple(x.shape))))
+        else:
+            x = block_forward(x, p, f"transformer.h.{i}.", cfg, rope, mask_add,
+                              drop=None if dropout is None else (dropout[0], dropout[1][1 + i]))
     emb = layer_norm(x, p["transformer.ln_f.weight"])
     if return_embeddings:
         return emb
@@ -398,8 +432,11 @@ class OracleEncoder(nn.Module):
             n -= self.params[0].numel()
         return n
 
+    torch_dropout_p = 0.0   # > 0 (bench.py's cpu_baseline at the reference's default): training-mode dropout, torch's generator
+
     def forward(self, idx, attn_mask=None, return_embeddings=False):
-        return model_forward(self.named_weights(), self.cfg, idx, attn_mask, return_embeddings, rope=self.rope)
+        return model_forward(self.named_weights(), self.cfg, idx, attn_mask, return_embeddings, rope=self.rope,
+                             torch_dropout_p=self.torch_dropout_p if self.training else 0.0)
 
 
 def flops_per_token(cfg: RefConfig, T: int) -> float:

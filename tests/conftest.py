@@ -33,3 +33,17 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _device_status_is_clean(request):
+    """After every GPU test: nothing it launched may have reported a failure through the library's device status word (today: the
+    one-kernel attention backward's hand-off chain giving up) — a set bit is a hard test failure, never a silent wrong gradient.
+    Tests that provoke the failure on purpose read (and clear) the word themselves."""
+    yield
+    if "gpu" not in request.keywords or not _has_gpu():
+        return
+    import torch
+    from omnibiote_amd import _lib
+    torch.cuda.synchronize()
+    _lib.check_device_status(request.node.name)

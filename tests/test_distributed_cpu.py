@@ -243,3 +243,76 @@ def test_product_scheduling_two_ranks_match_one_rank_on_the_concatenated_batch(t
         step(ids, mlm_mask=mlm)
     for a, b in zip(two["w"], ref.parameters()):
         torch.testing.assert_close(a, b.detach(), rtol=1e-7, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------ the all-links gradient exchange (comm.py)
+def _exchange_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from omnibiote_amd import comm
+    from omnibiote_amd import train_encoder as TE
+    res = {}
+    # (a) the hook's arithmetic on raw buckets of awkward sizes, bf16: every rank must end with the same tensor, equal to the
+    #     fixed-order fp32 sum of all ranks' contributions rounded once
+    for n in (1, 63, 64, 1000, 4097):
+        g = torch.Generator().manual_seed(1000 * n + rank)
+        mine = (torch.randn(n, generator=g) * 3).to(torch.bfloat16)
+        alls = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(alls, mine)
+        want = comm.reduce_shards_fixed_order(torch.stack(alls), world, torch.bfloat16)
+
+        class _B:   # the three methods of dist.GradBucket the hooks use
+            def __init__(self, t): self.t = t
+            def buffer(self): return self.t
+            def index(self): return 0
+            def is_last(self): return True
+        got = comm.AllLinksHook()(None, _B(mine.clone())).wait()
+        ref = mine.clone()
+        ref = comm.allreduce_mean_hook()(None, _B(ref)).wait()
+        res[n] = (torch.equal(got, want), (got.float() - ref.float()).abs().max().item(), ref.float().abs().max().item(),
+                  torch.equal(got, ref))
+    # (b) through DDP and the product's TrainStep: all_links against DDP's own all-reduce, fp32 oracle model
+    outs = {}
+    for ex in ("allreduce", "all_links"):
+        torch.manual_seed(0)
+        R, cfg, enc = _make(CFG)
+        model = TE.wrap_ddp(enc, None, bucket_cap_mb=1, grad_exchange=ex)
+        opt = torch.optim.AdamW(enc.parameters(), lr=1e-2)
+        step = TE.TrainStep(model, opt, None, mini_batch_size=2, n_head=cfg.n_head, loss_impl="torch", mask_impl="dense")
+        ids = _batch(4 * world, 32, 128, seed=7)
+        mine_rows = ids[rank * 4:(rank + 1) * 4]
+        losses = []
+        for s in range(3):
+            np.random.seed(50 + s)
+            losses.append(step(mine_rows)["loss"].item())
+        outs[ex] = (losses, [p.detach().clone() for p in enc.parameters()])
+    if rank == 0:
+        torch.save({"raw": res, "ddp": outs}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 4])
+def test_all_links_exchange_equals_the_bucketed_all_reduce(tmp_path, world):
+    """comm.AllLinksHook (reduce-scatter + all-gather that drives every link of the mesh, one all_to_all + one
+    all_gather per bucket, the reduction done in fp32 in rank order and rounded once) against DDP's bucketed all-reduce
+    (training/train_encoder.py:185).  On raw bf16 buckets of ragged sizes: the result is exactly the fixed-order fp32 mean on every
+    rank; at world 2 that is ALSO bit for bit the all-reduce's result (a sum of two has one order and one rounding), at world 4 the
+    ring's per-hop bf16 roundings move it by at most a few units in the last place.  Through DDP + TrainStep (fp32 oracle
+    model, three optimizer steps): the two exchanges give the same losses and the same weights to fp32 reduction-order noise."""
+    out = os.path.join(str(tmp_path), "x.pt")
+    mp.spawn(_exchange_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r = torch.load(out, weights_only=False)
+    for n, (exact, diff, scale, same) in r["raw"].items():
+        assert exact, f"bucket of {n}: not the fixed-order fp32 mean"
+        if world == 2:
+            assert same, f"bucket of {n}: differs from the all-reduce at world 2"
+        else:
+            assert diff <= 2.0 ** -6 * max(scale, 1e-3), (n, diff, scale)   # <= 2 bf16 units in the last place of the largest value
+    (la, wa), (lb, wb) = r["ddp"]["allreduce"], r["ddp"]["all_links"]
+    np.testing.assert_allclose(la, lb, rtol=1e-6)
+    for x, y in zip(wa, wb):
+        torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-4)

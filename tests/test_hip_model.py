@@ -803,13 +803,24 @@ def test_dropout_masked_gradient_handoff_between_blocks(monkeypatch):
         assert torch.equal(out["1"][1][k], out["0"][1][k]), k
 
 
-def test_two_train_steps_on_two_models_in_two_threads_share_no_state():
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_two_train_steps_on_two_models_in_two_threads_share_no_state(monkeypatch, p_drop):
     """The backward switches (in-place accumulation, fp32 LayerNorm partials, the embedding sort order) belong to the
     TrainStep that built the graph: each autograd node captures them at forward time (model.GradPolicy on ctx), the fp32
-    partial buffers live in the step object.  Two steps on two different models running CONCURRENTLY in two threads of one
-    process must each produce, bit for bit, what they produce alone."""
+    partial buffers live in the step object; with dropout on, the masked gradient handed from block to block travels in an object
+    of the forward call that made the graph (model._GradHandOff — rounds 3-4 kept it in a process-wide table) and the seed handed
+    to the block above is a local of that call.  Two steps on two different models running CONCURRENTLY in two threads of one
+    process must each produce, bit for bit, what they produce alone.  (Dropout seeds come from torch's process-wide CPU generator,
+    whose draws two threads would interleave: for this test each thread draws from a counter of its own.)"""
     import threading
+    from omnibiote_amd import model as M
     from omnibiote_amd import train_encoder as TE
+    tl = threading.local()
+
+    def thread_seed():
+        tl.n = getattr(tl, "n", 0) + 1
+        return (tl.base * 1000003 + tl.n * 7919) % (2 ** 62)
+    monkeypatch.setattr(M, "_new_seed", thread_seed)
     C, H, Lyr, V, T, rows, mini = 128, 2, 2, 512, 64, 24, 4          # 6 micro-batches: accumulate + LN partial modes 1/2/3 all occur
     problems = []
     for seed in (0, 1):
@@ -822,7 +833,11 @@ def test_two_train_steps_on_two_models_in_two_threads_share_no_state():
     def run(i, out, barrier=None):
         w, ids, mlm = problems[i]
         torch.cuda.set_device(0)
+        tl.base, tl.n = 17 + i, 0
         m = _tiny_model(w, C, H, Lyr, V, T)
+        if p_drop > 0:
+            TE.set_dropout(m, p_drop)
+            m.train()
         step = TE.TrainStep(m, TE.FusedAdamW(m.parameters(), lr=1e-3), None, mini_batch_size=mini, n_head=H)
         losses = []
         with torch.cuda.stream(torch.cuda.Stream()):

@@ -266,6 +266,71 @@ def test_attention_fwd_bwd(hs, T, mode):
     close(dqkv, dref, atol=1.5e-2, rtol=2.0 ** -6, what=f"attn bwd {mode}")
 
 
+def test_attention_backward_hand_off_failure_is_reported_not_silent():
+    """A wait of the one-kernel backward's dQ hand-off chain that gives up must be a hard failure the host sees: the kernel ORs
+    OBTE_STATUS_ATTN_BWD_HANDOFF into the library's device status word (pinned host memory) and obte_device_status / the Python
+    check raise at the next synchronising point.  Forced here through the test hook obte_fault_inject(1): the counter of slice 0
+    of (batch 0, head 0) is never added to and waits give up after 2^10 polls instead of 2^20.  Before and after, the same call
+    is clean and bitwise reproducible (the word is sticky until read, then cleared; a failure leaves no state behind)."""
+    from omnibiote_amd import _lib as L
+    B, H, T, hs = 1, 2, 1024, 128
+    C = H * hs
+    scale = 8.0 / C
+    qkv, q, k, v = _attn_case(B, T, H, hs, seed=11)
+    d_o = rnd(B, T, C, seed=12)
+    o = ops()
+    got, lse = o.attn_fwd(qkv.to(DEV), B, T, H, hs, scale, None)
+    good = o.attn_bwd(qkv.to(DEV), got, d_o.to(DEV), lse, B, T, H, hs, scale, None)
+    torch.cuda.synchronize()
+    assert L.lib().obte_device_status(0) == 0
+    prev = L.lib().obte_fault_inject(1)
+    try:
+        o.attn_bwd(qkv.to(DEV), got, d_o.to(DEV), lse, B, T, H, hs, scale, None)
+        torch.cuda.synchronize()
+    finally:
+        L.lib().obte_fault_inject(prev)
+    assert L.lib().obte_device_status(0) & L.STATUS_ATTN_BWD_HANDOFF, "the timed-out hand-off went unreported"
+    with pytest.raises(L.DeviceStatusError, match="hand-off"):
+        L.check_device_status("forced failure")
+    assert L.lib().obte_device_status(0) == 0                     # read once, cleared
+    again = o.attn_bwd(qkv.to(DEV), got, d_o.to(DEV), lse, B, T, H, hs, scale, None)
+    torch.cuda.synchronize()
+    L.check_device_status("after the forced failure")
+    assert torch.equal(good, again)
+
+
+def test_attention_backward_one_kernel_under_contention_keeps_its_chain():
+    """The regime the hand-off's forward progress was questioned in: 32 rows x 8 heads at T = 1024 = 1024
+    workgroups of one (4 x the CUs), launched on two streams at once while a third stream holds CUs with a long-running
+    kernel of its own.  Every launch must finish with a clean status word and give, bit for bit, what it gives alone."""
+    from omnibiote_amd import _lib as L
+    B, H, T, hs = 32, 8, 1024, 128
+    C = H * hs
+    scale = 8.0 / C
+    g = torch.Generator(device=DEV).manual_seed(3)
+    qkv = torch.randn(B, T, 3 * C, device=DEV, generator=g).to(BF)
+    d_o = (torch.randn(B, T, C, device=DEV, generator=g) * 0.1).to(BF)
+    o = ops()
+    out, lse = o.attn_fwd(qkv, B, T, H, hs, scale, None)
+    alone = o.attn_bwd(qkv, out, d_o, lse, B, T, H, hs, scale, None)
+    torch.cuda.synchronize()
+    L.check_device_status("alone")
+    s1, s2, s3 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    big = torch.randn(8192, 8192, device=DEV, dtype=torch.float32)
+    res = {}
+    for rep in range(2):
+        with torch.cuda.stream(s3):                              # a CU hog of another kind (fp32 matmuls: long-running workgroups)
+            for _ in range(6):
+                big = big @ big * 1e-4
+        for name, st in (("a", s1), ("b", s2)):
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    res[name] = o.attn_bwd(qkv, out, d_o, lse, B, T, H, hs, scale, None)
+        torch.cuda.synchronize()
+        L.check_device_status(f"contended launches, round {rep}")
+        assert torch.equal(res["a"], alone) and torch.equal(res["b"], alone)
+
+
 @pytest.mark.parametrize("T,mode", [(600, "ranges"), (600, "none"), (1024, "ranges"), (333, "ranges")])
 def test_attention_backward_one_kernel_form(T, mode):
     """The one-kernel backward (head size 128, key ranges or no mask, no dropout; csrc/attention_bwd_fused.hip) over several

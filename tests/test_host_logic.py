@@ -277,32 +277,39 @@ def test_tuner_lists_the_192_wide_and_the_persistent_structure_only_where_they_a
     assert (5, 128, 1) not in tune.candidates(8200, 4096, 1024, L.EPI_NONE, True, True)        # ragged rows
 
 
-def test_masked_gradient_handoff_table_checks_storage_shape_probability_and_seed(monkeypatch):
-    """model._masked_grad_put / _take (dropout: a block's dx under the mask of the block below): the entry is taken only by the
-    gradient tensor it was stored for, with the taker's own probability and seed; anything else gets None (and the block masks
-    its own gradient); the switch OBTE_DROPOUT_HANDOFF=0 turns the hand-off off; the table stays small."""
+def test_masked_gradient_handoff_checks_storage_shape_version_probability_and_seed(monkeypatch):
+    """model._GradHandOff (dropout: a block's dx under the mask of the block below; one object per forward call, nothing global):
+    an entry is taken only by the gradient tensor it was stored for, untouched since (its version counter: an in-place
+    accumulation of a second contribution or a hook editing the gradient bump it), with the taker's own probability and seed;
+    anything else gets None (and the block masks its own gradient); OBTE_DROPOUT_HANDOFF=0 turns the hand-off off; two
+    objects never see each other's entries."""
     from omnibiote_amd import model as M
-    M._masked_grad.clear()
+    assert not hasattr(M, "_masked_grad")            # the process-wide table of rounds 3-4 is gone
+    h = M._GradHandOff()
     dx, dxm = torch.zeros(4, 8), torch.ones(4, 8)
-    M._masked_grad_put(dx, dxm, 0.1, 77)
-    assert M._masked_grad_take(torch.zeros(4, 8), (0.1, 77)) is None        # another tensor
-    assert M._masked_grad_take(dx, (0.1, 78)) is None                       # (taken out by the mismatch: the block masks dy itself)
-    M._masked_grad_put(dx, dxm, 0.1, 77)
-    assert M._masked_grad_take(dx, (0.2, 77)) is None
-    M._masked_grad_put(dx, dxm, 0.1, 77)
-    assert M._masked_grad_take(dx.view(8, 4), (0.1, 77)) is None            # same storage, another shape
-    M._masked_grad_put(dx, dxm, 0.1, 77)
-    assert M._masked_grad_take(dx, (0.1, 77)) is dxm and M._masked_grad_take(dx, (0.1, 77)) is None   # consumed once
-    M._masked_grad_put(dx, None, 0.1, 77)
-    assert not M._masked_grad
-    keep = [torch.zeros(2, 2) for _ in range(20)]
-    for t in keep:
-        M._masked_grad_put(t, torch.ones(2, 2), 0.1, 1)
-    assert len(M._masked_grad) <= 8
+    h.put(3, dx, dxm, 0.1, 77)
+    assert h.take(2, dx, (0.1, 77)) is None                                  # another block's slot
+    assert h.take(3, torch.zeros(4, 8), (0.1, 77)) is None                   # another tensor (and the entry is consumed)
+    assert h.take(3, dx, (0.1, 77)) is None
+    h.put(3, dx, dxm, 0.1, 77)
+    assert h.take(3, dx, (0.1, 78)) is None                                  # another seed
+    h.put(3, dx, dxm, 0.1, 77)
+    assert h.take(3, dx, (0.2, 77)) is None                                  # another probability
+    h.put(3, dx, dxm, 0.1, 77)
+    assert h.take(3, dx.view(8, 4), (0.1, 77)) is None                       # same storage, another shape
+    h.put(3, dx, dxm, 0.1, 77)
+    dx.add_(1.0)                                                             # what autograd's InputBuffer does with a second contribution
+    assert h.take(3, dx, (0.1, 77)) is None
+    h.put(3, dx, dxm, 0.1, 77)
+    assert h.take(3, dx, (0.1, 77)) is dxm and h.take(3, dx, (0.1, 77)) is None   # consumed once
+    h.put(3, dx, None, 0.1, 77)
+    assert not h.slots
+    other = M._GradHandOff()
+    h.put(1, dx, dxm, 0.1, 5)
+    assert other.take(1, dx, (0.1, 5)) is None and h.take(1, dx, (0.1, 5)) is dxm   # per forward call, not per process
     monkeypatch.setenv("OBTE_DROPOUT_HANDOFF", "0")
-    M._masked_grad_put(dx, dxm, 0.1, 77)
-    assert M._masked_grad_take(dx, (0.1, 77)) is None
-    M._masked_grad.clear()
+    h.put(3, dx, dxm, 0.1, 77)
+    assert h.take(3, dx, (0.1, 77)) is None
 
 
 def test_forward_rows_contract_is_checked_on_the_host():
@@ -315,3 +322,33 @@ def test_forward_rows_contract_is_checked_on_the_host():
     for bad in (torch.zeros(3, dtype=torch.int32), torch.zeros((2, 2), dtype=torch.int64), [0, 1], torch.zeros(3, dtype=torch.int64)):
         with pytest.raises(ValueError):
             _check_rows(bad, 16, 1)   # the last one: a CPU tensor (the model lives on the GPU)
+
+
+def test_attention_backward_workspace_is_zero_where_the_one_kernel_form_does_not_apply():
+    """obte_attn_bwd_ws_bytes answers 0 — "allocate nothing, the two-kernel form runs" — wherever the one-kernel backward does not
+    apply (other head sizes, more than 256 query slices, rows whose byte offsets pass 32 bits), never a sentinel a caller would
+    hand to an allocator; the block's backward workspace, which contains it, stays a sane number at long contexts (ctx_len is a
+    free argument of the reference: train_encoder.py:444)."""
+    lib = _lib.lib()
+    assert lib.obte_attn_bwd_ws_bytes(8, 1024, 8, 128) > 0
+    assert lib.obte_attn_bwd_ws_bytes(8, 8192, 8, 128) > 0
+    assert lib.obte_attn_bwd_ws_bytes(1, 16384, 8, 128) == 0        # 512 slices: the pair of kernels
+    assert lib.obte_attn_bwd_ws_bytes(1, 8224, 8, 128) == 0
+    assert lib.obte_attn_bwd_ws_bytes(8, 1024, 8, 64) == 0
+    assert lib.obte_attn_bwd_ws_bytes(0, 1024, 8, 128) == 0
+    small = lib.obte_block_bwd_ws_bytes(1, 8192, 1024, 8)
+    for T in (16384, 32768):
+        b = lib.obte_block_bwd_ws_bytes(1, T, 1024, 8)
+        assert 0 < b < (1 << 36), b
+        assert b < 8 * small * (T // 8192)                          # grows with the activations, not with a sentinel
+
+
+def test_block_activation_buffer_leaves_out_the_dropout_keep_bits_without_dropout():
+    """obte_block_act_bytes_p(p = 0) ends before the attention dropout's keep bits (B H ceil(T/32) T words — 134 MB per block at
+    B = 8, T = 4096); with p > 0 it is obte_block_act_bytes."""
+    lib = _lib.lib()
+    for B, T, C, H in ((8, 1024, 1024, 8), (8, 4096, 1024, 8), (2, 1024, 2048, 16)):
+        full, bits = lib.obte_block_act_bytes(B, T, C, H), lib.obte_attn_drop_bits_bytes(B, T, H)
+        assert lib.obte_block_act_bytes_p(B, T, C, H, 0.1) == full
+        lean = lib.obte_block_act_bytes_p(B, T, C, H, 0.0)
+        assert full - lean == (bits + 255) // 256 * 256 and lean > 0
