@@ -22,105 +22,17 @@
 // tile is staged through LDS and written in 16-B pieces of full 128-B row segments, applying the epilogue.
 // Split-K (for weight gradients whose output has fewer tiles than the chip has CUs): each split writes an fp32
 // partial tile to a slab; a second kernel sums the splits in a fixed order (bitwise reproducible) and rounds once.
-#include "common.h"
+#include "gemm_common.h"
 #include <string.h>
 
 int obte_gemm_bf16_v1(const obte_gemm_args* g, obte_stream s);
+// structure 7 (gemm_bf16_v7.hip): which (layout, epilogue) combinations it is instantiated for, whether a problem can run on it, its launch
+namespace obte_gemm_v2 { struct GemmParams; }
+bool obte_gemm_v7_has(bool a_kmajor, bool b_kmajor, int epilogue);
+bool obte_gemm_v7_eligible(const obte_gemm_args* g);
+int obte_gemm_v7_launch(const obte_gemm_v2::GemmParams& p, bool a_kmajor, bool b_kmajor, int epilogue, hipStream_t st);
 
 namespace obte_gemm_v2 {
-
-constexpr int BM = 256, BKT = 64;
-constexpr int NTHREADS = 512;
-constexpr int A_TILE = BM * BKT * 2;            // 32 KiB
-// Two tile widths.  BN = 128: 48 KiB per stage, 3-stage ring (loads two K-tiles ahead) — used where the grid
-// would otherwise not fill the chip (N = 1024 outputs).  BN = 256: 64 KiB per stage, two stages — 131 FLOP per
-// loaded byte instead of 87; a CU pulls ~70 GB/s from its L2 and ~25-30 GB/s from beyond it (measured), and at
-// ~8 TFLOP/s per CU a 256x128 tile needs 94 GB/s: the wide tile is what keeps the MFMAs fed.
-template <int BN> struct Cfg {
-    static constexpr int B_TILE = BN * BKT * 2;
-    static constexpr int STAGE = A_TILE + B_TILE;
-    static constexpr int NSTAGE = BN == 128 ? 3 : 2;
-    static constexpr int EPI_BYTES = 8 * 64 * 272;       // epilogue staging: 8 waves x 64 rows x (<=128 bf16 | 64 f32, + pad)
-    static constexpr int SMEM = NSTAGE * STAGE > EPI_BYTES ? NSTAGE * STAGE : EPI_BYTES;   // 144 KiB / 136 KiB: one workgroup per CU
-    static constexpr int NPB = BN / 64;                  // LDS-DMA pieces per wave for the B tile (A: 4); BN = 192: 3
-    static constexpr int NJ = BN / 32;                   // 16-wide n sub-tiles per wave (wave tile 64 x BN/2)
-};
-constexpr int EPI_LD_F32 = 272;                 // bytes per staged f32 row: 64 f32 + 16 B pad
-
-struct GemmParams {
-    const bf16* a; const bf16* b; bf16* d; const bf16* aux; bf16* d2; float* slab;
-    int64_t M, N, K, lda, ldb, ldd;
-    int64_t store_rows;   // = M; 0 in the timing-only 'nostore' diagnostic
-    int nt_store;         // non-temporal output stores (outputs that exceed the 256-MiB Infinity Cache)
-    int delay_sleeps;     // debug build only: every second workgroup of a CU (odd hardware wave slot) sleeps this many x 3.4 us first
-    unsigned long long* dbg_times;   // debug build only (OBTE_GEMM_TIMES=1): per workgroup, s_memrealtime at entry / first operands landed / loop end / stores issued / stores done
-    int64_t a_elems, b_elems;
-    int tiles_m, tiles_n, splits, k_per_split;   // k_per_split in K-tiles
-    float alpha;
-    DropCfg drop;
-    const float* rope_cos; const float* rope_sin; int64_t rope_T; int rope_hs;
-};
-
-#ifdef OBTE_DEBUG_HOOKS
-#define OBTE_GSTAMP(p, k) do { if ((p).dbg_times && threadIdx.x == 0) (p).dbg_times[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define OBTE_GSTAMP(p, k) do { } while (0)
-#endif
-__device__ __forceinline__ int kmaj_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-__device__ __forceinline__ int mn_f(int krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
-template <int ROWB>
-__device__ __forceinline__ int mnmaj_off(int krow, int chunk) { return krow * ROWB + ((chunk ^ mn_f(krow)) << 4); }
-
-// byte offsets, relative to the tile origin, of the LDS-DMA pieces this lane issues (piece = wave + 8*i)
-template <bool KMAJOR, int MN, int NP>
-__device__ __forceinline__ void dma_offsets(int wave, int lane, int64_t ld, int (&voff)[NP]) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int piece = wave + 8 * i;  // 1 KiB of the image
-        if (KMAJOR) {
-            const int row = piece * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-            voff[i] = (int)((row * ld + chunk * 8) * 2);
-        } else {
-            constexpr int CPR = MN / 8;          // 16-B chunks per k-row: 32 (A) or 16 (B)
-            constexpr int RPP = 64 / CPR;        // k-rows per 1-KiB piece: 2 or 4
-            const int krow = piece * RPP + lane / CPR;
-            const int chunk = (lane % CPR) ^ mn_f(krow);
-            voff[i] = (int)((krow * ld + chunk * 8) * 2);
-        }
-    }
-}
-
-template <int NP>
-__device__ __forceinline__ void dma_tile(const bf16* origin, int64_t elems_left, const int (&voff)[NP], char* lds_tile, int wave) {
-#ifdef OBTE_DMA_BUILTIN
-    __amdgpu_buffer_rsrc_t rsrc = make_rsrc(origin, elems_left * 2);
-#pragma unroll
-    for (int i = 0; i < NP; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + (wave + 8 * i) * 1024), 16, voff[i], 0, 0, 0);
-#else
-    const i32x4_t rsrc = make_rsrc_words(origin, elems_left * 2);
-    const uint32_t base = lds_addr_of(lds_tile) + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) lds_dma16(rsrc, base + 8 * i * 1024, voff[i]);
-#endif
-}
-
-// 16 (m or n) x 32 (k) fragment for v_mfma_f32_16x16x32_bf16: lane l holds index (l&15), k = 8*(l>>4)+j.
-template <bool KMAJOR, int MN>
-__device__ __forceinline__ bf16x8 load_frag(const char* tile, int mn0, int s, int lane) {
-    if (KMAJOR) {
-        return *reinterpret_cast<const bf16x8*>(tile + kmaj_off(mn0 + (lane & 15), 4 * s + (lane >> 4)));
-    } else {
-        const int li = lane & 15;
-        const int krow = 32 * s + 8 * (lane >> 4) + (li >> 2);
-        const int chunk = (mn0 >> 3) + ((li & 3) >> 1);
-        const int sub = (li & 1) * 8;
-        const bf16x4 lo = lds_read_tr16(tile + mnmaj_off<MN * 2>(krow, chunk) + sub);
-        const bf16x4 hi = lds_read_tr16(tile + mnmaj_off<MN * 2>(krow + 4, chunk) + sub);
-        return join8(lo, hi);
-    }
-}
 
 // Tile epilogue shared by both main-loop structures: stage the accumulators through LDS, apply EPI, write 16-B pieces.
 template <int EPI, bool SPLIT, int BN>
@@ -673,136 +585,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v5_kernel(GemmParams p) {
 OBTE_INST5(true, true) OBTE_INST5(true, false)
 #undef OBTE_INST5
 
-// ---- structure 6: 256 x 256 tile, FOUR waves (one per SIMD), 128 x 128 per wave, accumulators in AGPRs ---------------------------
-// One wave per SIMD has the SIMD's whole register file: the 64 accumulator quads (256 registers) live in AGPRs through asm MFMAs
-// with "+a" operands, the VGPRs hold double-buffered fragments — and, in the persistent form, the previous tile's output on its
-// way out.  Per k-step of 32 a wave reads 16 fragments for 64 MFMAs (the eight-wave structures: 12 for 32), i.e. 2/3 of their LDS
-// traffic per FLOP.  K-tile ring of two 64-KiB stages as in the 256-wide structure 2; x W^T layouts (k-contiguous A and B).
-constexpr int V6_THREADS = 256;
-constexpr int V6_STAGE = 2 * BM * BKT * 2;            // 64 KiB: A 256 x 64, B 256 x 64
-constexpr int V6_LDE = 128 * 2 + 16;                   // staged row of the 128-wide wave tile
-constexpr int V6_SMEM = 4 * 128 * V6_LDE > 2 * V6_STAGE ? 4 * 128 * V6_LDE : 2 * V6_STAGE;   // 136 KiB
-__device__ __forceinline__ void mfma16_acc(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-    asm volatile("s_nop 0\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-template <int EPI>
-__global__ __launch_bounds__(V6_THREADS, 1) void gemm_v6_kernel(GemmParams p) {
-    constexpr int BN = 256;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int tid_ = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int group_sz = 8 * p.tiles_n;
-    const int first_m = (tid_ / group_sz) * 8;
-    const int gsz = min(p.tiles_m - first_m, 8);
-    const int tm = first_m + (tid_ % group_sz) % gsz;
-    const int tn = (tid_ % group_sz) / gsz;
-    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-    // LDS-DMA pieces of 1 KiB (8 rows x 128 B of a k-contiguous tile): piece = wave + 4 i, i < 8, per operand
-    int voff_a[8], voff_b[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = (wave + 4 * i) * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        voff_a[i] = (int)((row * p.lda + chunk * 8) * 2);
-        voff_b[i] = (int)((row * p.ldb + chunk * 8) * 2);
-    }
-    const int wm = wave >> 1, wn = wave & 1;
-    f32x4 acc[8][8];   // [ni][mi]: C^T quads, row = n, col = m
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nk = (int)((p.K + BKT - 1) / BKT);
-    auto issue = [&](int t, int stage) {
-        const int64_t k0 = (int64_t)t * BKT;
-        const int64_t ao = m0 * p.lda + k0, bo = n0 * p.ldb + k0;
-        const i32x4_t ra = make_rsrc_words(p.a + ao, (p.a_elems - ao) * 2), rb = make_rsrc_words(p.b + bo, (p.b_elems - bo) * 2);
-        const uint32_t base = lds_addr_of(smem + stage * V6_STAGE) + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) lds_dma16(ra, base + 4 * i * 1024, voff_a[i]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) lds_dma16(rb, base + A_TILE + 4 * i * 1024, voff_b[i]);
-    };
-    auto load_a = [&](int t, int ks, bf16x8 (&af)[8]) {
-        const char* ta = smem + (t & 1) * V6_STAGE;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = load_frag<true, BM>(ta, wm * 128 + i * 16, ks, lane);
-    };
-    auto load_b = [&](int t, int ks, bf16x8 (&bfr)[8]) {
-        const char* tb = smem + (t & 1) * V6_STAGE + A_TILE;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) bfr[i] = load_frag<true, BN>(tb, wn * 128 + i * 16, ks, lane);
-    };
-    auto mma = [&](const bf16x8 (&af)[8], const bf16x8 (&bfr)[8]) {
-#pragma unroll
-        for (int ni = 0; ni < 8; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) mfma16_acc(acc[ni][mi], bfr[ni], af[mi]);
-    };
-    bf16x8 a0[8], b0[8], a1[8], b1[8];
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    load_a(0, 0, a0); load_b(0, 0, b0);
-    for (int t = 0; t + 1 < nk; ++t) {
-        load_a(t, 1, a1); load_b(t, 1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // K-tile t + 1 has landed; this wave's reads of tile t are in registers
-        __builtin_amdgcn_s_barrier();
-        load_a(t + 1, 0, a0); load_b(t + 1, 0, b0);
-        if (t + 2 < nk) issue(t + 2, t & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    load_a(nk - 1, 1, a1); load_b(nk - 1, 1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(a0, b0);
-    mma(a1, b1);
-
-    // ---- epilogue: accumulators -> per-wave staging (128 rows x 128 bf16) -> 16-byte row chunks -> global --------------------
-    __syncthreads();
-    const int em = lane & 15, en = (lane >> 4) * 4;
-    char* stg = smem + wave * (128 * V6_LDE);
-#pragma unroll
-    for (int ni = 0; ni < 8; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            bf16x4 v;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) v[rr] = f2bf(acc[ni][mi][rr] * p.alpha);
-            *reinterpret_cast<bf16x4*>(stg + (mi * 16 + em) * V6_LDE + (ni * 16 + en) * 2) = v;
-        }
-    __syncthreads();
-    const int64_t o_l = (m0 + wm * 128 + lane / 16) * p.ldd + n0 + wn * 128 + (lane % 16) * 8;
-#pragma unroll
-    for (int it = 0; it < 32; ++it) {
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + (4 * it + lane / 16) * V6_LDE + (lane % 16) * 16);
-        const int64_t o = o_l + (int64_t)it * 4 * p.ldd;
-        if (EPI == OBTE_EPI_GELU) {
-            bf16x8 g;
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                f32x2_t act, der;
-                gelu_ref_both2(f32x2_t{bf2f(v[j]), bf2f(v[j + 1])}, act, der);
-                g[j] = f2bf(act[0]); g[j + 1] = f2bf(act[1]);
-                v[j] = f2bf(der[0]); v[j + 1] = f2bf(der[1]);
-            }
-            *reinterpret_cast<bf16x8*>(p.d2 + o) = g;
-        }
-        *reinterpret_cast<bf16x8*>(p.d + o) = v;
-    }
-}
-template __global__ void gemm_v6_kernel<OBTE_EPI_NONE>(GemmParams);
-template __global__ void gemm_v6_kernel<OBTE_EPI_GELU>(GemmParams);
-
 // Explicit instantiations: with implicit instantiation alone hipcc (ROCm 7.2) emitted the host stub of only the
 // first specialisation it met; the library then failed to load with undefined kernel symbols.
 #define OBTE_INST(AK, BK, BN)                                                                    \
@@ -841,39 +623,6 @@ OBTE_INST192(OBTE_EPI_NONE) OBTE_INST192(OBTE_EPI_GELU) OBTE_INST192(OBTE_EPI_AD
 // front of every transposing LDS read, i.e. drained the whole ring at each half-step for the k-strided layouts.
 // k-contiguous half image: [256 rows][32 k], 64-B rows, chunk c of row r at c ^ ((4 - (r>>2)) & 3) (conflict-free
 // ds_read_b128 for the 16x32 fragment); k-strided half image: [32 k][256], as above.
-constexpr int H_TILE = BM * 32 * 2;             // 16 KiB per operand per half-stage
-constexpr int H_STAGE = 2 * H_TILE;             // 32 KiB
-constexpr int V3_RING = 4 * H_STAGE;            // 128 KiB
-constexpr int V3_SMEM = V3_RING > Cfg<256>::EPI_BYTES ? V3_RING : Cfg<256>::EPI_BYTES;
-
-__device__ __forceinline__ int kmaj32_off(int row, int chunk) { return row * 64 + ((chunk ^ ((4 - (row >> 2)) & 3)) << 4); }
-
-template <bool KMAJOR>
-__device__ __forceinline__ void dma_offsets_h(int wave, int lane, int64_t ld, int (&voff)[2]) {
-    if (KMAJOR) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (wave + 8 * i) * 16 + (lane >> 2);
-            const int chunk = (lane & 3) ^ ((4 - (row >> 2)) & 3);
-            voff[i] = (int)((row * ld + chunk * 8) * 2);
-        }
-    } else {
-        dma_offsets<false, 256, 2>(wave, lane, ld, voff);   // 32 k-rows x 512 B = pieces 0..15
-    }
-}
-
-template <bool KMAJOR>
-__device__ __forceinline__ bf16x8 load_frag_h(const char* tile, int mn0, int lane) {
-    if (KMAJOR) return *reinterpret_cast<const bf16x8*>(tile + kmaj32_off(mn0 + (lane & 15), lane >> 4));
-    return load_frag<false, 256>(tile, mn0, 0, lane);
-}
-
-// bijective XCD remap: workgroups that land on one XCD (bid % 8) get a contiguous range of work ids
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-}
-
 // one 256x256 tile (or K-split of it) of problem p; wgid in [0, tiles_m * tiles_n * splits)
 template <bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPLIT>
 __device__ __forceinline__ void v3_tile(const GemmParams& p, const int wgid, char* smem) {
@@ -1418,21 +1167,6 @@ int dispatch5(const GemmParams& p, int epi, hipStream_t st) {
     obte_set_error("obte_gemm_bf16: epilogue %d has no persistent form", epi);
     return OBTE_EINVAL;
 }
-template <int EPI>
-int launch6(const GemmParams& p, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_v6_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, V6_SMEM);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_v6_kernel<EPI>), dim3(p.tiles_m * p.tiles_n), dim3(V6_THREADS), V6_SMEM, st, p);
-    OBTE_CHECK_LAUNCH("obte_gemm_bf16");
-    return OBTE_OK;
-}
-static bool v6_eligible(const obte_gemm_args* g) {
-    return g->a_kmajor && g->b_kmajor && g->M % BM == 0 && g->N % 256 == 0 && g->K % BKT == 0 && g->K >= 2 * BKT &&
-           (g->epilogue == OBTE_EPI_NONE || g->epilogue == OBTE_EPI_GELU);
-}
 // the persistent structure takes whole 256 x 128 tiles of k-contiguous A, at least two per workgroup, ten K-tiles or more
 static bool v5_eligible(const obte_gemm_args* g) {
     if (!g->b_kmajor) { const char* e = getenv("OBTE_GEMM_V5_NN"); if (!(e && e[0] == '1')) return false; }   // (B not k-contiguous: the build spills; opt-in for experiments)
@@ -1502,8 +1236,9 @@ static bool lookup_plan(const obte_gemm_args* g, Plan* out, bool* near_match = n
 
 extern "C" int obte_gemm_plan_set(int a_kmajor, int b_kmajor, int epilogue, int64_t M, int64_t N, int64_t K, int variant,
                                   int bn, int splits) {
-    OBTE_REQUIRE(variant >= 1 && variant <= 6 && (bn == 128 || bn == 256 || bn == 192) && splits >= 1 && splits <= 64, "obte_gemm_plan_set: bad plan");
-    OBTE_REQUIRE(!(variant == 6 && (bn != 256 || splits != 1 || !a_kmajor || !b_kmajor)), "obte_gemm_plan_set: the four-wave structure is 256 wide, k-contiguous operands, no split-K");
+    OBTE_REQUIRE(variant >= 1 && variant <= 7 && variant != 6 && (bn == 128 || bn == 256 || bn == 192) && splits >= 1 && splits <= 64, "obte_gemm_plan_set: bad plan");
+    OBTE_REQUIRE(!(variant == 7 && (bn != 256 || splits != 1 || !obte_gemm_v7_has(a_kmajor != 0, b_kmajor != 0, epilogue))),
+                 "obte_gemm_plan_set: the persistent continuous-ring structure is 256 wide, no split-K, x W^T and dy W layouts with their epilogues");
     OBTE_REQUIRE(!(variant == 5 && (bn != 128 || splits != 1 || !a_kmajor)), "obte_gemm_plan_set: the persistent structure is 128 wide, k-contiguous A, no split-K");
     OBTE_REQUIRE(!(bn == 192 && (variant != 2 || splits != 1 || !a_kmajor || !b_kmajor || epilogue == OBTE_EPI_GELU_BWD)),
                  "obte_gemm_plan_set: the 192-wide tile exists for the K-tile ring, k-contiguous operands, no split-K");
@@ -1658,7 +1393,7 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     if (pl.splits > 1 && (!can_split || (int64_t)pl.splits * g->M * g->N * 4 > workspace_bytes)) pl = make_plan(g->M, g->N, g->K, false);
     if (pl.bn == 192 && !(g->a_kmajor && g->b_kmajor && g->epilogue != OBTE_EPI_GELU_BWD)) pl = make_plan(g->M, g->N, g->K, false);
     if (pl.variant == 5 && !v5_eligible(g)) pl = make_plan(g->M, g->N, g->K, false);   // (a plan borrowed by a near shape, or edge tiles)
-    if (pl.variant == 6 && !v6_eligible(g)) pl = make_plan(g->M, g->N, g->K, false);
+    if (pl.variant == 7 && !obte_gemm_v7_eligible(g)) pl = Plan{256, 1, 3};              // (the same: the half-tile ring one tile per workgroup)
     // profiler record kind = layout/epilogue code + 1000 * kernel structure (1: gemm_bf16_kernel, 2: gemm_v2_kernel, 3: gemm_v3_kernel)
     const int kind0 = (g->a_kmajor ? 8 : 0) + (g->b_kmajor ? 4 : 0) + g->epilogue;
     if (use_v1() || pl.variant == 1) {
@@ -1683,11 +1418,10 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     p.dbg_times = debug_gemm_times_buffer((int64_t)p.tiles_m * p.tiles_n * p.splits);
 #endif
     const bool long_enough = p.k_per_split >= 2 && nk - (int64_t)(p.splits - 1) * p.k_per_split >= 2;   // the half-tile rings need >= 4 half-steps
-    const bool v6 = pl.variant == 6 && pl.bn == 256 && p.splits == 1;
-    if (v6) {
-        const int prof6 = obte_prof_begin(st, kind0 + 6000, g->M, g->N, g->K);
-        rc = g->epilogue == OBTE_EPI_GELU ? launch6<OBTE_EPI_GELU>(p, st) : launch6<OBTE_EPI_NONE>(p, st);
-        obte_prof_end(prof6, st);
+    if (pl.variant == 7 && pl.bn == 256 && p.splits == 1) {
+        const int prof7 = obte_prof_begin(st, kind0 + 7000, g->M, g->N, g->K);
+        rc = obte_gemm_v7_launch(p, g->a_kmajor != 0, g->b_kmajor != 0, g->epilogue, st);
+        obte_prof_end(prof7, st);
         return rc;
     }
     const bool v5 = pl.variant == 5 && pl.bn == 128 && p.splits == 1;
@@ -1729,6 +1463,33 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
 }
 
 extern "C" int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s) { return obte_gemm_bf16_ws(g, nullptr, 0, s); }
+
+// structure 8 (gemm_bf16_v8.hip): 1 = launched, 0 = does not apply, < 0 = error
+int obte_gemm_v8_try(const obte_gemm_args* gs, int count, void* ws, int64_t ws_bytes, hipStream_t st);
+
+// With a workspace: the leading weight-gradient problems as the evenly divided persistent launch of structure 8, the rest of the group
+// (the short-K input gradient that used to fill the CUs the full-K tiles left idle) as a launch of its own; else the full-K grouped launch.
+extern "C" int obte_gemm_grouped_bf16_ws(const obte_gemm_args* gs, int count, void* workspace, int64_t workspace_bytes, obte_stream s) {
+    OBTE_REQUIRE(gs && count >= 1 && count <= GROUP_MAX, "obte_gemm_grouped_bf16: count must be 1..%d", GROUP_MAX);
+    static const bool off = [] { const char* e = getenv("OBTE_GROUPED_SPLIT"); return e && e[0] == '0'; }();   // A/B timing, tests
+    int lead = 0;
+    while (lead < count && !gs[lead].a_kmajor && !gs[lead].b_kmajor && gs[lead].K == gs[0].K) ++lead;
+    if (!workspace || off || lead == 0) return obte_gemm_grouped_bf16(gs, count, s);
+    for (int i = 0; i < lead; ++i) { const int vrc = validate_args(gs + i); if (vrc != OBTE_OK) return vrc; }
+    hipStream_t st = (hipStream_t)s;
+    double flop = 0.0;
+    for (int i = 0; i < lead; ++i) flop += 2.0 * (double)gs[i].M * (double)gs[i].N * (double)gs[i].K;
+    // profiler record of the split launch alone (kind 32 / 34 + 8000: structure 8); what follows records itself
+    const int prof = obte_prof_begin(st, 32 + (gs[0].epilogue == OBTE_EPI_ADD ? 2 : 0) + 8000,
+                                     (int64_t)(flop / (2.0 * (double)gs[0].N * (double)gs[0].K) + 0.5), gs[0].N, gs[0].K);
+    const int rc = obte_gemm_v8_try(gs, lead, workspace, workspace_bytes, st);
+    obte_prof_end(rc == 1 ? prof : -1, st);   // (a record that is never closed is dropped by the collector)
+    if (rc == 0) return obte_gemm_grouped_bf16(gs, count, s);
+    if (rc < 0) return rc;
+    if (lead == count) return OBTE_OK;
+    if (count - lead == 1) return obte_gemm_bf16(gs + lead, s);
+    return obte_gemm_grouped_bf16(gs + lead, count - lead, s);
+}
 
 // Grouped launch (see gemm_v3_group_kernel).  Each problem: any layout, epilogue NONE or ADD, K >= 128.
 extern "C" int obte_gemm_grouped_bf16(const obte_gemm_args* gs, int count, obte_stream s) {

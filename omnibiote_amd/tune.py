@@ -50,6 +50,16 @@ def _time_once(a, b, M, N, K, ak, bk, epi, aux, out, reps=6, rope=None) -> float
     return best
 
 
+def v7_applies(M: int, N: int, K: int, epi: int, a_kmajor: bool, b_kmajor: bool) -> bool:
+    """Mirror of obte_gemm_v7_eligible (csrc/gemm_bf16_v7.hip): whole 256 x 256 tiles, one or more per CU, K >= 256, x W^T or dy W
+    with the epilogues it is built for, an output that stays within the Infinity Cache."""
+    if not a_kmajor:
+        return False
+    ok_epi = (L.EPI_NONE, L.EPI_GELU, L.EPI_ADD, L.EPI_ADD_DROPOUT, L.EPI_ROPE_QK) if b_kmajor else (L.EPI_NONE, L.EPI_GELU_BWD)
+    return (epi in ok_epi and M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 256 and (M // 256) * (N // 256) >= 256
+            and M * N * 2 <= (256 << 20))
+
+
 def candidates(M: int, N: int, K: int, epi: int, a_kmajor: bool = False, b_kmajor: bool = False) -> List[Tuple[int, int, int]]:
     """(variant, bn, splits)."""
     c = [(1, 128, 1), (2, 128, 1)]
@@ -58,6 +68,8 @@ def candidates(M: int, N: int, K: int, epi: int, a_kmajor: bool = False, b_kmajo
     if (a_kmajor and b_kmajor and M % 256 == 0 and N % 128 == 0 and K % 64 == 0 and K >= 640 and (M // 256) * (N // 128) >= 512
             and epi in (L.EPI_NONE, L.EPI_GELU, L.EPI_ADD, L.EPI_GELU_BWD)):
         c.append((5, 128, 1))      # persistent 256 x 128 tiles, a tile's stores leave under the next tile's main loop
+    if v7_applies(M, N, K, epi, a_kmajor, b_kmajor):
+        c.append((7, 256, 1))      # the 256 x 256 half-tile ring, persistent: the LDS-DMA stream runs on across tiles (csrc/gemm_bf16_v7.hip)
     if K >= 128:
         c.append((4, 128, 1))      # the half-tile ring at two workgroups per CU
     if N >= 256:
@@ -83,7 +95,7 @@ def rank_candidates(times: dict) -> list:
     goes first — inside the step, with warm operands and neighbours, it is the one that holds its time (the row-compact readout
     input gradient: 160-195 us on the half-tile ring against 190-215 us when the K-tile ring won the coin toss)."""
     results = sorted((t, c[0], c[1], c[2]) for c, t in times.items())
-    prefer = {5: 0, 3: 1, 2: 2, 4: 3, 1: 4}
+    prefer = {7: -1, 5: 0, 3: 1, 2: 2, 4: 3, 1: 4}
     tied = [r for r in results if r[0] <= results[0][0] * 1.03]
     tied.sort(key=lambda r: (prefer.get(r[1], 9), r[0]))
     return tied[:1] + [r for r in results if r is not tied[0]]

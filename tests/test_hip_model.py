@@ -778,16 +778,16 @@ def test_dropout_masked_gradient_handoff_between_blocks(monkeypatch):
     w = R.hash_weights(R.RefConfig(block_size=T, vocab_size=V, n_layer=Lyr, n_head=H, n_embd=C))
     ids = torch.from_numpy(TE.synthetic_rows(rows, T, V, np.random.default_rng(0), single_document=False)).to(DEV)
     out, taken = {}, {}
-    real_take = M._masked_grad_take
+    real_take = M._GradHandOff.take
     for mode in ("1", "0"):
         monkeypatch.setenv("OBTE_DROPOUT_HANDOFF", mode)
         count = [0]
 
-        def counting_take(dy, drop, _c=count):
-            r = real_take(dy, drop)
+        def counting_take(self, index, dy, drop, _c=count):
+            r = real_take(self, index, dy, drop)
             _c[0] += int(r is not None)
             return r
-        monkeypatch.setattr(M, "_masked_grad_take", counting_take)
+        monkeypatch.setattr(M._GradHandOff, "take", counting_take)
         m = _tiny_model(w, C, H, Lyr, V, T)
         TE.set_dropout(m, 0.1)
         step = TE.TrainStep(m, torch.optim.SGD(m.parameters(), lr=0.0), None, mini_batch_size=mini, n_head=H, max_grad_norm=1e9)

@@ -882,28 +882,78 @@ def test_gemm_persistent_structure_with_deferred_stores():
         L().check(lib.obte_gemm_plan_clear(), "obte_gemm_plan_clear")
 
 
-def test_gemm_four_wave_structure():
-    """Structure 6 (256 x 256 tile, four waves, one per SIMD, the 64 accumulator quads in AGPRs through asm MFMAs): an A/B
-    candidate reachable through the plan table (x @ W^T, plain and GELU pair).  Same per-tile arithmetic as the K-tile ring: equal
-    bit for bit, 2 to 64 K-tiles, one tile to several rounds; shapes it does not take fall back."""
-    o, lib = ops(), L().lib()
+def test_gemm_persistent_continuous_ring_structure():
+    """Structure 7 (csrc/gemm_bf16_v7.hip: the 256 x 256 half-tile ring as a persistent kernel — the LDS-DMA stream runs on across
+    tiles, each wave's epilogue goes through 4 KiB of staging of its own, stores drain under the next tile's loop): every layout and
+    epilogue it is built for — x W^T plain / GELU pair / residual add / residual add + dropout / RoPE on the q, k thirds; dy W plain /
+    GELU' — at 1, 2, 2.5 and 8 tiles per workgroup and K from 256 to 4096, bit for bit against structure 3 (the same main loop
+    and per-tile arithmetic, one tile per workgroup), against the fp32 reference, and with an exact identity product; shapes it
+    does not take (ragged, fewer tiles than CUs, short K) fall back; the plan table refuses layouts it has no form for."""
+    o, lib, Lm = ops(), L().lib(), L()
+    def plan(ak, bk, epi, M, N, K, variant):
+        Lm.check(lib.obte_gemm_plan_set(ak, bk, epi, M, N, K, variant, 256, 1), "obte_gemm_plan_set")
     try:
-        for (M, N, K, epi) in [(256, 256, 128, 0), (512, 512, 192, 0), (1024, 768, 1024, 0), (8192, 4096, 1024, 1), (2048, 1024, 4096, 0)]:
-            x, w = rnd(M, K, seed=3).to(DEV), rnd(N, K, seed=4, scale=0.2).to(DEV)
+        # x W^T, plain: tile counts around the persistent walk's edges (256 = one each, 320 = some two, 512, 2048)
+        for (M, N, K) in [(8192, 2048, 256), (8192, 2560, 512), (16384, 2048, 1024), (32768, 4096, 1024), (8192, 2048, 4096)]:
+            x, w = rnd(M, K, seed=61).to(DEV), rnd(N, K, seed=62, scale=0.2).to(DEV)
             outs = {}
-            for variant in (2, 6):
-                L().check(lib.obte_gemm_plan_set(1, 1, epi, M, N, K, variant, 256, 1), "obte_gemm_plan_set")
-                outs[variant] = o.linear_fwd(x, w, epilogue=epi)
-            if epi == L().EPI_GELU:
-                assert torch.equal(outs[2][0], outs[6][0]) and torch.equal(outs[2][1], outs[6][1])
+            for variant in (7, 3):
+                plan(1, 1, Lm.EPI_NONE, M, N, K, variant)
+                outs[variant] = o.linear_fwd(x, w)
+            assert torch.equal(outs[7], outs[3]), f"structure 7 vs 3, NT {M}x{N}x{K}"
+            rows = torch.arange(0, M, 257)
+            close(outs[7][rows.to(DEV)], x[rows.to(DEV)].float().cpu() @ w.float().cpu().t(), atol=0.02 * math.sqrt(K) * 0.2, what=f"NT structure 7 {M}x{N}x{K}")
+        # epilogues of the forward
+        M, N, K = 16384, 3072, 1024
+        x, w, r = rnd(M, K, seed=7).to(DEV), rnd(N, K, seed=8, scale=0.2).to(DEV), rnd(M, N, seed=9).to(DEV)
+        T, hs = 1024, 128
+        tab = torch.randn(T, hs // 2, generator=torch.Generator().manual_seed(1))
+        rope = (torch.cos(tab).to(DEV), torch.sin(tab).to(DEV))
+        for epi in (Lm.EPI_GELU, Lm.EPI_ADD, Lm.EPI_ADD_DROPOUT, Lm.EPI_ROPE_QK):
+            outs = {}
+            for variant in (7, 3):
+                plan(1, 1, epi, M, N, K, variant)
+                kw = {}
+                if epi in (Lm.EPI_ADD, Lm.EPI_ADD_DROPOUT):
+                    kw["aux"] = r
+                if epi == Lm.EPI_ADD_DROPOUT:
+                    kw["dropout"] = (0.1, SEED, 2)
+                if epi == Lm.EPI_ROPE_QK:
+                    outs[variant] = o.gemm(x.reshape(-1), w.reshape(-1), M, N, K, True, True, epi, rope=(rope[0], rope[1], T, hs))
+                else:
+                    outs[variant] = o.linear_fwd(x, w, epilogue=epi, **kw)
+            if epi == Lm.EPI_GELU:
+                assert torch.equal(outs[7][0], outs[3][0]) and torch.equal(outs[7][1], outs[3][1]), "GELU pair"
+                acc = (x[:256].float().cpu() @ w.float().cpu().t())
+                close(outs[7][1][:256], R.gelu_erf(acc.to(BF).float()), atol=0.03, what="gelu act, structure 7")
             else:
-                assert torch.equal(outs[2], outs[6]), (M, N, K)
-                close(outs[6][:256], x[:256].float().cpu() @ w.float().cpu().t(), atol=0.02 * math.sqrt(K) * 0.2, what="four-wave structure")
-        L().check(lib.obte_gemm_plan_set(1, 1, 0, 300, 520, 128, 6, 256, 1), "obte_gemm_plan_set")   # ragged: heuristic plan instead
-        xs, ws = rnd(300, 128, seed=1), rnd(520, 128, seed=2, scale=0.2)
-        close(o.linear_fwd(xs.to(DEV), ws.to(DEV)), xs.float() @ ws.float().t(), atol=0.02 * math.sqrt(128) * 0.2, what="fallback")
+                assert torch.equal(outs[7].reshape(-1), outs[3].reshape(-1)), f"epilogue {epi}"
+        # dy W (B k-strided): plain and GELU'
+        M, N, K = 16384, 4096, 1024
+        dy, w, h = rnd(M, K, seed=11).to(DEV), rnd(K, N, seed=12, scale=0.2).to(DEV), rnd(M, N, seed=13).to(DEV)
+        for epi in (Lm.EPI_NONE, Lm.EPI_GELU_BWD):
+            outs = {}
+            for variant in (7, 3):
+                plan(1, 0, epi, M, N, K, variant)
+                outs[variant] = o.gemm(dy.reshape(-1), w.reshape(-1), M, N, K, True, False, epi, h.reshape(-1) if epi == Lm.EPI_GELU_BWD else None)
+            assert torch.equal(outs[7], outs[3]), f"NN epilogue {epi}"
+        close(outs[7].reshape(M, N)[:256], (dy[:256].float().cpu() @ w.float().cpu()).to(BF).float() * h[:256].float().cpu(), atol=0.05, what="dgrad + GELU', structure 7")
+        # exact identity product with an asymmetric B, two tiles per workgroup
+        M, N, K = 16384, 2048, 1024
+        plan(1, 1, Lm.EPI_NONE, M, N, K, 7)
+        eye = torch.zeros(M, K); eye[torch.arange(K), torch.arange(K)] = 1.0; eye[8192 + torch.arange(K), torch.arange(K)] = 1.0
+        b = (torch.arange(N * K).reshape(N, K) % 251 - 125).float().to(BF)
+        got = o.linear_fwd(eye.to(BF).to(DEV), b.to(DEV)).cpu().float()
+        assert torch.equal(got[:K], b.float().t()) and torch.equal(got[8192:8192 + K], b.float().t()) and not got[K:8192].any() and not got[8192 + K:].any()
+        # shapes the structure does not take fall back (ragged; fewer tiles than CUs; K of two K-tiles) instead of failing
+        for (M, N, K) in [(300, 520, 128), (2048, 2048, 1024), (16384, 4096, 128)]:
+            plan(1, 1, 0, M, N, K, 7)
+            xs, ws = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2)
+            close(o.linear_fwd(xs.to(DEV), ws.to(DEV))[:300], xs[:300].float() @ ws.float().t(), atol=0.02 * math.sqrt(K) * 0.2, what="fallback")
+        with pytest.raises(RuntimeError, match="continuous-ring structure"):
+            Lm.check(lib.obte_gemm_plan_set(0, 0, 0, 8192, 4096, 8192, 7, 256, 1), "obte_gemm_plan_set")
     finally:
-        L().check(lib.obte_gemm_plan_clear(), "obte_gemm_plan_clear")
+        Lm.check(lib.obte_gemm_plan_clear(), "obte_gemm_plan_clear")
 
 
 def test_gemm_192_wide_tile():
@@ -986,6 +1036,54 @@ def test_gemm_grouped_matches_single_launches(accumulate):
         bad[0] = L().GemmArgs(q["a"].data_ptr(), q["b"].data_ptr(), q["out"].data_ptr(), None, None, q["M"], q["N"], K, q["M"], q["N"], q["N"],
                               0, 0, L().EPI_GELU, 1.0, 0.0, 0, 0)
         L().check(L().lib().obte_gemm_grouped_bf16(bad, 1, None), "obte_gemm_grouped_bf16")
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("C,K", [(1024, 8192), (1024, 4096), (512, 2048)])
+def test_gemm_grouped_split_weight_gradients(accumulate, C, K):
+    """Structure 8 (csrc/gemm_bf16_v8.hip; obte_gemm_grouped_bf16_ws): the four weight gradients of a block — dW = dY^T X with
+    K = tokens, [4C, C], [C, 4C], [3C, C], [C, C] — as ONE persistent launch whose tiles' K ranges are cut into aligned parts
+    (4 at C = 1024: 768 items on 256 CUs; other sizes: whatever split fills whole rounds, or the full-K launch where none does),
+    the parts summed in fp32 in a fixed order through scratch, followed by the group's short-K input gradient as a launch of its
+    own: against fp32 references (overwrite and accumulate-in-place), against the full-K grouped launch (fp32 summation order
+    differs: one bf16 rounding apart at most), bitwise run to run, and with a clean device status word."""
+    from omnibiote_amd import _lib as Lm
+    o = ops()
+    shapes = [(4 * C, C), (C, 4 * C), (3 * C, C), (C, C)]
+    g = torch.Generator(device=DEV).manual_seed(5)
+
+    def problems(split_tag):
+        probs = []
+        for i, (M, N) in enumerate(shapes):
+            probs.append(dict(a=data[i][0], b=data[i][1], M=M, N=N, K=K, out=data[i][2].clone(), accumulate=accumulate))
+        probs.append(dict(a=dy5, b=w5, M=K, N=C, K=3 * C, out=torch.full((K, C), 7.0, dtype=BF, device=DEV), a_kmajor=True))
+        return probs
+    data = []
+    for i, (M, N) in enumerate(shapes):
+        a = (torch.randn(K, M, device=DEV, generator=g) * 0.5).to(BF)
+        b = (torch.randn(K, N, device=DEV, generator=g) * 0.5).to(BF)
+        base = torch.randn(M, N, device=DEV, generator=g).to(BF)
+        data.append((a, b, base))
+    dy5 = (torch.randn(K, 3 * C, device=DEV, generator=g) * 0.5).to(BF)
+    w5 = (torch.randn(3 * C, C, device=DEV, generator=g) * 0.2).to(BF)
+    ws = Lm.lib().obte_gemm_grouped_workspace_bytes
+    split_outs = o.gemm_grouped(problems("split"), split=True)
+    again = o.gemm_grouped(problems("split"), split=True)
+    full_outs = o.gemm_grouped(problems("full"))
+    torch.cuda.synchronize()
+    Lm.check_device_status("split weight gradients")
+    for i, (M, N) in enumerate(shapes):
+        a, b, base = data[i]
+        rows = torch.arange(0, M, 97, device=DEV)
+        acc = a[:, rows].float().t() @ b.float()
+        ref = (base[rows].float() + acc.to(BF).float()) if accumulate else acc
+        close(split_outs[i][rows], ref.cpu(), atol=0.01 * math.sqrt(K) + 0.02, what=f"split wgrad {M}x{N}")
+        d = (split_outs[i].float() - full_outs[i].float()).abs()
+        bar = 2.0 ** -7 * full_outs[i].float().abs() + 1e-3
+        assert (d <= bar).all(), (i, d.max().item())
+        assert torch.equal(split_outs[i], again[i]), "split weight gradients are not run-to-run bitwise"
+    close(split_outs[4][:512], (dy5[:512].float() @ w5.float()).cpu(), atol=0.01 * math.sqrt(3 * C) + 0.02, what="the group's input gradient")
+    assert torch.equal(split_outs[4], full_outs[4])
 
 
 @pytest.mark.parametrize("accumulate", [False, True])
