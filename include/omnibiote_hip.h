@@ -46,8 +46,7 @@ int obte_struct_sizes(int64_t* out, int cap);
  * are INVALID, and obte_last_error() then says which condition it was.  Negative: the word could not be allocated.
  * Replaces nothing in the reference (PyTorch raises from its own kernels' asserts the same way: at the next synchronise). */
 enum {
-    OBTE_STATUS_ATTN_BWD_HANDOFF = 1,  /* obte_attn_bwd, one-kernel form: a bounded wait of the dQ hand-off chain gave up */
-    OBTE_STATUS_GEMM_SPLIT_HANDOFF = 2 /* obte_gemm_grouped_bf16_ws, split form: a tile's owner gave up waiting for a part's image */
+    OBTE_STATUS_ATTN_BWD_HANDOFF = 1   /* obte_attn_bwd, one-kernel form: a bounded wait of the dQ hand-off chain gave up */
 };
 int obte_device_status(int clear);
 /* Test hook (never set by the product): make the next launches of a kernel fail in a chosen way so that the reporting above can
@@ -167,14 +166,6 @@ int64_t obte_gemm_workspace_bytes_max(int64_t M, int64_t N, int64_t K);
  * the CUs those leave idle; and the readout's input gradient beside its weight gradient (model.py:253). */
 #define OBTE_GROUP_MAX 6
 int obte_gemm_grouped_bf16(const obte_gemm_args* gs, int count, obte_stream s);
-/* The same with a caller-owned scratch buffer of obte_gemm_grouped_workspace_bytes(gs, count) bytes (0: no use for one).  With it, a
- * group's leading weight-gradient problems (both operands k-strided, whole 256 x 256 tiles, one K) run as ONE persistent launch
- * whose work divides evenly over the 256 CUs: every tile's K range is cut into aligned parts (4 at n_embd = 1024: 768 items, three
- * per CU), the parts of a tile are summed in fp32 in a fixed order through the scratch (bitwise reproducible; a wait that gives up
- * sets OBTE_STATUS_GEMM_SPLIT_HANDOFF), and the remaining problems of the group follow as a launch of their own.  Without a
- * buffer, or for groups this does not apply to: obte_gemm_grouped_bf16. */
-int64_t obte_gemm_grouped_workspace_bytes(const obte_gemm_args* gs, int count);
-int obte_gemm_grouped_bf16_ws(const obte_gemm_args* gs, int count, void* workspace, int64_t workspace_bytes, obte_stream s);
 
 /* ---- dropout (training/model.py:83-84,160,204) -------------------------------------------------------------------
  * Every dropout site of the path is a matrix and draws its mask from one counter-based generator: element (row, col) of

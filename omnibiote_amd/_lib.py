@@ -89,8 +89,6 @@ SYMBOLS = {
     "obte_gemm_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "obte_gemm_bf16_ws": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p, C.c_int64, c_stream]),
     "obte_gemm_grouped_bf16": (C.c_int, [C.POINTER(GemmArgs), C.c_int, c_stream]),
-    "obte_gemm_grouped_workspace_bytes": (C.c_int64, [C.POINTER(GemmArgs), C.c_int]),
-    "obte_gemm_grouped_bf16_ws": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_void_p, C.c_int64, c_stream]),
     "obte_gemm_plan_set": (C.c_int, [C.c_int] * 3 + [C.c_int64] * 3 + [C.c_int] * 3),
     "obte_gemm_plan_clear": (C.c_int, []),
     "obte_gemm_workspace_bytes_max": (C.c_int64, [C.c_int64] * 3),
@@ -178,7 +176,6 @@ def check(rc: int, what: str = "") -> None:
 
 
 STATUS_ATTN_BWD_HANDOFF = 1
-STATUS_GEMM_SPLIT_HANDOFF = 2
 
 
 class DeviceStatusError(RuntimeError):

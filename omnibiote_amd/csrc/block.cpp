@@ -35,7 +35,7 @@ struct ActLayout {
 };
 
 struct WsLayout {
-    int64_t dhpre, dh, dx1, dyattn, dqkv, delta, lnws, dym, dym2, gemmws, gemmws_bytes, attnws, attnws_bytes, groupws, groupws_bytes, total;
+    int64_t dhpre, dh, dx1, dyattn, dqkv, delta, lnws, dym, dym2, gemmws, gemmws_bytes, attnws, attnws_bytes, total;
     WsLayout(int64_t B, int64_t T, int C, int H) {
         const int64_t M = B * T;
         int64_t o = 0;
@@ -58,13 +58,6 @@ struct WsLayout {
         gemmws = take(gemmws_bytes > 0 ? gemmws_bytes : 256);
         attnws_bytes = obte_attn_bwd_ws_bytes(B, T, H, C / H);   // the one-kernel attention backward's dQ contributions (0: not applicable)
         attnws = take(attnws_bytes > 0 ? attnws_bytes : 256);
-        {   // the four weight gradients as the evenly divided persistent launch (obte_gemm_grouped_bf16_ws): fp32 images of the K parts
-            obte_gemm_args gs[4] = {};
-            const int64_t mn[4][2] = {{4 * C, C}, {C, 4 * C}, {3 * C, C}, {C, C}};
-            for (int i = 0; i < 4; ++i) { gs[i].M = mn[i][0]; gs[i].N = mn[i][1]; gs[i].K = M; gs[i].ldd = mn[i][1]; gs[i].epilogue = OBTE_EPI_NONE; }
-            groupws_bytes = obte_gemm_grouped_workspace_bytes(gs, 4);
-        }
-        groupws = take(groupws_bytes > 0 ? groupws_bytes : 256);
         total = o;
     }
 };
@@ -319,9 +312,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
             gs[np].epilogue = OBTE_EPI_NONE; gs[np].alpha = 1.0f;
             ++np;
         }
-        // (the workspace is sized for the full group of four weight gradients; any other group — the rows form — takes the full-K launch)
-        const bool four = grouped_mlp && W.groupws_bytes > 0;
-        TRY(obte_gemm_grouped_bf16_ws(gs, np, four ? (void*)(S + W.groupws) : nullptr, four ? W.groupws_bytes : 0, s));
+        TRY(obte_gemm_grouped_bf16(gs, np, s));
     }
     // dx = dx1 + LN1'(dh1); with dropout and a block below, also dropout(dx) under that block's (seed, site 3) mask
     if (drop && d->dx_masked)

@@ -117,53 +117,33 @@ __device__ __forceinline__ bf16x8 join8(bf16x4 a, bf16x4 b) {
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// gelu_erf with the reference's constant 1.41421 (training/model.py:25) and its derivative.
-// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, below fp32 resolution of the bf16-rounded results),
-// branch-free: one v_rcp_f32, one v_exp_f32 and five FMAs — the ocml erff is branchy and several times longer, and
-// the GEMM epilogues that call this are not hidden behind MFMA work.  The exp(-u^2) is shared with the derivative.
+// gelu_erf with the reference's constant 1.41421 (training/model.py:25) and its derivative, two elements at a time.
+// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, below fp32 resolution of the bf16-rounded results), branch-free: per
+// element one v_rcp_f32, one v_exp_f32 and — on v_pk_{mul,fma}_f32, one issue slot per pair — five multiplies and seven FMAs
+// (the ocml erff is branchy and several times longer).  The GELU epilogues are vector-ALU bound (both waves of a SIMD run this over
+// 8192 elements each per 256 x 256 tile: ~9 us of a 36-us tile at K = 1024, round-5 stamps), so the sequence is kept minimal:
+//   w = x sqrt(log2 e) / c          u = x / c is never formed: exp(-u^2) = exp2(-w^2), |u| = |w| / sqrt(log2 e)
+//   g = exp2(-w w)                   (negation: a source modifier)
+//   t = 1 / (1 + p' |w|)             (abs: a source modifier of the scalar FMA; p' = 0.3275911 / sqrt(log2 e))
+//   q = a1 + t (a2 + t (a3 + t (a4 + t a5)))
+//   erf|u| = 1 - q (t g),  Phi = 0.5 + 0.5 copysign(erf|u|, x),  gelu = x Phi,  gelu' = Phi + (x g) / (c sqrt(pi))
+// Every GEMM structure calls this one function, so their GELU outputs agree bit for bit.
 #define OBTE_GELU_C 1.41421f
-__device__ __forceinline__ void erf_and_gauss(float u, float& erf_u, float& gauss) {
-    const float au = fabsf(u);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * au);
-    gauss = __expf(-u * u);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    erf_u = copysignf(1.0f - poly * gauss, u);
-}
-__device__ __forceinline__ float gelu_ref(float x) {
-    float e, g;
-    erf_and_gauss(x * (1.0f / OBTE_GELU_C), e, g);
-    return x * 0.5f * (1.0f + e);
-}
-__device__ __forceinline__ void gelu_ref_both(float x, float& act, float& der) {
-    float e, g;
-    erf_and_gauss(x * (1.0f / OBTE_GELU_C), e, g);
-    const float half_cdf = 0.5f * (1.0f + e);
-    act = x * half_cdf;
-    der = half_cdf + x * (0.5641895835477563f / OBTE_GELU_C) * g;
-}
-// Two elements at a time on v_pk_{mul,fma,add}_f32 (one issue slot for both); only the rcp and exp stay scalar.
-// Same formula and constants as erf_and_gauss / gelu_ref_both above.  (Measured: the GELU epilogue's extra ~20 us on
-// the fc shape is its second 67-MB output, not this arithmetic — packed or scalar time the same.)
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gelu_ref_both2(f32x2_t x, f32x2_t& act, f32x2_t& der) {
-    const f32x2_t u = x * (1.0f / OBTE_GELU_C);
-    const f32x2_t au = __builtin_elementwise_abs(u);
-    const f32x2_t den = au * 0.3275911f + 1.0f;
-    const f32x2_t t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-    const f32x2_t e2 = u * u * -1.4426950408889634f;   // exp(-u^2) = exp2(-u^2 * log2 e)
-    const f32x2_t gauss = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
-    const f32x2_t poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const f32x2_t e_abs = 1.0f - poly * gauss;
-    const f32x2_t e = {__builtin_copysignf(e_abs[0], u[0]), __builtin_copysignf(e_abs[1], u[1])};
+    constexpr float K2 = 1.2011224087864498f / OBTE_GELU_C;        // sqrt(log2 e) / c
+    constexpr float P2 = 0.3275911f / 1.2011224087864498f;
+    const f32x2_t w = x * K2;
+    const f32x2_t t2 = w * w;
+    const f32x2_t gauss = {__builtin_amdgcn_exp2f(-t2[0]), __builtin_amdgcn_exp2f(-t2[1])};
+    const f32x2_t t = {__builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(w[0]), P2, 1.0f)),
+                       __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_fabsf(w[1]), P2, 1.0f))};
+    const f32x2_t q = 0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f)));
+    const f32x2_t e_abs = 1.0f - q * (t * gauss);
+    const f32x2_t e = {__builtin_copysignf(e_abs[0], x[0]), __builtin_copysignf(e_abs[1], x[1])};
     const f32x2_t half_cdf = e * 0.5f + 0.5f;
     act = x * half_cdf;
-    der = half_cdf + x * (0.5641895835477563f / OBTE_GELU_C) * gauss;
-}
-__device__ __forceinline__ float gelu_ref_grad(float x) {
-    float e, g;
-    erf_and_gauss(x * (1.0f / OBTE_GELU_C), e, g);
-    // d/dx [0.5 x (1 + erf(x/c))] = 0.5 (1 + erf(u)) + x * (1/(c*sqrt(pi))) * exp(-u^2)
-    return 0.5f * (1.0f + e) + x * (0.5641895835477563f / OBTE_GELU_C) * g;
+    der = half_cdf + (x * gauss) * (0.5641895835477563f / OBTE_GELU_C);
 }
 
 // ---- dropout: counter-based keep decision -------------------------------------------------------------------

@@ -84,7 +84,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmParams& p, f32x4 (&acc)[
     for (int ni = 0; ni < NJ; ++ni)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)   // (as one vector conversion: two v_pk_mul + two v_cvt_pk per quad; element by element hipcc emitted ten instructions)
-            *reinterpret_cast<bf16x4*>(stg + (mi * 16 + em) * LDE + (ni * 16 + en) * 2) = __builtin_convertvector(acc[ni][mi] * p.alpha, bf16x4);
+            *reinterpret_cast<bf16x4*>(stg + (mi * 16 + em) * LDE + (ni * 16 + en) * 2) =
+                __builtin_convertvector((EPI == OBTE_EPI_NONE || EPI == OBTE_EPI_ADD) ? acc[ni][mi] * p.alpha : acc[ni][mi], bf16x4);   // (alpha != 1 only with these two: validate_args)
     // Interior tiles whose epilogue READS global memory (residual / gradient accumulation, GELU', dropout + residual, RoPE
     // tables) take a branch-free path that issues every one of those loads BEFORE the first store.  In the guarded loop below
     // each iteration is load -> s_waitcnt vmcnt(0) -> arithmetic -> store behind a bounds branch hipcc does not schedule
@@ -1463,33 +1464,6 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
 }
 
 extern "C" int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s) { return obte_gemm_bf16_ws(g, nullptr, 0, s); }
-
-// structure 8 (gemm_bf16_v8.hip): 1 = launched, 0 = does not apply, < 0 = error
-int obte_gemm_v8_try(const obte_gemm_args* gs, int count, void* ws, int64_t ws_bytes, hipStream_t st);
-
-// With a workspace: the leading weight-gradient problems as the evenly divided persistent launch of structure 8, the rest of the group
-// (the short-K input gradient that used to fill the CUs the full-K tiles left idle) as a launch of its own; else the full-K grouped launch.
-extern "C" int obte_gemm_grouped_bf16_ws(const obte_gemm_args* gs, int count, void* workspace, int64_t workspace_bytes, obte_stream s) {
-    OBTE_REQUIRE(gs && count >= 1 && count <= GROUP_MAX, "obte_gemm_grouped_bf16: count must be 1..%d", GROUP_MAX);
-    static const bool off = [] { const char* e = getenv("OBTE_GROUPED_SPLIT"); return e && e[0] == '0'; }();   // A/B timing, tests
-    int lead = 0;
-    while (lead < count && !gs[lead].a_kmajor && !gs[lead].b_kmajor && gs[lead].K == gs[0].K) ++lead;
-    if (!workspace || off || lead == 0) return obte_gemm_grouped_bf16(gs, count, s);
-    for (int i = 0; i < lead; ++i) { const int vrc = validate_args(gs + i); if (vrc != OBTE_OK) return vrc; }
-    hipStream_t st = (hipStream_t)s;
-    double flop = 0.0;
-    for (int i = 0; i < lead; ++i) flop += 2.0 * (double)gs[i].M * (double)gs[i].N * (double)gs[i].K;
-    // profiler record of the split launch alone (kind 32 / 34 + 8000: structure 8); what follows records itself
-    const int prof = obte_prof_begin(st, 32 + (gs[0].epilogue == OBTE_EPI_ADD ? 2 : 0) + 8000,
-                                     (int64_t)(flop / (2.0 * (double)gs[0].N * (double)gs[0].K) + 0.5), gs[0].N, gs[0].K);
-    const int rc = obte_gemm_v8_try(gs, lead, workspace, workspace_bytes, st);
-    obte_prof_end(rc == 1 ? prof : -1, st);   // (a record that is never closed is dropped by the collector)
-    if (rc == 0) return obte_gemm_grouped_bf16(gs, count, s);
-    if (rc < 0) return rc;
-    if (lead == count) return OBTE_OK;
-    if (count - lead == 1) return obte_gemm_bf16(gs + lead, s);
-    return obte_gemm_grouped_bf16(gs + lead, count - lead, s);
-}
 
 // Grouped launch (see gemm_v3_group_kernel).  Each problem: any layout, epilogue NONE or ADD, K >= 128.
 extern "C" int obte_gemm_grouped_bf16(const obte_gemm_args* gs, int count, obte_stream s) {

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v7_kernel(GemmParams p) {
             asm volatile("" : "+v"(wl), "+v"(sw));
 #pragma unroll
             for (int ni = 0; ni < NJ; ++ni)   // chunk (2 ni + (g4 >> 1)) ^ em = (2 ni) ^ ((g4 >> 1) ^ em): 2 ni has bit 0 clear
-                *reinterpret_cast<bf16x4*>(stg + wl + (sw ^ (uint32_t)(ni << 5))) = __builtin_convertvector(acc[ni][mi] * p.alpha, bf16x4);
+                *reinterpret_cast<bf16x4*>(stg + wl + (sw ^ (uint32_t)(ni << 5))) = __builtin_convertvector((EPI == OBTE_EPI_NONE || EPI == OBTE_EPI_ADD) ? acc[ni][mi] * p.alpha : acc[ni][mi], bf16x4);   // (alpha != 1 only with these two: validate_args)
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const uint32_t r = (uint32_t)(4 * it + g4);

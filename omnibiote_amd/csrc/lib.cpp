@@ -54,8 +54,6 @@ extern "C" int obte_device_status(int clear) {
     if (v & OBTE_STATUS_ATTN_BWD_HANDOFF)
         obte_set_error("device status 0x%x: the attention backward's dQ hand-off chain timed out (a workgroup of a (batch, head) never signalled): "
                        "the gradients of that launch are invalid", v);
-    else if (v & OBTE_STATUS_GEMM_SPLIT_HANDOFF)
-        obte_set_error("device status 0x%x: a split weight-gradient tile's owner timed out waiting for a part's image: the gradients of that launch are invalid", v);
     else if (v) obte_set_error("device status 0x%x", v);
     return v;
 }

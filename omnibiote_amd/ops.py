@@ -134,12 +134,10 @@ def gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True, epilogue=L.EPI_NONE, aux=N
     return (d, d2) if d2 is not None else d
 
 
-def gemm_grouped(problems, split: bool = False):
+def gemm_grouped(problems):
     """Up to six GEMMs in a single launch (obte_gemm_grouped_bf16).  ``problems`` is a list of dicts with keys
     a, b, M, N, K, out and optionally a_kmajor / b_kmajor (default False: the weight-gradient layout) and accumulate
-    (out += alpha A B in place) / alpha.  Put the problems with the longest K first.  Returns the outs.
-    split: give the library the scratch that lets it run the leading weight-gradient problems as ONE persistent launch whose
-    K ranges are cut so that the work divides evenly over the CUs (obte_gemm_grouped_bf16_ws), where that applies."""
+    (out += alpha A B in place) / alpha.  Put the problems with the longest K first.  Returns the outs."""
     assert 1 <= len(problems) <= 6
     arr = (L.GemmArgs * len(problems))()
     for i, q in enumerate(problems):
@@ -150,12 +148,7 @@ def gemm_grouped(problems, split: bool = False):
         arr[i] = L.GemmArgs(_ptr(a), _ptr(b), _ptr(out), _ptr(out) if acc else None, None, M, N, K,
                             K if ak else M, K if bk else N, N, int(ak), int(bk),
                             L.EPI_ADD if acc else L.EPI_NONE, float(q.get("alpha", 1.0)), 0.0, 0, 0)
-    ws_bytes = int(L.lib().obte_gemm_grouped_workspace_bytes(arr, len(problems))) if split else 0
-    if ws_bytes > 0:   # the leading weight-gradient problems as the evenly divided persistent launch (include/omnibiote_hip.h)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=problems[0]["a"].device)
-        L.check(L.lib().obte_gemm_grouped_bf16_ws(arr, len(problems), _ptr(ws), ws_bytes, _stream()), "obte_gemm_grouped_bf16_ws")
-    else:
-        L.check(L.lib().obte_gemm_grouped_bf16(arr, len(problems), _stream()), "obte_gemm_grouped_bf16")
+    L.check(L.lib().obte_gemm_grouped_bf16(arr, len(problems), _stream()), "obte_gemm_grouped_bf16")
     return [q["out"] for q in problems]
 
 

@@ -1039,54 +1039,6 @@ def test_gemm_grouped_matches_single_launches(accumulate):
 
 
 @pytest.mark.parametrize("accumulate", [False, True])
-@pytest.mark.parametrize("C,K", [(1024, 8192), (1024, 4096), (512, 2048)])
-def test_gemm_grouped_split_weight_gradients(accumulate, C, K):
-    """Structure 8 (csrc/gemm_bf16_v8.hip; obte_gemm_grouped_bf16_ws): the four weight gradients of a block — dW = dY^T X with
-    K = tokens, [4C, C], [C, 4C], [3C, C], [C, C] — as ONE persistent launch whose tiles' K ranges are cut into aligned parts
-    (4 at C = 1024: 768 items on 256 CUs; other sizes: whatever split fills whole rounds, or the full-K launch where none does),
-    the parts summed in fp32 in a fixed order through scratch, followed by the group's short-K input gradient as a launch of its
-    own: against fp32 references (overwrite and accumulate-in-place), against the full-K grouped launch (fp32 summation order
-    differs: one bf16 rounding apart at most), bitwise run to run, and with a clean device status word."""
-    from omnibiote_amd import _lib as Lm
-    o = ops()
-    shapes = [(4 * C, C), (C, 4 * C), (3 * C, C), (C, C)]
-    g = torch.Generator(device=DEV).manual_seed(5)
-
-    def problems(split_tag):
-        probs = []
-        for i, (M, N) in enumerate(shapes):
-            probs.append(dict(a=data[i][0], b=data[i][1], M=M, N=N, K=K, out=data[i][2].clone(), accumulate=accumulate))
-        probs.append(dict(a=dy5, b=w5, M=K, N=C, K=3 * C, out=torch.full((K, C), 7.0, dtype=BF, device=DEV), a_kmajor=True))
-        return probs
-    data = []
-    for i, (M, N) in enumerate(shapes):
-        a = (torch.randn(K, M, device=DEV, generator=g) * 0.5).to(BF)
-        b = (torch.randn(K, N, device=DEV, generator=g) * 0.5).to(BF)
-        base = torch.randn(M, N, device=DEV, generator=g).to(BF)
-        data.append((a, b, base))
-    dy5 = (torch.randn(K, 3 * C, device=DEV, generator=g) * 0.5).to(BF)
-    w5 = (torch.randn(3 * C, C, device=DEV, generator=g) * 0.2).to(BF)
-    ws = Lm.lib().obte_gemm_grouped_workspace_bytes
-    split_outs = o.gemm_grouped(problems("split"), split=True)
-    again = o.gemm_grouped(problems("split"), split=True)
-    full_outs = o.gemm_grouped(problems("full"))
-    torch.cuda.synchronize()
-    Lm.check_device_status("split weight gradients")
-    for i, (M, N) in enumerate(shapes):
-        a, b, base = data[i]
-        rows = torch.arange(0, M, 97, device=DEV)
-        acc = a[:, rows].float().t() @ b.float()
-        ref = (base[rows].float() + acc.to(BF).float()) if accumulate else acc
-        close(split_outs[i][rows], ref.cpu(), atol=0.01 * math.sqrt(K) + 0.02, what=f"split wgrad {M}x{N}")
-        d = (split_outs[i].float() - full_outs[i].float()).abs()
-        bar = 2.0 ** -7 * full_outs[i].float().abs() + 1e-3
-        assert (d <= bar).all(), (i, d.max().item())
-        assert torch.equal(split_outs[i], again[i]), "split weight gradients are not run-to-run bitwise"
-    close(split_outs[4][:512], (dy5[:512].float() @ w5.float()).cpu(), atol=0.01 * math.sqrt(3 * C) + 0.02, what="the group's input gradient")
-    assert torch.equal(split_outs[4], full_outs[4])
-
-
-@pytest.mark.parametrize("accumulate", [False, True])
 def test_linear_bwd_grouped_pair_matches_two_launches(monkeypatch, accumulate):
     """The readout's backward as one grouped launch (input gradient with K = vocabulary beside the weight gradient with
     K = tokens, alpha = 1/width_mult on both) against the two single launches and fp32 references."""
