@@ -217,8 +217,8 @@ typedef struct {
     float dropout_p; uint64_t dropout_seed;     /* must equal the forward call's */
     const int32_t* query_bounds;                /* nullable; with a dense mask: int32 [B,T,2] per KEY, see obte_mask_bounds */
     const int32_t* ranges_exact;                /* nullable; with mask + key_ranges + query_bounds: obte_mask_bounds' flag */
-    /* optional scratch of obte_attn_bwd_ws_bytes() bytes: with it, head_dim 128, no dense mask and dropout_p = 0 the backward
-     * runs as ONE kernel that forms each score tile once (five MFMA products per tile instead of the seven of the
+    /* optional scratch of obte_attn_bwd_ws_bytes() bytes: with it, head_dim 128, no dense mask and either dropout_p = 0 or the
+     * forward's keep bits in drop_bits, the backward runs as ONE kernel that forms each score tile once (five MFMA products per tile instead of the seven of the
      * dQ + dK/dV kernel pair): per-key-block fp32 contributions to dQ land in the scratch and are summed in key-block order
      * (no atomics: bitwise reproducible).  NULL / too small: the two-kernel form. */
     void* ws; int64_t ws_bytes;

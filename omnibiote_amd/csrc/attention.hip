@@ -1104,7 +1104,7 @@ extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
     p.drop_bits_in = (p.drop.thresh16 != 0 && a->head_dim == 128 && mode != MASK_DENSE) ? a->drop_bits : nullptr;
     const int prof = obte_prof_begin((hipStream_t)s, 101, a->B * a->n_head, a->T, a->head_dim);
     const int64_t fused_ws = a->head_dim == 128 ? fused_bwd_ws_bytes(a->B, a->T, a->n_head) : 0;   // 0: the one-kernel form does not apply
-    if (mode != MASK_DENSE && a->head_dim == 128 && p.drop.thresh16 == 0 && a->ws && attn_bwd_mode() == 0 && fused_ws > 0 &&
+    if (mode != MASK_DENSE && a->head_dim == 128 && (p.drop.thresh16 == 0 || p.drop_bits_in) && a->ws && attn_bwd_mode() == 0 && fused_ws > 0 &&
         a->ws_bytes >= fused_ws && a->T * 3 * a->n_head * 128 * 2 < (1ll << 31)) {   // (its per-lane byte offsets are 32-bit)
         if (mode == MASK_RANGES) p.query_bounds = nullptr;   // a range mask without a dense tensor: symmetric (the key's own range)
         rc = launch_bwd_fused(p, mode, a->ws, (hipStream_t)s);

@@ -155,7 +155,13 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(FusedParams fp, int 
     }
 }
 
-template <int D, int MODE, int SK = 0>   // SK: timing-only skip bits (debug library), compile-time so that the variants cost no branches
+// DROP: attention-probability dropout (model.py:83,121) from the keep bits the forward left behind (obte_attn_fwd_args::drop_bits:
+// one word per KEY and 32-query slice, bit i = query 32 t + i kept) — with O = (P o M) V, M = keep / (1 - p):
+//     dV^T += dO^T (P o M),   dS = P o (M o dP - delta) = (P o M) o dP - P delta,   delta = rowsum(dO o O) as without dropout,
+// so per element one bit field extract, the scaled probability under the bit as a mask (it IS the dV operand), and an FMA in
+// place of the multiply; both key tiles take the row-constant path of key tile 1 (dP chains from zero, -delta added in the
+// arithmetic: the masked product must not carry the constant).  The lane's two words of the NEXT slice are loaded beside its tiles.
+template <int D, int MODE, int SK = 0, bool DROP = false>   // SK: timing-only skip bits (debug library), compile-time so that the variants cost no branches
 __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedParams fp) {
     static_assert(D == 128, "the one-kernel backward is written for head_dim 128");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -202,6 +208,14 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         const bf16* vptr = p.qkv + (b * T + key_c) * ld + 2 * C + hd * D;
 #pragma unroll
         for (int s = 0; s < NS; ++s) vf[kt][s] = *reinterpret_cast<const bf16x8*>(vptr + 16 * s + 8 * h);
+    }
+    // dropout: this lane's keep words, one per key tile and slice (slice t at + t * T words)
+    const uint32_t* kw_src[2] = {nullptr, nullptr};
+    uint32_t kw[2] = {0u, 0u}, kw_next[2] = {0u, 0u};
+    if (DROP) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+            kw_src[kt] = p.drop_bits_in + ((b * p.H + hd) * (int64_t)fp.nsl) * T + (k_ok[kt] ? key[kt] : T - 1);
     }
     {   // the K rows of the block: LDS-DMA, zero-filled past T
         TileDma<D, FB_KEYS, FB_NW> dmk;
@@ -308,6 +322,7 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         for (int j = 0; j < 4; ++j) issue_piece(0, t0, j);
         load_stats(t0 * 32);
         store_stats(stage_of(0), t0 * 32);
+        if (DROP) { kw[0] = kw_src[0][(int64_t)t0 * T]; kw[1] = kw_src[1][(int64_t)t0 * T]; }
     }
     dma_wait_all();
     prologue_wait_all();
@@ -521,8 +536,9 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         for (int n = 0; n < RA - 1; ++n) rdA(sb, n);
         inside = __all(q0 >= qs[0] && q0 + 32 <= qe[0] && q0 >= qs[1] && q0 + 32 <= qe[1]);
         sc0 = row_init(sb, 0);
-        dp0 = row_init(sb, 1);
+        dp0 = DROP ? zero16 : row_init(sb, 1);   // (dropout: the masked product must not carry -delta; it is added in the arithmetic)
         if (!inside) mask_init(sc0, 0, q0);
+        const uint32_t kwh[2] = {kw[0] >> (4 * h), kw[1] >> (4 * h)};   // bit (r & 3) + 8 (r >> 2) = the query row of register r
 
         bf16x8 ka[RD], db[RD];          // D phase: K^T and dS^T fragments of key step ks in ring slot ks % RD
         auto rdD = [&](int ks) {
@@ -589,6 +605,27 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
                 dp1[r] = ds;
             }
         };
+        // dropout forms (both key tiles): q = the scaled probability under its keep bit (the dV operand), dS = q dP + p (-delta)
+        f32x4 d0c[2];                        // key tile 0's -delta chunks (rows 8 i + 4 h .. + 3), read one chunk ahead like tile 1's
+        auto rd_const0 = [&](int i) { d0c[i & 1] = lds_f4(sb.st, 128 + 32 * i); };
+        auto fin_drop = [&](f32x16& sc, f32x16& dp, uint32_t (&pw)[8], uint32_t (&dw)[8], const uint32_t kword, const float ndelta, int r) {
+            const int bit = (r & 3) + 8 * (r >> 2);
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)kword, bit, 1);        // 0 / 0xffffffff
+            const float pq = __uint_as_float(__float_as_uint(sc[r] * p.drop.scale) & m);
+            float ds = __builtin_fmaf(pq, dp[r], sc[r] * ndelta);
+            if (r & 1) {
+                bf16x2 a = {f2bf(__uint_as_float(pw[r >> 1])), f2bf(pq)};   // (pw[r >> 1] holds q of the even element: below)
+                bf16x2 c = {f2bf(dp[r - 1]), f2bf(ds)};
+                uint32_t aw = __builtin_bit_cast(uint32_t, a), cw = __builtin_bit_cast(uint32_t, c);
+                asm volatile("" : "+v"(aw), "+v"(cw));
+                pw[r >> 1] = aw; dw[r >> 1] = cw;
+            } else {
+                uint32_t qbits = __float_as_uint(pq);
+                asm volatile("" : "+v"(ds), "+v"(qbits));
+                dp[r] = ds;
+                pw[r >> 1] = qbits;          // parked until the odd element packs the pair
+            }
+        };
         auto frag_of = [](const uint32_t (&w)[8], int kk) {
             const u32x4 v = {w[4 * kk], w[4 * kk + 1], w[4 * kk + 2], w[4 * kk + 3]};
             return __builtin_bit_cast(bf16x8, v);
@@ -606,6 +643,8 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
                 if (n >= 4) issue_piece(it + 1, t_next, n - 4);
                 if (n == 7) load_stats_issue(t_next * 32);
             }
+            if (DROP && n == 7 && more) { kw_next[0] = kw_src[0][(int64_t)t_next * T]; kw_next[1] = kw_src[1][(int64_t)t_next * T]; }
+            if (DROP && n == 7) rd_const0(0);
             if (n == 7) poll_issue(t);                // this slice's counter, looked at an iteration from now (after the end-of-iteration wait)
             sc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % RA], fk[n % RA], sc0, 0, 0, 0);
             OBTE_SB();
@@ -620,7 +659,12 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
             if (ks >= 16 - (RA - 1)) rdA(sb, 8 + ks - (16 - (RA - 1)));   // A1's first fragments
             if (ks == 0) sm_exp(sc0, 0);
             if (ks + 1 < 16) sm_exp(sc0, ks + 1);
-            sm_fin(sc0, dp0, pw0, dw0, ks);
+            if (DROP) {
+                if ((ks & 3) == 0 && ks / 4 + 1 < 4) rd_const0(ks / 4 + 1);
+                fin_drop(sc0, dp0, pw0, dw0, kwh[0], d0c[(ks >> 2) & 1][ks & 3], ks);
+            } else {
+                sm_fin(sc0, dp0, pw0, dw0, ks);
+            }
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks % RD], db[ks % RD], ks == 0 ? zero16 : dq, 0, 0, 0);
             OBTE_SB();
         }
@@ -633,7 +677,8 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
             // the tile so far (requested at the top of the iteration; younger than its four pieces: the next slice's four LDS-DMA, its
             // row-constant load and this slice's poll — past the last slice only the poll) joins this workgroup's contribution, then leaves
             if (n == 8 && take_p) {
-                if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                if (more) { if (DROP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }   // (dropout: + the two keep-word loads)
+                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                 acc_add(dq);
             }
             if (n >= 9 && n < 13 && !first_it && !OBTE_SKIP(64)) store_acc(t_prev, dq, n - 9);   // (a chain's last member too: it finishes its tiles after the loop)
@@ -659,10 +704,10 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
             if ((g & 1) == 0 && g / 2 + 1 < 4) rd_const1(g / 2 + 1);
             if (g == 0) sm1_exp(0);
             sm1_exp(2 * g + 1);
-            sm1_fin(2 * g);
+            if (DROP) fin_drop(sc1, dp1, pw1, dw1, kwh[1], d4[((2 * g) >> 2) & 1][(2 * g) & 3], 2 * g); else sm1_fin(2 * g);
             mfma_acc(dv[0][dt], cdo[g % RC], frag_of(pw0, kk)); OBTE_SB();
             if (2 * g + 2 < 16) sm1_exp(2 * g + 2);
-            sm1_fin(2 * g + 1);
+            if (DROP) fin_drop(sc1, dp1, pw1, dw1, kwh[1], d4[((2 * g + 1) >> 2) & 1][(2 * g + 1) & 3], 2 * g + 1); else sm1_fin(2 * g + 1);
             mfma_acc(dk[0][dt], cq[g % RC], frag_of(dw0, kk)); OBTE_SB();
         }
         OBTE_PHASE(3);
@@ -684,6 +729,7 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
             if (first_it) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         }
+        if (DROP) { asm volatile("" : "+v"(kw_next[0]), "+v"(kw_next[1])); kw[0] = kw_next[0]; kw[1] = kw_next[1]; }   // (their loads are older than the stores the wait leaves in flight)
         st_l = *raw_st;          // (behind the wait: what the two LDS-DMA loads of this iteration left in this wave's raw area)
         have_cur = *raw_poll;
         if (more) store_stats(stage_of(it + 1), t_next * 32);
@@ -817,6 +863,8 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
 
 template __global__ void attn_bwd_fused_kernel<128, MASK_NONE>(FusedParams);
 template __global__ void attn_bwd_fused_kernel<128, MASK_RANGES>(FusedParams);
+template __global__ void attn_bwd_fused_kernel<128, MASK_NONE, 0, true>(FusedParams);
+template __global__ void attn_bwd_fused_kernel<128, MASK_RANGES, 0, true>(FusedParams);
 #ifdef OBTE_DEBUG_HOOKS
 #define OBTE_FUSED_SKIPS(X) X(4) X(35) X(39) X(64) X(103) X(128) X(231) X(255)
 #define X(m) template __global__ void attn_bwd_fused_kernel<128, MASK_RANGES, m>(FusedParams);
@@ -866,7 +914,15 @@ int launch_bwd_fused(const AttnParams& p, int mode, void* ws, hipStream_t st) {
     OBTE_CHECK_LAUNCH("obte_attn_bwd(prep)");
     const int smem = FusedShape<128>::SMEM;
     const dim3 grid((unsigned)(fp.nkb * p.H * p.B)), block(FB_NW * 64);
-    if (mode == MASK_NONE) {
+    if (p.drop.thresh16 != 0) {   // dropout: the forward's keep bits (the caller checked they are there)
+        if (mode == MASK_NONE) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<128, MASK_NONE, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<128, MASK_NONE, 0, true>), grid, block, smem, st, fp);
+        } else {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<128, MASK_RANGES, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<128, MASK_RANGES, 0, true>), grid, block, smem, st, fp);
+        }
+    } else if (mode == MASK_NONE) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<128, MASK_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         hipLaunchKernelGGL((attn_bwd_fused_kernel<128, MASK_NONE>), grid, block, smem, st, fp);
     } else {

@@ -316,13 +316,14 @@ def attn_fwd(qkv, B, T, H, hs, scale, mask: Optional[MaskSpec] = None, dropout_p
 def attn_bwd(qkv, o, d_o, lse, B, T, H, hs, scale, mask: Optional[MaskSpec] = None, rope=None, dropout_p=0.0, dropout_seed=0,
              one_kernel: bool = True, drop_bits=None):
     """one_kernel: hand the library the scratch that lets it run the one-kernel backward where that form applies (head size
-    128, no dense mask, no dropout: include/omnibiote_hip.h, obte_attn_bwd_args::ws); False: the dQ + dK/dV kernel pair."""
+    128, no dense mask; with dropout: only from the forward's keep bits, drop_bits — include/omnibiote_hip.h,
+    obte_attn_bwd_args::ws); False: the dQ + dK/dV kernel pair."""
     _need(qkv, "qkv"); _need(o, "o"); _need(d_o, "d_o"); _need(lse, "lse", torch.float32)
     mask = mask or MaskSpec()
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, T), dtype=torch.float32, device=qkv.device)
     cos, sin = rope if rope is not None else (None, None)
-    ws_bytes = int(L.lib().obte_attn_bwd_ws_bytes(B, T, H, hs)) if (one_kernel and dropout_p == 0.0 and mask.dense is None) else 0
+    ws_bytes = int(L.lib().obte_attn_bwd_ws_bytes(B, T, H, hs)) if (one_kernel and (dropout_p == 0.0 or drop_bits is not None) and mask.dense is None) else 0
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device) if ws_bytes > 0 else None
     a = L.AttnBwdArgs(_ptr(qkv), _ptr(o), _ptr(d_o), _ptr(lse), _ptr(delta), _ptr(dqkv), _ptr(cos), _ptr(sin),
                       _ptr(mask.ranges), _ptr(mask.dense), mask.sb, mask.sh, mask.sq, B, T, H, hs, float(scale),

@@ -391,8 +391,18 @@ def test_attention_dropout_keep_bits_from_the_forward(T, mode):
     out1, lse1, bits = o.attn_fwd(qd, B, T, H, hs, scale, spec, dropout_p=p, dropout_seed=seed, keep_bits=True)
     assert torch.equal(out0, out1) and torch.equal(lse0, lse1) and bits is not None
     hashed = o.attn_bwd(qd, out0, d_o, lse0, B, T, H, hs, scale, spec, dropout_p=p, dropout_seed=seed)
-    from_bits = o.attn_bwd(qd, out0, d_o, lse0, B, T, H, hs, scale, spec, dropout_p=p, dropout_seed=seed, drop_bits=bits)
+    from_bits = o.attn_bwd(qd, out0, d_o, lse0, B, T, H, hs, scale, spec, dropout_p=p, dropout_seed=seed, drop_bits=bits, one_kernel=False)
     assert torch.equal(hashed, from_bits)
+    # the ONE-kernel backward takes the dropout path from the same bits (round 5): the kernel pair's gradients to rounding (the two
+    # forms sum in different orders), bitwise run to run, inverse RoPE included
+    fused = o.attn_bwd(qd, out0, d_o, lse0, B, T, H, hs, scale, spec, dropout_p=p, dropout_seed=seed, drop_bits=bits)
+    close(fused, from_bits.float().cpu(), atol=4e-3, rtol=2.0 ** -7, what=f"one-kernel dropout backward vs kernel pair, T={T} {mode}")
+    assert torch.equal(fused, o.attn_bwd(qd, out0, d_o, lse0, B, T, H, hs, scale, spec, dropout_p=p, dropout_seed=seed, drop_bits=bits))
+    tab = torch.randn(T, hs // 2, generator=torch.Generator().manual_seed(2))
+    rope = (torch.cos(tab).to(DEV), torch.sin(tab).to(DEV))
+    fused_r = o.attn_bwd(qd, out0, d_o, lse0, B, T, H, hs, scale, spec, rope=rope, dropout_p=p, dropout_seed=seed, drop_bits=bits)
+    pair_r = o.attn_bwd(qd, out0, d_o, lse0, B, T, H, hs, scale, spec, rope=rope, dropout_p=p, dropout_seed=seed, drop_bits=bits, one_kernel=False)
+    close(fused_r, pair_r.float().cpu(), atol=4e-3, rtol=2.0 ** -7, what="one-kernel dropout backward vs kernel pair, inverse RoPE")
     # the bits are the oracle's mask: word (b*H + h, t, key) bit i = keep(row (b, h, 32 t + i), key)
     nsl = (T + 31) // 32
     w = bits.reshape(B * H, nsl, T).cpu().numpy().astype(np.uint32)

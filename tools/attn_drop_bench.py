@@ -3,7 +3,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from omnibiote_amd import ops, masks
-B, H, T, hs, p = 8, 8, 1024, 128, 0.1
+B, H, T, hs, p = int(os.environ.get('OBTE_BENCH_B', '8')), 8, 1024, 128, 0.1
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
 qkv = torch.randn(B, T, 3 * H * hs, device=dev, generator=g).to(torch.bfloat16)
@@ -27,4 +27,5 @@ for pp in (0.0, p):
         o2, lse2, bits = ops.attn_fwd(qkv, B, T, H, hs, scale, spec, pp, 1234, keep_bits=True)
         tf2 = timeit(lambda: ops.attn_fwd(qkv, B, T, H, hs, scale, spec, pp, 1234, keep_bits=True))
         tb2 = timeit(lambda: ops.attn_bwd(qkv, o, d_o, lse, B, T, H, hs, scale, spec, dropout_p=pp, dropout_seed=1234, drop_bits=bits))
-        print(f"dropout {pp:g} with keep bits: attn fwd {tf2:7.1f} us | bwd {tb2:7.1f} us", flush=True)
+        tb3 = timeit(lambda: ops.attn_bwd(qkv, o, d_o, lse, B, T, H, hs, scale, spec, dropout_p=pp, dropout_seed=1234, drop_bits=bits, one_kernel=False))
+        print(f"dropout {pp:g} with keep bits: attn fwd {tf2:7.1f} us | bwd one kernel {tb2:7.1f} us | bwd kernel pair {tb3:7.1f} us", flush=True)
