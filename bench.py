@@ -117,7 +117,7 @@ HBM_KINDS = {110: lambda d0, d1, d2: 4.0 * d0 * d1, 111: lambda d0, d1, d2: (6.0
              112: lambda d0, d1, d2: 4.0 * d0 * d1, 113: lambda d0, d1, d2: 14.0 * d0}   # algorithmic bytes per launch
 PEAK_HBM_TBS = 8.0   # MI355X HBM3E (MI355X_MICROARCH.md)
 # profiler kind = code above + 1000 * kernel structure: the name rocprofv3 --kernel-trace shows for that launch
-STRUCT_NAMES = {1: "gemm_bf16_kernel", 2: "gemm_v2_kernel", 3: "gemm_v3_kernel", 4: "gemm_v4_kernel", 5: "gemm_v5_kernel", 7: "gemm_v7_kernel"}
+STRUCT_NAMES = {1: "gemm_bf16_kernel", 2: "gemm_v2_kernel", 3: "gemm_v3_kernel", 4: "gemm_v4_kernel", 7: "gemm_v7_kernel"}
 GEMM_FAMILY = "bf16 MFMA GEMM family: " + ", ".join(sorted(set(STRUCT_NAMES.values()))) + ", gemm_v3_group_kernel"
 
 

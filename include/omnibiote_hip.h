@@ -146,8 +146,9 @@ int64_t obte_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64_t workspace_bytes, obte_stream s);
 /* Tuned plans.  The library holds five GEMM structures (variant 1: 128x128 tiles, two workgroups per CU; 2: the K-tile ring,
  * 256x128 / 256x192 / 256x256 tiles, one workgroup per CU, optional split-K; 3: the half-tile ring, 256x256; 4: the half-tile
- * ring at 256x128 and two workgroups per CU; 5: persistent 256x128 tiles whose output is stored from inside the next tile's
- * main loop — whole tiles, k-contiguous operands, >= 2 tiles per workgroup, no split-K); which is fastest depends on the shape
+ * ring at 256x128 and two workgroups per CU; 7: the 256x256 half-tile ring as a persistent kernel whose operand stream runs on
+ * across tiles — whole tiles, at least one per CU, no split-K, the x W^T and dy W layouts; numbers 5 and 6 were structures
+ * that lost every comparison and were removed); which is fastest depends on the shape
  * (tile quantisation against 256 CUs, K length, where the operands are served from).  A host-side tuner times the candidates once
  * per (layout, epilogue, M, N, K) and records the winner here; unknown shapes fall back to a built-in heuristic, and a plan a shape
  * cannot run (a borrowed near-match, edge tiles) falls back the same way.

@@ -377,215 +377,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v2_kernel(GemmParams p) {
 #endif
 }
 
-// ---- structure 5: the K-tile ring (256 x 128, three stages) as a PERSISTENT kernel whose stores leave under the next tile ----------
-// The epilogue of every structure above is ~4 us of serial latency per tile with the matrix pipe idle (the slowest wave leaves
-// the loop, conversion + staging + barrier, read back, per-chunk addressing + stores; 7.5 us with the GELU arithmetic) — the same
-// with 32 or 256 workgroups in the grid, so neither the fabric nor the CU's store path (which moves a 128-KB tile in 0.75 us:
-// tools/micro/store_path.hip); DESIGN 10.2 — and nothing of it needs the matrix pipe, so it can run under the NEXT tile's
-// main loop.  Here one workgroup per CU walks tiles q = blockIdx.x, + gridDim.x, ...; at the end of a tile the
-// accumulators go through the LDS staging as before, but the 16-byte output chunks come back into REGISTERS (8 per lane: the
-// 256 x 128 tile is what leaves room for them) and are stored one per K-step from inside the NEXT tile's main loop, where they
-// cost an issue slot each; the epilogue arithmetic (GELU and its derivative) moves with them.  The last tile of a workgroup drains
-// as before.  vmcnt retires in issue order, so the ring's counted waits name the stores too: the wait of a step allows this
-// step's and the previous step's stores in flight beside the six pieces of K-tile t + 2.
-// Operands read by the epilogue (residual, GELU') are requested at the START of their tile and combined when the chunks are read
-// back, so the deferred part is a plain store.  Whole tiles only (M % 256 = N % 128 = K % 64 = 0, K >= 640): the launcher checks.
-template <bool A_KMAJOR, bool B_KMAJOR, int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_v5_kernel(GemmParams p) {
-    using CF = Cfg<128>;
-    constexpr int BN = 128, NJ = CF::NJ, NPB = CF::NPB, STAGE_BYTES = CF::STAGE, NW = BN / 2, LDE = NW * 2 + 16, NIT = 8;
-    constexpr bool READS = EPI == OBTE_EPI_ADD || EPI == OBTE_EPI_GELU_BWD;
-    constexpr int SPS = EPI == OBTE_EPI_GELU ? 2 : 1;   // stores per chunk
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int ntiles = p.tiles_m * p.tiles_n;
-    int voff_a[4], voff_b[NPB];
-    dma_offsets<A_KMAJOR, BM, 4>(wave, lane, p.lda, voff_a);
-    dma_offsets<B_KMAJOR, BN, NPB>(wave, lane, p.ldb, voff_b);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nk = (int)((p.K + BKT - 1) / BKT);
-    const int em = lane & 15, en = (lane >> 4) * 4;
-    char* stg = smem + wave * (64 * LDE);
-    const int64_t row_step = (int64_t)(64 / (NW / 8)) * p.ldd;   // chunk it of a lane: 8 rows further down
-    bf16x8 pend[NIT];
-    int64_t pend_o = 0;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) pend[i] = bf16x8{};
-
-    auto emit = [&](auto itc) {   // chunk `it` of the previous tile leaves
-        constexpr int it = decltype(itc)::value;
-        const int64_t o = pend_o + it * row_step;
-        bf16x8 v = pend[it];
-        if (EPI == OBTE_EPI_GELU) {
-            bf16x8 g;
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                f32x2_t act, der;
-                gelu_ref_both2(f32x2_t{bf2f(v[j]), bf2f(v[j + 1])}, act, der);
-                g[j] = f2bf(act[0]); g[j + 1] = f2bf(act[1]);
-                v[j] = f2bf(der[0]); v[j + 1] = f2bf(der[1]);
-            }
-            *reinterpret_cast<bf16x8*>(p.d2 + o) = g;
-        }
-        if (p.nt_store) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p.d + o), "v"(v) : "memory");
-        else *reinterpret_cast<bf16x8*>(p.d + o) = v;
-    };
-
-    auto run_tile = [&](int q, auto stores_c) {
-        constexpr bool STORES = decltype(stores_c)::value;   // a previous tile's chunks are pending
-        // tile q -> (tm, tn): the bijective XCD remap of the one-tile-per-workgroup structures over the tile index
-        const int xcd = q & 7, q8 = ntiles >> 3, r8 = ntiles & 7;
-        const int tid_ = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (q >> 3);
-        const int group_sz = 8 * p.tiles_n;
-        const int first_m = (tid_ / group_sz) * 8;
-        const int gsz = min(p.tiles_m - first_m, 8);
-        const int tm = first_m + (tid_ % group_sz) % gsz;
-        const int tn = (tid_ % group_sz) / gsz;
-        const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-        const int64_t o_l = (m0 + wm * 64 + lane / (NW / 8)) * p.ldd + n0 + wn * NW + (lane % (NW / 8)) * 8;
-
-        f32x4 acc[NJ][4];
-#pragma unroll
-        for (int i = 0; i < NJ; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto issue = [&](int t, int stage) {
-            const int64_t k0 = (int64_t)t * BKT;
-            const int64_t ao = A_KMAJOR ? (m0 * p.lda + k0) : (k0 * p.lda + m0);
-            const int64_t bo = B_KMAJOR ? (n0 * p.ldb + k0) : (k0 * p.ldb + n0);
-            char* st = smem + stage * STAGE_BYTES;
-            dma_tile<4>(p.a + ao, p.a_elems - ao, voff_a, st, wave);
-            dma_tile<NPB>(p.b + bo, p.b_elems - bo, voff_b, st + A_TILE, wave);
-        };
-        auto load_frags = [&](int t, int ks, bf16x8 (&af)[4], bf16x8 (&bfr)[NJ]) {
-            const char* ta = smem + (t % 3) * STAGE_BYTES;
-            const char* tb = ta + A_TILE;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KMAJOR, BM>(ta, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-            for (int i = 0; i < NJ; ++i) bfr[i] = load_frag<B_KMAJOR, BN>(tb, wn * (BN / 2) + i * 16, ks, lane);
-        };
-        auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&bfr)[NJ]) {
-#pragma unroll
-            for (int ni = 0; ni < NJ; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
-        };
-        // counted wait of a step: `extra` vector-memory operations (this step's and the previous step's stores; at step 0 the
-        // epilogue operands of this tile too) may stay in flight beside the six pieces of K-tile t + 2
-        auto wait_step = [&](bool more, auto extra_c) {
-            constexpr int X = decltype(extra_c)::value;
-            static_assert(X + 6 <= 15, "vmcnt immediate");
-            if (more) __builtin_amdgcn_s_waitcnt(0x0070 | (6 + X)); else __builtin_amdgcn_s_waitcnt(0x0070 | X);
-        };
-
-        bf16x8 a0[4], b0[NJ], a1[4], b1[NJ];
-        bf16x8 r[NIT];
-        issue(0, 0);
-        issue(1, 1);
-        if (READS) {   // this tile's epilogue operands: in flight under the loop, combined when the chunks are read back
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) r[it] = *reinterpret_cast<const bf16x8*>(p.aux + o_l + it * row_step);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NIT) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        load_frags(0, 0, a0, b0);
-        auto step = [&](int t, auto slot_c) {
-            constexpr int SLOT = decltype(slot_c)::value;   // >= 0: chunk SLOT of the previous tile is stored in this step; -1: none
-            const bool more = t + 2 < nk;
-            if (more) issue(t + 2, (t + 2) % 3);
-            load_frags(t, 1, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (SLOT >= 0) emit(std::integral_constant<int, (SLOT >= 0 ? SLOT : 0)>{});
-            constexpr int S_now = SLOT >= 0 ? SPS : 0, S_prev = SLOT >= 1 ? SPS : 0;   // (slot 0 follows a step without stores; the step after the last slot passes -2)
-            constexpr int S_after = SLOT == -2 ? SPS : 0;
-            constexpr int R0 = (READS && SLOT == 0) ? NIT : 0;                           // step 0: the operand loads are older than K-tile 2 only
-            wait_step(more, std::integral_constant<int, S_now + S_prev + S_after + R0>{});
-            __builtin_amdgcn_s_barrier();
-            load_frags(t + 1, 0, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        int t = 0;
-        if (STORES) {
-            step(0, std::integral_constant<int, 0>{}); step(1, std::integral_constant<int, 1>{});
-            step(2, std::integral_constant<int, 2>{}); step(3, std::integral_constant<int, 3>{});
-            step(4, std::integral_constant<int, 4>{}); step(5, std::integral_constant<int, 5>{});
-            step(6, std::integral_constant<int, 6>{}); step(7, std::integral_constant<int, 7>{});
-            step(8, std::integral_constant<int, -2>{});   // (the stores of step 7 may still be in flight)
-            t = 9;
-        } else if (READS) {
-            // (no pending chunks, but the operand loads sit between K-tiles 1 and 2 in the queue)
-            const bool more = 2 < nk;
-            if (more) issue(2, 2);
-            load_frags(0, 1, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            wait_step(more, std::integral_constant<int, NIT>{});
-            __builtin_amdgcn_s_barrier();
-            load_frags(1, 0, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            t = 1;
-        }
-        for (; t + 1 < nk; ++t) step(t, std::integral_constant<int, -1>{});
-        load_frags(nk - 1, 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a0, b0);
-        mma(a1, b1);
-
-        // ---- end of the tile: accumulators -> staging -> this lane's eight 16-byte chunks, kept in registers -------------------
-        __syncthreads();   // all fragment reads done, no LDS-DMA outstanding: the ring becomes the staging area
-#pragma unroll
-        for (int ni = 0; ni < NJ; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                bf16x4 v;
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) v[rr] = f2bf(acc[ni][mi][rr] * p.alpha);
-                *reinterpret_cast<bf16x4*>(stg + (mi * 16 + em) * LDE + (ni * 16 + en) * 2) = v;
-            }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + (8 * it + lane / 8) * LDE + (lane % 8) * 16);
-            if (EPI == OBTE_EPI_ADD) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(r[it][j]) + bf2f(v[j]));
-            } else if (EPI == OBTE_EPI_GELU_BWD) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * bf2f(r[it][j]));
-            }
-            pend[it] = v;
-        }
-        pend_o = o_l;
-        __syncthreads();   // the staging is free: the next tile's LDS-DMA may land
-    };
-
-    int q = blockIdx.x;
-    if (q >= ntiles) return;
-    run_tile(q, std::false_type{});
-    for (q += gridDim.x; q < ntiles; q += gridDim.x) run_tile(q, std::true_type{});
-    emit(std::integral_constant<int, 0>{}); emit(std::integral_constant<int, 1>{}); emit(std::integral_constant<int, 2>{}); emit(std::integral_constant<int, 3>{});
-    emit(std::integral_constant<int, 4>{}); emit(std::integral_constant<int, 5>{}); emit(std::integral_constant<int, 6>{}); emit(std::integral_constant<int, 7>{});
-}
-#define OBTE_INST5(AK, BK)                                                          \
-    template __global__ void gemm_v5_kernel<AK, BK, OBTE_EPI_NONE>(GemmParams);     \
-    template __global__ void gemm_v5_kernel<AK, BK, OBTE_EPI_GELU>(GemmParams);     \
-    template __global__ void gemm_v5_kernel<AK, BK, OBTE_EPI_ADD>(GemmParams);      \
-    template __global__ void gemm_v5_kernel<AK, BK, OBTE_EPI_GELU_BWD>(GemmParams);
-OBTE_INST5(true, true) OBTE_INST5(true, false)
-#undef OBTE_INST5
-
 // Explicit instantiations: with implicit instantiation alone hipcc (ROCm 7.2) emitted the host stub of only the
 // first specialisation it met; the library then failed to load with undefined kernel symbols.
 #define OBTE_INST(AK, BK, BN)                                                                    \
@@ -1145,37 +936,6 @@ using namespace obte_gemm_v2;
 // Tile width and split-K plan.  Prefer the 256-wide tile (higher FLOP per loaded byte) whenever it still yields
 // at least one workgroup per CU, directly or through a split of a long K; otherwise the 128-wide tile.
 // Split-K needs a workspace, epilogue NONE and ldd == N.
-template <bool AK, bool BK, int EPI>
-int launch5(const GemmParams& p, hipStream_t st) {
-    static bool attr_set = false;  // idempotent; a race only repeats the call
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_v5_kernel<AK, BK, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg<128>::SMEM);
-        attr_set = true;
-    }
-    const int ntiles = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL((gemm_v5_kernel<AK, BK, EPI>), dim3(ntiles < 256 ? ntiles : 256), dim3(NTHREADS), Cfg<128>::SMEM, st, p);
-    OBTE_CHECK_LAUNCH("obte_gemm_bf16");
-    return OBTE_OK;
-}
-template <bool AK, bool BK>
-int dispatch5(const GemmParams& p, int epi, hipStream_t st) {
-    switch (epi) {
-        case OBTE_EPI_NONE: return launch5<AK, BK, OBTE_EPI_NONE>(p, st);
-        case OBTE_EPI_GELU: return launch5<AK, BK, OBTE_EPI_GELU>(p, st);
-        case OBTE_EPI_ADD: return launch5<AK, BK, OBTE_EPI_ADD>(p, st);
-        case OBTE_EPI_GELU_BWD: return launch5<AK, BK, OBTE_EPI_GELU_BWD>(p, st);
-    }
-    obte_set_error("obte_gemm_bf16: epilogue %d has no persistent form", epi);
-    return OBTE_EINVAL;
-}
-// the persistent structure takes whole 256 x 128 tiles of k-contiguous A, at least two per workgroup, ten K-tiles or more
-static bool v5_eligible(const obte_gemm_args* g) {
-    if (!g->b_kmajor) { const char* e = getenv("OBTE_GEMM_V5_NN"); if (!(e && e[0] == '1')) return false; }   // (B not k-contiguous: the build spills; opt-in for experiments)
-    return g->a_kmajor && g->M % BM == 0 && g->N % 128 == 0 && g->K % BKT == 0 && g->K >= 10 * BKT && (g->M / BM) * (g->N / 128) >= 512 &&
-           (g->epilogue == OBTE_EPI_NONE || g->epilogue == OBTE_EPI_GELU || g->epilogue == OBTE_EPI_ADD || g->epilogue == OBTE_EPI_GELU_BWD) &&
-           (g->epilogue != OBTE_EPI_ADD || g->aux != nullptr);
-}
-
 struct Plan { int bn; int splits; int variant; };   // variant: 1 = first structure (gemm_bf16_v1.hip), 2 / 3 / 4 = this file (K-tile ring / half-tile ring / half-tile ring at two workgroups per CU)
 static int splits_for(int64_t tiles, int64_t nk) {
     if (tiles >= 200 || nk < 16) return 1;
@@ -1237,10 +997,9 @@ static bool lookup_plan(const obte_gemm_args* g, Plan* out, bool* near_match = n
 
 extern "C" int obte_gemm_plan_set(int a_kmajor, int b_kmajor, int epilogue, int64_t M, int64_t N, int64_t K, int variant,
                                   int bn, int splits) {
-    OBTE_REQUIRE(variant >= 1 && variant <= 7 && variant != 6 && (bn == 128 || bn == 256 || bn == 192) && splits >= 1 && splits <= 64, "obte_gemm_plan_set: bad plan");
+    OBTE_REQUIRE(variant >= 1 && variant <= 7 && variant != 5 && variant != 6 && (bn == 128 || bn == 256 || bn == 192) && splits >= 1 && splits <= 64, "obte_gemm_plan_set: bad plan");
     OBTE_REQUIRE(!(variant == 7 && (bn != 256 || splits != 1 || !obte_gemm_v7_has(a_kmajor != 0, b_kmajor != 0, epilogue))),
                  "obte_gemm_plan_set: the persistent continuous-ring structure is 256 wide, no split-K, x W^T and dy W layouts with their epilogues");
-    OBTE_REQUIRE(!(variant == 5 && (bn != 128 || splits != 1 || !a_kmajor)), "obte_gemm_plan_set: the persistent structure is 128 wide, k-contiguous A, no split-K");
     OBTE_REQUIRE(!(bn == 192 && (variant != 2 || splits != 1 || !a_kmajor || !b_kmajor || epilogue == OBTE_EPI_GELU_BWD)),
                  "obte_gemm_plan_set: the 192-wide tile exists for the K-tile ring, k-contiguous operands, no split-K");
     OBTE_REQUIRE(!(variant == 3 && bn != 256), "obte_gemm_plan_set: the four-half-stage structure is 256 wide");
@@ -1393,7 +1152,6 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     }
     if (pl.splits > 1 && (!can_split || (int64_t)pl.splits * g->M * g->N * 4 > workspace_bytes)) pl = make_plan(g->M, g->N, g->K, false);
     if (pl.bn == 192 && !(g->a_kmajor && g->b_kmajor && g->epilogue != OBTE_EPI_GELU_BWD)) pl = make_plan(g->M, g->N, g->K, false);
-    if (pl.variant == 5 && !v5_eligible(g)) pl = make_plan(g->M, g->N, g->K, false);   // (a plan borrowed by a near shape, or edge tiles)
     if (pl.variant == 7 && !obte_gemm_v7_eligible(g)) pl = Plan{256, 1, 3};              // (the same: the half-tile ring one tile per workgroup)
     // profiler record kind = layout/epilogue code + 1000 * kernel structure (1: gemm_bf16_kernel, 2: gemm_v2_kernel, 3: gemm_v3_kernel)
     const int kind0 = (g->a_kmajor ? 8 : 0) + (g->b_kmajor ? 4 : 0) + g->epilogue;
@@ -1425,14 +1183,10 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
         obte_prof_end(prof7, st);
         return rc;
     }
-    const bool v5 = pl.variant == 5 && pl.bn == 128 && p.splits == 1;
-    const bool v3 = !v5 && use_v3(pl.variant) && pl.bn == 256 && long_enough;
-    const bool v4 = !v5 && !v3 && use_v4(pl.variant) && pl.bn == 128 && long_enough;
-    const int prof = obte_prof_begin(st, kind0 + (v5 ? 5000 : (v3 ? 3000 : (v4 ? 4000 : 2000))), g->M, g->N, g->K);
-    if (v5) {
-        if (g->b_kmajor) rc = dispatch5<true, true>(p, g->epilogue, st);
-        else rc = dispatch5<true, false>(p, g->epilogue, st);
-    } else if (v4) {
+    const bool v3 = use_v3(pl.variant) && pl.bn == 256 && long_enough;
+    const bool v4 = !v3 && use_v4(pl.variant) && pl.bn == 128 && long_enough;
+    const int prof = obte_prof_begin(st, kind0 + (v3 ? 3000 : (v4 ? 4000 : 2000)), g->M, g->N, g->K);
+    if (v4) {
         if (g->a_kmajor && g->b_kmajor) rc = dispatch4<true, true>(p, g->epilogue, st);
         else if (g->a_kmajor && !g->b_kmajor) rc = dispatch4<true, false>(p, g->epilogue, st);
         else if (!g->a_kmajor && g->b_kmajor) rc = dispatch4<false, true>(p, g->epilogue, st);
@@ -1448,7 +1202,7 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
     else if (!g->a_kmajor && g->b_kmajor) rc = dispatch<false, true>(p, g->epilogue, pl.bn, st);
     else rc = dispatch<false, false>(p, g->epilogue, pl.bn, st);
 #ifdef OBTE_DEBUG_HOOKS
-    if (rc == OBTE_OK && p.dbg_times && !v5) debug_gemm_report(p, v3 ? 3 : (v4 ? 4 : 2), g->epilogue, st);
+    if (rc == OBTE_OK && p.dbg_times) debug_gemm_report(p, v3 ? 3 : (v4 ? 4 : 2), g->epilogue, st);
 #endif
     if (rc == OBTE_OK && p.splits > 1) {
         const int64_t mn = g->M * g->N;

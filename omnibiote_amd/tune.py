@@ -65,9 +65,6 @@ def candidates(M: int, N: int, K: int, epi: int, a_kmajor: bool = False, b_kmajo
     c = [(1, 128, 1), (2, 128, 1)]
     if a_kmajor and b_kmajor and N % 192 == 0 and epi != L.EPI_GELU_BWD:
         c.append((2, 192, 1))      # 256 x 192 tiles: full rounds where N / 256 leaves a ragged one (c_attn: 3072 -> 512 tiles)
-    if (a_kmajor and b_kmajor and M % 256 == 0 and N % 128 == 0 and K % 64 == 0 and K >= 640 and (M // 256) * (N // 128) >= 512
-            and epi in (L.EPI_NONE, L.EPI_GELU, L.EPI_ADD, L.EPI_GELU_BWD)):
-        c.append((5, 128, 1))      # persistent 256 x 128 tiles, a tile's stores leave under the next tile's main loop
     if v7_applies(M, N, K, epi, a_kmajor, b_kmajor):
         c.append((7, 256, 1))      # the 256 x 256 half-tile ring, persistent: the LDS-DMA stream runs on across tiles (csrc/gemm_bf16_v7.hip)
     if K >= 128:
@@ -95,7 +92,7 @@ def rank_candidates(times: dict) -> list:
     goes first — inside the step, with warm operands and neighbours, it is the one that holds its time (the row-compact readout
     input gradient: 160-195 us on the half-tile ring against 190-215 us when the K-tile ring won the coin toss)."""
     results = sorted((t, c[0], c[1], c[2]) for c, t in times.items())
-    prefer = {7: -1, 5: 0, 3: 1, 2: 2, 4: 3, 1: 4}
+    prefer = {7: 0, 3: 1, 2: 2, 4: 3, 1: 4}
     tied = [r for r in results if r[0] <= results[0][0] * 1.03]
     tied.sort(key=lambda r: (prefer.get(r[1], 9), r[0]))
     return tied[:1] + [r for r in results if r is not tied[0]]
@@ -188,8 +185,12 @@ def load_plans(path: str) -> int:
         return import_plans(json.load(f))
 
 
+REMOVED_STRUCTURES = (5, 6)   # plan files of older builds may name them: those shapes are simply tuned again
+
+
 def import_plans(rows: list) -> int:
     lib = L.lib()
+    rows = [r for r in rows if int(r["variant"]) not in REMOVED_STRUCTURES]
     for r in rows:
         L.check(lib.obte_gemm_plan_set(int(r["a_kmajor"]), int(r["b_kmajor"]), int(r["epilogue"]), int(r["M"]), int(r["N"]), int(r["K"]),
                                        int(r["variant"]), int(r["bn"]), int(r["splits"])), "obte_gemm_plan_set")

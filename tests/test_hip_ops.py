@@ -843,55 +843,6 @@ def test_gemm_both_tile_widths(monkeypatch, bn):
     close(o.linear_fwd(x.to(DEV), w.to(DEV), alpha=1 / 42.0), acc / 42.0, atol=2e-3, what="alpha")
 
 
-def test_gemm_persistent_structure_with_deferred_stores():
-    """Structure 5 (persistent 256 x 128 tiles; a tile's output chunks wait in registers and are stored from inside the next
-    tile's main loop): x @ W^T plain, GELU pair, residual add, at 2, 3 and 4+ tiles per workgroup and K of 10 and more K-tiles —
-    against the fp32 reference, against the one-tile-per-workgroup structure bit for bit (same per-tile arithmetic), and with an
-    exact identity product."""
-    o, lib = ops(), L().lib()
-    def plan(epi, M, N, K, variant):
-        L().check(lib.obte_gemm_plan_set(1, 1, epi, M, N, K, variant, 128, 1), "obte_gemm_plan_set")
-    try:
-        for (M, N, K) in [(8192, 2048, 640), (8192, 4096, 1024), (4096, 8192 + 128 * 3, 704), (16384, 1024, 1024)]:
-            x, w = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=0.2)
-            xd, wd = x.to(DEV), w.to(DEV)
-            plan(L().EPI_NONE, M, N, K, 5)
-            got5 = o.linear_fwd(xd, wd)
-            plan(L().EPI_NONE, M, N, K, 2)
-            got2 = o.linear_fwd(xd, wd)
-            assert torch.equal(got5, got2), f"persistent vs K-tile ring {M}x{N}x{K}"
-            rows = torch.arange(0, M, 131)
-            close(got5[rows.to(DEV)], x[rows].float() @ w.float().t(), atol=0.02 * math.sqrt(K) * 0.2, what=f"NT persistent {M}x{N}x{K}")
-        M, N, K = 8192, 2048, 1024
-        x, w, r = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=0.2), rnd(M, N, seed=9)
-        xd, wd, rd = x.to(DEV), w.to(DEV), r.to(DEV)
-        for epi in (L().EPI_ADD, L().EPI_GELU):
-            outs = {}
-            for variant in (5, 2):
-                plan(epi, M, N, K, variant)
-                outs[variant] = o.linear_fwd(xd, wd, epilogue=epi, aux=rd if epi == L().EPI_ADD else None)
-            if epi == L().EPI_GELU:
-                assert torch.equal(outs[5][0], outs[2][0]) and torch.equal(outs[5][1], outs[2][1]), "GELU pair"
-                acc = (x[:256].float() @ w.float().t())
-                close(outs[5][1][:256], R.gelu_erf(acc.to(BF).float()), atol=0.03, what="gelu act persistent")
-            else:
-                assert torch.equal(outs[5], outs[2]), "residual add"
-                close(outs[5][:256], r[:256].float() + (x[:256].float() @ w.float().t()).to(BF).float(), atol=0.03, what="add persistent")
-        plan(L().EPI_NONE, 8192, 2048, 1024, 5)
-        eye = torch.zeros(8192, 1024); eye[torch.arange(1024), torch.arange(1024)] = 1.0; eye[4096 + torch.arange(1024), torch.arange(1024)] = 1.0
-        b = (torch.arange(2048 * 1024).reshape(2048, 1024) % 251 - 125).float().to(BF)
-        got = o.linear_fwd(eye.to(BF).to(DEV), b.to(DEV)).cpu().float()
-        assert torch.equal(got[:1024], b.float().t()) and torch.equal(got[4096:5120], b.float().t()) and not got[1024:4096].any()
-        # shapes the structure does not take fall back to the heuristic plan instead of failing
-        plan(L().EPI_NONE, 512, 512, 1024, 5)
-        xs, ws = rnd(512, 1024, seed=1), rnd(512, 1024, seed=2, scale=0.2)
-        close(o.linear_fwd(xs.to(DEV), ws.to(DEV)), xs.float() @ ws.float().t(), atol=0.02 * 32 * 0.2, what="fallback")
-        with pytest.raises(RuntimeError, match="persistent structure"):
-            L().check(lib.obte_gemm_plan_set(0, 0, 0, 8192, 4096, 1024, 5, 128, 1), "obte_gemm_plan_set")
-    finally:
-        L().check(lib.obte_gemm_plan_clear(), "obte_gemm_plan_clear")
-
-
 def test_gemm_persistent_continuous_ring_structure():
     """Structure 7 (csrc/gemm_bf16_v7.hip: the 256 x 256 half-tile ring as a persistent kernel — the LDS-DMA stream runs on across
     tiles, each wave's epilogue goes through 4 KiB of staging of its own, stores drain under the next tile's loop): every layout and

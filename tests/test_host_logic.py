@@ -260,21 +260,25 @@ def test_tuner_ranking_breaks_ties_towards_the_deeper_ring_and_lists_the_masked_
 
 def test_tuner_lists_the_192_wide_and_the_persistent_structure_only_where_they_apply():
     """tune.candidates: the 256 x 192 tile (structure 2) for x W^T products whose N is a multiple of 192 and whose epilogue it
-    implements; the persistent structure 5 for whole 256 x 128 tiles of k-contiguous operands, >= 2 tiles per workgroup, K >= 640."""
+    implements; the persistent continuous-ring structure 7 for whole 256 x 256 tiles, at least one per CU, of the x W^T and dy W
+    layouts with the epilogues it is built for."""
     from omnibiote_amd import tune
     L = _lib
-    c = tune.candidates(8192, 3072, 1024, L.EPI_ROPE_QK, True, True)
-    assert (2, 192, 1) in c and (5, 128, 1) not in c                      # RoPE epilogue: no persistent form
-    c = tune.candidates(8192, 3072, 1024, L.EPI_NONE, True, True)
-    assert (2, 192, 1) in c and (5, 128, 1) in c
+    c = tune.candidates(4096, 3072, 1024, L.EPI_ROPE_QK, True, True)
+    assert (2, 192, 1) in c and (7, 256, 1) not in c                      # 16 x 12 = 192 tiles: fewer than the CUs
+    c = tune.candidates(32768, 3072, 1024, L.EPI_ROPE_QK, True, True)
+    assert (2, 192, 1) in c and (7, 256, 1) in c
     assert (2, 192, 1) not in tune.candidates(8192, 3072, 1024, L.EPI_NONE, True, False)       # x W layouts only
     assert (2, 192, 1) not in tune.candidates(8192, 3072, 1024, L.EPI_GELU_BWD, True, True)
     assert (2, 192, 1) not in tune.candidates(8192, 4096, 1024, L.EPI_GELU, True, True)        # 4096 is not a multiple of 192
-    assert (5, 128, 1) in tune.candidates(8192, 4096, 1024, L.EPI_GELU, True, True)
-    assert (5, 128, 1) not in tune.candidates(8192, 1024, 1024, L.EPI_ADD, True, True)         # 256 tiles: one per workgroup
-    assert (5, 128, 1) in tune.candidates(32768, 1024, 1024, L.EPI_ADD, True, True)
-    assert (5, 128, 1) not in tune.candidates(8192, 4096, 576, L.EPI_NONE, True, True)         # nine K-tiles: too short
-    assert (5, 128, 1) not in tune.candidates(8200, 4096, 1024, L.EPI_NONE, True, True)        # ragged rows
+    assert (7, 256, 1) in tune.candidates(8192, 4096, 1024, L.EPI_GELU, True, True)            # 512 tiles
+    assert (7, 256, 1) not in tune.candidates(8192, 1024, 1024, L.EPI_ADD, True, True)         # 128 tiles: fewer than the CUs
+    assert (7, 256, 1) in tune.candidates(32768, 4096, 1024, L.EPI_GELU_BWD, True, False)
+    assert (7, 256, 1) not in tune.candidates(32768, 4096, 1024, L.EPI_GELU_BWD, True, True)   # GELU' exists for dy W only
+    assert (7, 256, 1) not in tune.candidates(32768, 1024, 1024, L.EPI_NONE, False, False)     # weight-gradient layout: not built
+    assert (7, 256, 1) not in tune.candidates(8200, 4096, 1024, L.EPI_NONE, True, True)        # ragged rows
+    assert (7, 256, 1) not in tune.candidates(8192, 4096, 192, L.EPI_NONE, True, True)         # three K-tiles: too short
+    assert not any(v in (5, 6) for v, _, _ in tune.candidates(32768, 4096, 1024, L.EPI_NONE, True, True))   # structures removed
 
 
 def test_masked_gradient_handoff_checks_storage_shape_version_probability_and_seed(monkeypatch):

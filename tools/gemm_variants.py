@@ -21,7 +21,7 @@ rope = None
 if epi == 5:
     tab = torch.randn(1024, 64, device=dev, generator=g)
     rope = (torch.cos(tab), torch.sin(tab), 1024, 128)
-for variant, bn in ((2, 128), (5, 128), (4, 128), (2, 256), (3, 256), (7, 256)):
+for variant, bn in ((2, 128), (4, 128), (2, 256), (3, 256), (7, 256)):
     if lib.obte_gemm_plan_set(int(ak), int(bk), epi, M, N, K, variant, bn, 1) != 0:
         continue
     res = {}

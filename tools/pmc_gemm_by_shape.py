@@ -82,7 +82,7 @@ def run(rows, plans):
     torch.cuda.synchronize()
 
 
-GEMM = ("gemm_v2_kernel", "gemm_v3_", "gemm_v4_kernel", "gemm_v5_kernel", "gemm_v7_kernel", "gemm_bf16_kernel", "splitk_reduce")
+GEMM = ("gemm_v2_kernel", "gemm_v3_", "gemm_v4_kernel", "gemm_v7_kernel", "gemm_bf16_kernel", "splitk_reduce")
 
 
 def load(path):

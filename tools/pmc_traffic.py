@@ -7,7 +7,7 @@ import csv
 import json
 import sys
 
-GEMM = ("gemm_v2_kernel", "gemm_v3_", "gemm_v4_kernel", "gemm_v5_kernel", "gemm_bf16_kernel")
+GEMM = ("gemm_v2_kernel", "gemm_v3_", "gemm_v4_kernel", "gemm_v7_kernel", "gemm_bf16_kernel")
 WITH_REDUCE = GEMM + ("splitk_reduce",)   # a split-K launch is one call of the entry point: its reduce kernel counts with it
 
 

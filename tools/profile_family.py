@@ -4,7 +4,7 @@ object (whose `avg_launch_ms` is the mean over every launch of the GEMM family).
 import csv
 import sys
 
-FAMILIES = [("gemm", ("gemm_v2_kernel", "gemm_v3_", "gemm_v4_kernel", "gemm_v5_kernel", "gemm_bf16_kernel")), ("splitk_reduce", ("splitk_reduce",)),
+FAMILIES = [("gemm", ("gemm_v2_kernel", "gemm_v3_", "gemm_v4_kernel", "gemm_v7_kernel", "gemm_bf16_kernel")), ("splitk_reduce", ("splitk_reduce",)),
             ("attn_fwd", ("attn_fwd_kernel",)),
             ("attn_bwd", ("attn_bwd_", "attn_delta", "attn_dq_reduce")),   # (attn_bwd_prep_kernel, attn_bwd_fused_kernel, the dQ / dK/dV pair)
             ("layernorm", ("ln_",)),
