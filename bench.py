@@ -629,7 +629,7 @@ def main():
                         return json.load(f).get("micro_batches_per_pass", 1) == a.micro_batches_per_pass
                 except Exception:
                     return False
-            pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_gemm_family_traffic.json", "r03_pmc_gemm_family_traffic.json", "r02_pmc_gemm_family_traffic.json"))
+            pmc = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_gemm_family_traffic.json", "r04_pmc_gemm_family_traffic.json", "r03_pmc_gemm_family_traffic.json", "r02_pmc_gemm_family_traffic.json"))
                         if os.path.exists(q) and _pmc_matches(q)), "")
             default_workload = (a.config == "small" and a.readout == "masked" and a.dropout == 0.0 and not a.multi_document
                                 and a.rows_per_rank == 128 and a.mini_batch_size == 8)
@@ -639,6 +639,11 @@ def main():
                 roofline["traffic"] = round(t["traffic_bytes_per_launch"])
                 roofline["traffic_unit"] = "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE)"
                 roofline["traffic_source"] = f"committed PMC pass ({os.path.basename(pmc)}): a static, pre-recorded figure, not measured in this run"
+                by_shape = os.path.join(ROOT, "profiles", "r05_pmc_gemm_by_shape.json")
+                if os.path.exists(by_shape):   # which launches read more than their operands, and by how much (tools/pmc_gemm_by_shape.py)
+                    with open(by_shape) as f:
+                        roofline["traffic_by_shape"] = {"source": os.path.basename(by_shape), "read_over_operands": {
+                            q["name"]: q["read_ratio"] for q in json.load(f)["shapes"]}}
             if a.shapes_out:
                 tab = {}
                 for t, d, k in zip(ms, dims, kind):

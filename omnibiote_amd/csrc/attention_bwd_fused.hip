@@ -30,6 +30,13 @@ using namespace obte_attn;
 
 constexpr int FB_NW = 4;       // waves per workgroup (one per SIMD)
 constexpr int FB_KEYS = 256;   // keys per workgroup: 64 per wave, two 32-key MFMA tiles
+#ifndef FB_FIN_IN_LOOP
+#define FB_FIN_IN_LOOP 1
+#endif
+#ifndef FB_RQ_AT
+#define FB_RQ_AT 2   // the C0 step that requests the rotation entries
+#endif
+constexpr bool FIN_IN_LOOP = FB_FIN_IN_LOOP != 0;   // a chain's last member finishes its dQ tile where it forms it (0: in a pass after the loop, as in round 4)
 #ifndef FB_RA
 #define FB_RA 4
 #define FB_RD 4
@@ -402,15 +409,31 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     };
     // the last member of a chain: softmax scale, inverse RoPE, one rounding to bf16; registers 4 i .. 4 i + 3 = head-dim columns
     // 32 wave + 8 i + 4 h .. + 3 of query 32 t + (lane & 31)
-    struct RopeQ { float2 c[4], s[4]; };
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    struct RopeQ { v2f c[4], s[4]; };
     auto load_rope = [&](int t, RopeQ& r) {
         const int q = min(t * 32 + (lane & 31), T - 1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t at = (int64_t)q * (D / 2) + (32 * wave + 8 * i + 4 * h) / 2;
-            r.c[i] = *reinterpret_cast<const float2*>(p.rope_cos + at);
-            r.s[i] = *reinterpret_cast<const float2*>(p.rope_sin + at);
+            r.c[i] = *reinterpret_cast<const v2f*>(p.rope_cos + at);
+            r.s[i] = *reinterpret_cast<const v2f*>(p.rope_sin + at);
         }
+    };
+    // the loop's form: register-destination loads through asm, NOT waited for in the statement — the loop's own counted wait in A1
+    // covers them (they are older than everything it leaves in flight) and every use is made to depend on that wait statement; that
+    // hipcc leaves the registers alone in between is what tools/fused_audit.py checks on the ISA (tests/test_host_logic.py runs it)
+    auto rope_request = [&](int t, RopeQ& r) {
+        const int q = min(t * 32 + (lane & 31), T - 1);
+        const int64_t at = (int64_t)q * (D / 2) + (32 * wave + 4 * h) / 2;   // piece i: + 4 i floats
+        const float* pc = p.rope_cos + at;
+        const float* ps = p.rope_sin + at;
+        asm volatile("global_load_dwordx2 %0, %8, off\n\tglobal_load_dwordx2 %1, %8, off offset:16\n\t"
+                     "global_load_dwordx2 %2, %8, off offset:32\n\tglobal_load_dwordx2 %3, %8, off offset:48\n\t"
+                     "global_load_dwordx2 %4, %9, off\n\tglobal_load_dwordx2 %5, %9, off offset:16\n\t"
+                     "global_load_dwordx2 %6, %9, off offset:32\n\tglobal_load_dwordx2 %7, %9, off offset:48"
+                     : "=&v"(r.c[0]), "=&v"(r.c[1]), "=&v"(r.c[2]), "=&v"(r.c[3]), "=&v"(r.s[0]), "=&v"(r.s[1]), "=&v"(r.s[2]), "=&v"(r.s[3])
+                     : "v"(pc), "v"(ps) : "memory");
     };
     auto store_final = [&](int t, const f32x16& dq, const RopeQ& r, int i) {   // piece i of 4
         const int q = t * 32 + (lane & 31);
@@ -421,6 +444,20 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
             g[0] = e0; g[1] = o0; g[2] = e1; g[3] = o1;
         }
         if (q < T) *reinterpret_cast<bf16x4*>(p.dqkv + (b * T + q) * ld + hd * D + 32 * wave + 8 * i + 4 * h) = bf16x4{f2bf(g[0]), f2bf(g[1]), f2bf(g[2]), f2bf(g[3])};
+    };
+    auto store_final4 = [&](int t, const f32x4& x, const RopeQ& r, int i) {   // the same from one piece's four values
+        const int q = t * 32 + (lane & 31);
+        float g[4] = {x[0] * p.scale, x[1] * p.scale, x[2] * p.scale, x[3] * p.scale};
+        if (p.rope_cos) {
+            const float e0 = g[0] * r.c[i].x + g[1] * r.s[i].x, o0 = -g[0] * r.s[i].x + g[1] * r.c[i].x;
+            const float e1 = g[2] * r.c[i].y + g[3] * r.s[i].y, o1 = -g[2] * r.s[i].y + g[3] * r.c[i].y;
+            g[0] = e0; g[1] = o0; g[2] = e1; g[3] = o1;
+        }
+        if (q < T) *reinterpret_cast<bf16x4*>(p.dqkv + (b * T + q) * ld + hd * D + 32 * wave + 8 * i + 4 * h) = bf16x4{f2bf(g[0]), f2bf(g[1]), f2bf(g[2]), f2bf(g[3])};
+    };
+    typedef __attribute__((address_space(3))) f32x4* lds_wf128_t;
+    auto acc_park = [&](const f32x16& dq, int i) {   // piece i of the finished sum into this wave's staging area, where acc_add reads piece i from
+        *(lds_wf128_t)(uintptr_t)(acc_rd + (uint32_t)(i * 1024)) = f32x4{dq[4 * i], dq[4 * i + 1], dq[4 * i + 2], dq[4 * i + 3]};
     };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
@@ -459,7 +496,8 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
 #endif
     // state carried over the loop edge: the A-phase fragment ring (k-step n = 8 kt + s in slot n % 3, read two k-steps ahead),
     // key tile 0's two chains holding their row constants, and whether the slice needs the range test
-    constexpr int RA = FB_RA, RD = FB_RD, RC = FB_RC;   // fragment rings: a fragment is read RING - 1 steps ahead of its MFMA
+    constexpr int RA = DROP ? 3 : FB_RA, RD = FB_RD, RC = FB_RC;   // fragment rings: a fragment is read RING - 1 steps ahead of its MFMA
+                                                                  // (dropout: the keep words and key tile 0's -delta chunks take the A ring's fourth slot; with it hipcc spills a V fragment)
     bf16x8 fq[RA], fd[RA], fk[RA];
     f32x16 sc0, dp0;
     bool inside = true;
@@ -531,6 +569,13 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         // the previous slice's tile so far: once it is this workgroup's turn (in steady state the counter polled an iteration ago
         // already says so), four LDS-DMA pieces in A0's first slots; they are read back in A1
         if (take_p) wait_turn(t_prev, info_prev & 0x7f, have_prev);
+        // A chain's last member finishes the previous slice's tile itself: the summed tile is parked in the wave's own staging area
+        // (A1, where it would otherwise leave for the scratch buffer; the area is free between this iteration's read of the incoming
+        // tile and the next iteration's request), the rotation entries of its queries are requested in C0, and the tile is scaled,
+        // rotated back, rounded once and stored piece by piece in C1, where the registers of key tile 1's chains are free again.
+        RopeQ rq;
+        f32x4 fin_piece;
+        const bool fin_p = FIN_IN_LOOP && last_p && !first_it;
         // the first fragments and the row constants of this slice (its tiles were published by the barrier that ended the previous iteration)
 #pragma unroll
         for (int n = 0; n < RA - 1; ++n) rdA(sb, n);
@@ -681,7 +726,10 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
                 else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                 acc_add(dq);
             }
-            if (n >= 9 && n < 13 && !first_it && !OBTE_SKIP(64)) store_acc(t_prev, dq, n - 9);   // (a chain's last member too: it finishes its tiles after the loop)
+            if (n >= 9 && n < 13 && !first_it && !OBTE_SKIP(64)) {
+                if (fin_p) acc_park(dq, n - 9);   // the chain ends here: finished in C1
+                else store_acc(t_prev, dq, n - 9);
+            }
             if (n == 15) rd_const1(0);
             if (n == 8) { sc1 = zero16; if (!inside) mask_init(sc1, 1, q0); }
             sc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % RA], fk[n % RA], sc1, 0, 0, 0);
@@ -700,6 +748,7 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         for (int g = 0; g < 8; ++g) {
             const int kk = g >> 2, dt = g & 3;
             rdC(g + RC - 1);   // (the last ones: C1's first steps, the same fragments again)
+            if (g == FB_RQ_AT && fin_p && p.rope_cos) rope_request(t_prev, rq);
             if (g >= 4) ds_words(dw0, 0, g - 4);
             if ((g & 1) == 0 && g / 2 + 1 < 4) rd_const1(g / 2 + 1);
             if (g == 0) sm1_exp(0);
@@ -716,7 +765,13 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
             const int kk = g >> 2, dt = g & 3;
             if (8 + g + RC - 1 < 16) rdC(8 + g + RC - 1);
             if (g < 4) ds_words(dw1, 1, g);
+            if (fin_p && !OBTE_SKIP(64)) {
+                // (nothing younger than the request is in flight: every use of the entries hangs on this statement's outputs)
+                if (g == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rq.c[0]), "+v"(rq.c[1]), "+v"(rq.c[2]), "+v"(rq.c[3]), "+v"(rq.s[0]), "+v"(rq.s[1]), "+v"(rq.s[2]), "+v"(rq.s[3]) :: "memory");
+                if ((g & 1) == 0) fin_piece = lds_f4(acc_rd, (g >> 1) * 1024);
+            }
             mfma_acc(dv[1][dt], cdo[(8 + g) % RC], frag_of(pw1, kk)); OBTE_SB();
+            if (fin_p && (g & 1) == 1 && !OBTE_SKIP(64)) store_final4(t_prev, fin_piece, rq, g >> 1);
             mfma_acc(dk[1][dt], cq[(8 + g) % RC], frag_of(dw1, kk)); OBTE_SB();
         }
         OBTE_PHASE(4);
@@ -758,8 +813,15 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         for (int ks = 0; ks < FB_KEYS / 16; ++ks)
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(Kblk, 16 * ks, wave, lane), ds_frag<D>(img, 16 * ks, lane), dq, 0, 0, 0);
         if (take_p) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); acc_add(dq); }
+        if (FIN_IN_LOOP && (info_prev & 0x80)) {
+            RopeQ rq;
+            if (p.rope_cos) load_rope(t_prev, rq);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) store_acc(t_prev, dq, i);
+            for (int i = 0; i < 4; ++i) store_final(t_prev, dq, rq, i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) store_acc(t_prev, dq, i);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // every wave's tiles have left; and every wave is done with the K rows (all 256 feed each wave's dQ tiles): they now carry rows out
@@ -810,7 +872,7 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     // addresses): softmax scale, inverse RoPE, one rounding to bf16.  Done here and not in the loop, where the rotation-table
     // entries would hold 16 registers through its tightest phase — and AFTER the dK / dV rows have left, so that the 256
     // accumulator registers are free and eight tiles (with their rotation entries) travel per dependent round trip.
-    {
+    if (!FIN_IN_LOOP) {
         constexpr int FIN = 8;
         int* lastlist = kbb;   // (the key blocks' ranges are no longer needed) compact list of those slices, in visiting order
         int n_last = 0;

@@ -216,7 +216,13 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     obte_bf16* dym = (obte_bf16*)(S + W.dym);
     obte_bf16* dym2 = (obte_bf16*)(S + W.dym2);
     const bool drop = d->dropout_p > 0.f;
-    const bool grouped = use_grouped_wgrad(C, M);
+    // rows form (the model's last block): only the attention half's two weight gradients are left for the grouped launch — 64
+    // tiles of K = M that keep a quarter of the chip busy for the whole launch while the input gradient's 512 short tiles finish on
+    // the rest in a fifth of the time (686 us for what three balanced launches do in ~430: round-5 profile) — so they go out as
+    // their own split-K launches with the tuned plans.  OBTE_GROUPED_LAST=1 restores the grouped form (A/B timing).
+    static const bool grouped_last = [] { const char* e = getenv("OBTE_GROUPED_LAST"); return e && e[0] == '1'; }();
+    const bool grouped_ok = use_grouped_wgrad(C, M);
+    const bool grouped = grouped_ok && (d->out_rows == nullptr || grouped_last);
     // rows form: the MLP half ran on Mm = n_out_rows positions (dy is [Mm, C]); its two weight gradients contract over those rows
     // and go out as their own launches, the grouped launch keeps the attention half's
     const bool rows_form = d->out_rows != nullptr;
@@ -233,7 +239,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     }
     TRY(gemm(dy_mlp, d->mlp_w, dhpre, Mm, 4 * C, C, C, 4 * C, 1, 0, OBTE_EPI_GELU_BWD, hpre, nullptr, s));      // dhpre = (dy W_mlp) * gelu'(h): hpre holds the derivative
     // rows form with enough rows for the grouped kernel's K: the MLP half's two weight gradients (K = Mm) share one launch below
-    const bool pair_mlp = rows_form && grouped && Mm >= 256;
+    const bool pair_mlp = rows_form && grouped_ok && Mm >= 256;
     if (!grouped_mlp && !pair_mlp) TRY(gemm(dy_mlp, hact, dmlp_w, C, 4 * C, Mm, C, 4 * C, 0, 0, wepi, accumulate_matrices ? dmlp_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_mlp = dy^T hact
     TRY(gemm(dhpre, d->fc_w, dh, Mm, C, 4 * C, 4 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s, rows_form ? gws : nullptr, rows_form ? W.gemmws_bytes : 0));   // dh2 = dhpre W_fc (rows form: few tiles over K = 4C, split-K)
     if (!grouped_mlp && !pair_mlp) TRY(gemm(dhpre, h2, dfc_w, 4 * C, C, Mm, 4 * C, C, 0, 0, wepi, accumulate_matrices ? dfc_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_fc = dhpre^T h2

@@ -6,7 +6,7 @@ import sys
 s = open(sys.argv[1]).read()
 want = sys.argv[2]
 dump = sys.argv[sys.argv.index("--dump") + 1] if "--dump" in sys.argv else None
-for k in re.split(r'\n(?=_Z\w+:\s*\n)', s):
+for k in re.split(r'\n(?=_Z\w+:[^\n]*\n)', s):
     m = re.match(r'(_Z\w+):', k)
     if not m or want not in m.group(1):
         continue
