@@ -230,31 +230,19 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         const int64_t row0 = (int64_t)kb * FB_KEYS;
         dmk.issue(p.qkv + (b * T + row0) * ld + C + hd * D, (((int64_t)T - row0) * ld - (C + hd * D)) * 2, Kblk, wave);
     }
-    // the slices this key block sweeps, their visiting order and, for each, this workgroup's place in the slice's hand-off chain
-    // (header): tab[i] = place | last << 7 of the i-th slice visited, s(i) = t_begin + (i + rot) mod n
-    int* kbb = scratch + 16;                                        // [nkb][2] slice ranges of this batch element's key blocks
-    uint8_t* tab = reinterpret_cast<uint8_t*>(scratch) + 64 + 1024;   // (the 1 KiB in between holds kbb: nkb <= 120)
-    for (int i = tid; i < 2 * fp.nkb; i += FB_NW * 64) kbb[i] = fp.kb_bounds[b * fp.nkb * 2 + i];
-    __syncthreads();
-    const int t_begin = __builtin_amdgcn_readfirstlane(kbb[2 * kb]);
-    const int t_end = __builtin_amdgcn_readfirstlane(kbb[2 * kb + 1]);
-    const int n_sl = t_end - t_begin;
-    const int rot = n_sl > 0 ? (int)(((int64_t)kb * n_sl) / fp.nkb) : 0;
-    for (int i = tid; i < n_sl; i += FB_NW * 64) {
-        const int s = t_begin + (i + rot) % n_sl;
-        int place = 0, cnt = 0;
-        for (int k2 = 0; k2 < fp.nkb; ++k2) {
-            const int tb2 = kbb[2 * k2], te2 = kbb[2 * k2 + 1], n2 = te2 - tb2;
-            if (s < tb2 || s >= te2) continue;
-            ++cnt;
-            if (k2 == kb) continue;
-            const int rot2 = (int)(((int64_t)k2 * n2) / fp.nkb);
-            const int tau2 = (s - tb2 - rot2 + n2) % n2;
-            if (tau2 < i || (tau2 == i && k2 < kb)) ++place;
-        }
-        tab[i] = (uint8_t)(place | ((place == cnt - 1) ? 0x80 : 0));
+    // The slices this key block sweeps: its own range straight from the prep kernel's table (two scalar loads: uniform), so that the
+    // first slice's tiles can be requested beside the K rows and the V fragments — ONE memory round trip for the whole prologue
+    // (it used to be three in a row: K / V / the table, then the chain places, then the first slice).
+    // (a SCALAR load: it has its own counter, so reading it does not wait for the vector loads issued above)
+    int t_begin, t_end;
+    {
+        const int32_t* bp = fp.kb_bounds + (b * fp.nkb + kb) * 2;
+        unsigned long long both;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(both) : "s"(bp) : "memory");
+        t_begin = (int)(both & 0xffffffffu); t_end = (int)(both >> 32);
     }
-    // (published to every wave by the barrier that ends the prologue)
+    const int n_sl = t_end - t_begin;
+    const int rot = n_sl > 0 ? (int)(((unsigned)kb * (unsigned)n_sl) / (unsigned)fp.nkb) : 0;
 
     const bf16* qbase = p.qkv + b * T * ld + hd * D;
     const bf16* dobase = p.d_o + b * T * C + hd * D;
@@ -328,9 +316,32 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
 #pragma unroll
         for (int j = 0; j < 4; ++j) issue_piece(0, t0, j);
         load_stats(t0 * 32);
-        store_stats(stage_of(0), t0 * 32);
         if (DROP) { kw[0] = kw_src[0][(int64_t)t0 * T]; kw[1] = kw_src[1][(int64_t)t0 * T]; }
     }
+    // the visiting order and, for each slice, this workgroup's place in the slice's hand-off chain (header): tab[i] = place | last << 7
+    // of the i-th slice visited, s(i) = t_begin + (i + rot) mod n — computed while the prologue's loads are in flight
+    int* kbb = scratch + 16;                                        // [nkb][2] slice ranges of this batch element's key blocks
+    uint8_t* tab = reinterpret_cast<uint8_t*>(scratch) + 64 + 1024;   // (the 1 KiB in between holds kbb: nkb <= 120)
+    for (int i = tid; i < 2 * fp.nkb; i += FB_NW * 64) kbb[i] = fp.kb_bounds[b * fp.nkb * 2 + i];
+    __syncthreads();
+    for (int i = tid; i < n_sl; i += FB_NW * 64) {
+        const unsigned x = (unsigned)(i + rot);
+        const int s = t_begin + (int)(x >= (unsigned)n_sl ? x - (unsigned)n_sl : x);
+        int place = 0, cnt = 0;
+        for (int k2 = 0; k2 < fp.nkb; ++k2) {
+            const int tb2 = kbb[2 * k2], te2 = kbb[2 * k2 + 1], n2 = te2 - tb2;
+            if (s < tb2 || s >= te2) continue;
+            ++cnt;
+            if (k2 == kb) continue;
+            const int rot2 = (int)(((unsigned)k2 * (unsigned)n2) / (unsigned)fp.nkb);
+            int tau2 = s - tb2 - rot2;
+            if (tau2 < 0) tau2 += n2;
+            if (tau2 < i || (tau2 == i && k2 < kb)) ++place;
+        }
+        tab[i] = (uint8_t)(place | ((place == cnt - 1) ? 0x80 : 0));
+    }
+    // (published to every wave by the barrier that ends the prologue)
+    if (n_sl > 0) store_stats(stage_of(0), slice_at(0) * 32);
     dma_wait_all();
     prologue_wait_all();
     __syncthreads();

@@ -193,18 +193,13 @@ def _tiles256(m, n):
 
 
 def linear_bwd_pair_is_grouped(M, N, K) -> bool:
-    """Whether linear_bwd (dy [M,N], x [M,K], W [N,K]) takes the single grouped launch: the input gradient has too few
-    256x256 tiles for the chip but a long K (= N), the weight gradient has many tiles of short K (= M), and the two
-    halves carry comparable work — the readout (N = vocabulary).  OBTE_GROUPED_LM=0/1 overrides."""
+    """Whether linear_bwd (dy [M,N], x [M,K], W [N,K]) takes the single grouped launch.  Only on request (OBTE_GROUPED_LM=1):
+    the readout's pair — an input gradient of few 256x256 tiles with a long K (= vocabulary) beside a weight gradient of many
+    tiles with a short K (= rows) — was grouped by default in rounds 3-4, when the single launches had no good split-K plans;
+    with the tuned plans the two launches are faster (round 5, masked rows 4 740-4 915: 1 030-1 080 us against 1 440-1 460 us
+    grouped; the step with every pass grouped 108.3 ms, with none 105.9 ms), so the default is the two launches."""
     import os
-    e = os.environ.get("OBTE_GROUPED_LM", "")
-    if e in ("0", "1"):
-        return e == "1" and M >= 128 and N >= 128
-    td, tw = _tiles256(M, K), _tiles256(N, K)
-    if not (M >= 4096 and N >= 8 * M and 64 <= td <= 160 and td % 8 == 0 and tw % 8 == 0 and tw >= 256):   # (a few tiles of dgrad beside 1024 of wgrad: two launches with split-K are 2.5x faster)
-        return False
-    work_d, work_w = td * N, tw * M
-    return 0.5 <= work_d / work_w <= 2.0
+    return os.environ.get("OBTE_GROUPED_LM", "") == "1" and M >= 128 and N >= 128
 
 
 def linear_bwd(dy2d, x2d, w, alpha=1.0, accumulate_into=None):
