@@ -59,7 +59,7 @@ struct FusedShape {
 
 struct FusedParams {
     AttnParams a;
-    float* dq_acc;         // fp32 [B*H][nsl][4 waves][4][64 lanes][4]: the running dQ^T tile of every slice
+    float* dq_acc;         // fp32 [B*H][nsl + 1][4 waves][4][64 lanes][4]: the running dQ^T tile of every slice (+ one trash tile per (batch, head))
     int32_t* flags;        // int32 [B*H][nsl]: contributions completed per slice (zeroed by the prep kernel, every call)
     int32_t* kb_bounds;    // int32 [B][nkb][2]: the slices [t_begin, t_end) each key block sweeps (prep kernel)
     int32_t* status;       // the library's device status word (pinned host memory, common.h): OBTE_STATUS_ATTN_BWD_HANDOFF is OR-ed into it
@@ -72,8 +72,15 @@ struct FusedParams {
 
 // one MFMA into a RESIDENT accumulator (AGPRs).  s_nop 1: the A / B operands may have been written by the vector ALU just
 // before (cdna_hip_programming.md §5.7 item 2: hipcc pads nothing for an asm statement).
+#ifndef FB_ACC_NOP
+#define FB_ACC_NOP 1
+#endif
 __device__ __forceinline__ void mfma_acc(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+#if FB_ACC_NOP
     asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+#else   // (timing experiments only: without the wait states a vector-ALU write of an operand right in front of the statement is a hazard)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+#endif
 }
 
 // B fragment of the dQ product from the dS image: MFMA column = query (lane & 31), k element j = key row
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     // ---- the hand-off of the dQ^T tiles (header) -------------------------------------------------------------------------------
     // this (batch, head)'s tiles through one buffer descriptor: tile of slice t at t * 16 KiB, this lane's four 16-byte pieces at
     // (4 wave + i) * 1 KiB + 16 lane
-    const __amdgpu_buffer_rsrc_t rs_acc = make_rsrc(fp.dq_acc + bh * fp.nsl * 4096, (int64_t)fp.nsl * 16384);
+    const __amdgpu_buffer_rsrc_t rs_acc = make_rsrc(fp.dq_acc + bh * (fp.nsl + 1) * 4096, (int64_t)(fp.nsl + 1) * 16384);   // (+ 1: the trash tile, below)
     int32_t* const flag_b = fp.flags + bh * fp.nsl;
     const int mute = (fp.no_signal_slice >= 0 && bh == 0) ? fp.no_signal_slice : -2;   // fault injection (tests): this slice's counter is never added to
     const int acc_lane = wave * 4096 + lane * 16;
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     // in flight — tools/fused_audit.py caught exactly that with register-destination loads here), sc1 like every read of a
     // handed-off tile; it is read back by the wave that asked for it, behind that wave's own counted vmcnt — no barrier involved.
     const uint32_t a_acc = lds_addr_of(accst) + wave * 4096;
-    const i32x4_t rs_accw = make_rsrc_words(fp.dq_acc + bh * fp.nsl * 4096, (int64_t)fp.nsl * 16384);
+    const i32x4_t rs_accw = make_rsrc_words(fp.dq_acc + bh * (fp.nsl + 1) * 4096, (int64_t)(fp.nsl + 1) * 16384);
     auto acc_request = [&](int t, int i) {   // piece i of 4
         const int off = t * 16384 + acc_lane;
         asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen sc1 lds" : : "s"(a_acc + i * 1024), "v"(off + i * 1024), "s"(rs_accw) : "memory");   // (no instruction offset: it would move the LDS address too)
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
 #endif
     // state carried over the loop edge: the A-phase fragment ring (k-step n = 8 kt + s in slot n % 3, read two k-steps ahead),
     // key tile 0's two chains holding their row constants, and whether the slice needs the range test
-    constexpr int RA = DROP ? 3 : FB_RA, RD = FB_RD, RC = FB_RC;   // fragment rings: a fragment is read RING - 1 steps ahead of its MFMA
+    constexpr int RA = DROP ? 3 : FB_RA, RD = DROP ? 3 : FB_RD, RC = FB_RC;   // fragment rings: a fragment is read RING - 1 steps ahead of its MFMA
                                                                   // (dropout: the keep words and key tile 0's -delta chunks take the A ring's fourth slot; with it hipcc spills a V fragment)
     bf16x8 fq[RA], fd[RA], fk[RA];
     f32x16 sc0, dp0;
@@ -566,20 +573,22 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
     int t_sig = -1;                         // the slice whose tile was stored an iteration ago and has not been counted on yet (-1: none)
     int have_prev = 0;                      // the previous slice's counter as polled during the previous iteration
     for (int it = 0; it < n_sl; ++it) {
-        const bool more = it + 1 < n_sl;
-        const int t = slice_at(it), t_next = more ? slice_at(it + 1) : t;
+        // (the last iteration "prefetches" its own slice once more into the free stage: every iteration then issues the same
+        //  operations, the counted waits are constants and the loop has no `is there a next slice` branches)
+        const int t = slice_at(it), t_next = it + 1 < n_sl ? slice_at(it + 1) : t;
         const int cur = it & 1;
         const int info = tab[it];                       // place | last << 7 of slice t for this workgroup
         const bool last_p = (info_prev & 0x80) != 0, first_it = it == 0;
         const bool take_p = !first_it && (info_prev & 0x7f) > 0;   // somebody hands the previous slice's tile on to this workgroup
         int have_cur = 0;
+        const int t_store = first_it ? fp.nsl : t_prev;
         const SliceBases sb = bases_of(it);
         const uint32_t ds_rd = opaque(a_ds + (cur ^ 1) * S::DSB + lds0);   // the previous slice's dS image (reads)
         char* img_cur = dsimg + cur * S::DSB;
         const int q0 = t * 32;
         // the previous slice's tile so far: once it is this workgroup's turn (in steady state the counter polled an iteration ago
         // already says so), four LDS-DMA pieces in A0's first slots; they are read back in A1
-        if (take_p) wait_turn(t_prev, info_prev & 0x7f, have_prev);
+        wait_turn(t_prev, info_prev & 0x7f, have_prev);   // (place 0, the first iteration: no turn to wait for, the loop inside does not run)
         // A chain's last member finishes the previous slice's tile itself: the summed tile is parked in the wave's own staging area
         // (A1, where it would otherwise leave for the scratch buffer; the area is free between this iteration's read of the incoming
         // tile and the next iteration's request), the rotation entries of its queries are requested in C0, and the tile is scaled,
@@ -694,12 +703,13 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         for (int n = 0; n < 8; ++n) {
             if (n + RA - 1 < 8) rdA(sb, n + RA - 1);
             if (n >= 8 - (RD - 1)) rdD(n - (8 - (RD - 1)));   // D's first fragments
-            if (n < 4 && take_p) acc_request(t_prev, n);   // (before everything else of this iteration: the A1 wait counts what follows)
-            if (more && !OBTE_SKIP(128)) {
+            if (n < 4 && take_p) acc_request(t_prev, n);   // (before everything else of this iteration: the A1 wait counts what follows.  Asking for the tile in every
+                                                           //  iteration, so that the request is no branch, was measured: + 1.7 % — an LDS-DMA piece costs far more to issue than a branch)
+            if (!OBTE_SKIP(128)) {
                 if (n >= 4) issue_piece(it + 1, t_next, n - 4);
                 if (n == 7) load_stats_issue(t_next * 32);
             }
-            if (DROP && n == 7 && more) { kw_next[0] = kw_src[0][(int64_t)t_next * T]; kw_next[1] = kw_src[1][(int64_t)t_next * T]; }
+            if (DROP && n == 7) { kw_next[0] = kw_src[0][(int64_t)t_next * T]; kw_next[1] = kw_src[1][(int64_t)t_next * T]; }
             if (DROP && n == 7) rd_const0(0);
             if (n == 7) poll_issue(t);                // this slice's counter, looked at an iteration from now (after the end-of-iteration wait)
             sc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[n % RA], fk[n % RA], sc0, 0, 0, 0);
@@ -733,13 +743,12 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
             // the tile so far (requested at the top of the iteration; younger than its four pieces: the next slice's four LDS-DMA, its
             // row-constant load and this slice's poll — past the last slice only the poll) joins this workgroup's contribution, then leaves
             if (n == 8 && take_p) {
-                if (more) { if (DROP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }   // (dropout: + the two keep-word loads)
-                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                if (DROP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // (dropout: + the two keep-word loads)
                 acc_add(dq);
             }
-            if (n >= 9 && n < 13 && !first_it && !OBTE_SKIP(64)) {
+            if (n >= 9 && n < 13 && !OBTE_SKIP(64)) {
                 if (fin_p) acc_park(dq, n - 9);   // the chain ends here: finished in C1
-                else store_acc(t_prev, dq, n - 9);
+                else store_acc(t_store, dq, n - 9);   // (the first iteration has no previous slice: its four stores go to the trash tile — the loop's counted waits see the same four stores in every iteration)
             }
             if (n == 15) rd_const1(0);
             if (n == 8) { sc1 = zero16; if (!inside) mask_init(sc1, 1, q0); }
@@ -791,14 +800,11 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
         // Those are what is counted on here: every wave's wait, the barrier, then ONE lane's add (Guideline 16, R1).  This
         // iteration's stores stay in flight (their acknowledgement takes longer than the 40 slots since) and are counted on an
         // iteration from now.  The same barrier publishes the next slice's tiles and this slice's dS image.
-        if (!OBTE_SKIP(16)) {
-            if (first_it) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        }
+        if (!OBTE_SKIP(16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // (four stores in EVERY iteration: the first one's go to the trash tile)
         if (DROP) { asm volatile("" : "+v"(kw_next[0]), "+v"(kw_next[1])); kw[0] = kw_next[0]; kw[1] = kw_next[1]; }   // (their loads are older than the stores the wait leaves in flight)
         st_l = *raw_st;          // (behind the wait: what the two LDS-DMA loads of this iteration left in this wave's raw area)
         have_cur = *raw_poll;
-        if (more) store_stats(stage_of(it + 1), t_next * 32);
+        store_stats(stage_of(it + 1), t_next * 32);
         if (!OBTE_SKIP(8)) __syncthreads();
         if (tid == 0 && t_sig >= 0 && t_sig != mute) __hip_atomic_fetch_add(flag_b + t_sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         OBTE_PHASE(5);
@@ -953,7 +959,7 @@ namespace obte_attn {
 static void ws_layout(int64_t B, int64_t T, int H, int64_t& nkb, int64_t& nsl, int64_t& o_flags, int64_t& o_bounds, int64_t& total) {
     nkb = (T + FB_KEYS - 1) / FB_KEYS; nsl = (T + 31) / 32;
     auto up = [](int64_t x) { return (x + 255) & ~int64_t(255); };
-    o_flags = up(B * H * nsl * (32 * 128 * 4));
+    o_flags = up(B * H * (nsl + 1) * (32 * 128 * 4));   // per (batch, head): one tile per slice + a trash tile (the first iteration's stores, which stand for no slice)
     o_bounds = o_flags + up(B * H * nsl * 4);
     total = o_bounds + up(B * nkb * 2 * 4) + 256;
 }

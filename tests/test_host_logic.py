@@ -328,6 +328,28 @@ def test_forward_rows_contract_is_checked_on_the_host():
             _check_rows(bad, 16, 1)   # the last one: a CPU tensor (the model lives on the GPU)
 
 
+def test_attention_backward_isa_keeps_its_hand_counted_waits_honest(tmp_path):
+    """The one-kernel attention backward counts its own vector-memory operations (s_waitcnt vmcnt(N) by hand).  That only holds
+    while hipcc puts nothing of its own into the slice loop's queue and leaves the registers of the asm-issued loads alone until the
+    wait that releases them; tools/fused_audit.py checks both on the ISA of every instantiation (no scratch access inside the loop;
+    no instruction touching an in-flight destination).  Compiled here exactly as csrc/Makefile compiles the file."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "omnibiote_amd", "csrc", "attention_bwd_fused.hip")
+    out = str(tmp_path / "fused.s")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only",
+                        src, "-o", out], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = subprocess.run([sys.executable, os.path.join(root, "tools", "fused_audit.py"), out], capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0 and "audit ok" in a.stdout, a.stdout[-3000:]
+    assert a.stdout.count("scratch accesses 0") == 4, a.stdout   # no mask / key ranges, each with and without dropout
+
+
 def test_attention_backward_workspace_is_zero_where_the_one_kernel_form_does_not_apply():
     """obte_attn_bwd_ws_bytes answers 0 — "allocate nothing, the two-kernel form runs" — wherever the one-kernel backward does not
     apply (other head sizes, more than 256 query slices, rows whose byte offsets pass 32 bits), never a sentinel a caller would
