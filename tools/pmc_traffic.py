@@ -5,8 +5,10 @@ FETCH_SIZE tallies wide coalesced reads at half their bytes -> x2; WRITE_SIZE is
 import collections
 import csv
 import json
+import os
 import sys
 
+PP = int(os.environ.get("OBTE_PMC_PER_PASS", "4"))   # micro-batches per pass of the profiled command
 GEMM = ("gemm_v2_kernel", "gemm_v3_", "gemm_v4_kernel", "gemm_v7_kernel", "gemm_bf16_kernel")
 WITH_REDUCE = GEMM + ("splitk_reduce",)   # a split-K launch is one call of the entry point: its reduce kernel counts with it
 
@@ -31,7 +33,9 @@ def main(fetch_csv, write_csv, out):
            "read_bytes_per_launch": 2.0 * fetch_kib * 1024 / calls, "write_bytes_per_launch": write_kib * 1024 / calls,
            "traffic_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024 / calls,
            "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; separate --pmc passes",
-           "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_roofline --pipeline_streams 1 --plan_cache plans.json (tools/profile_pmc_bench.sh)"}
+           "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_other_configs --no_roofline --no_variants --pipeline_streams 1 "
+                      f"--micro_batches_per_pass {PP} --plan_cache plans.json (tools/profile_pmc_bench.sh)",
+           "micro_batches_per_pass": PP}   # bench.py quotes this figure only for a run with the same launches
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -15,6 +15,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_sq -o x -- $CMD > $OUT/pmc_sq.log 2>&1
 echo "SQ rc=$?"
-python3 tools/pmc_traffic.py $(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv") $(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv") $OUT/gemm_family_traffic.json | tail -12
+OBTE_PMC_PER_PASS=$PP python3 tools/pmc_traffic.py $(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv") $(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv") $OUT/gemm_family_traffic.json | tail -12
 python3 tools/pmc_summary.py --skip 0 --match _kernel $(find $OUT/pmc_sq -name "*counter_collection.csv") > $OUT/pmc_sq_summary.txt 2>&1
 grep -c "==" $OUT/pmc_sq_summary.txt
