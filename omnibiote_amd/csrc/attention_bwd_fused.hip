@@ -743,7 +743,9 @@ __global__ __launch_bounds__(FB_NW * 64, 1) void attn_bwd_fused_kernel(FusedPara
             // the tile so far (requested at the top of the iteration; younger than its four pieces: the next slice's four LDS-DMA, its
             // row-constant load and this slice's poll — past the last slice only the poll) joins this workgroup's contribution, then leaves
             if (n == 8 && take_p) {
+#ifndef FB_EXP_NOACCWAIT   // (timing experiment only: how long the loop waits here for the tile handed on — results are wrong without the wait)
                 if (DROP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // (dropout: + the two keep-word loads)
+#endif
                 acc_add(dq);
             }
             if (n >= 9 && n < 13 && !OBTE_SKIP(64)) {
