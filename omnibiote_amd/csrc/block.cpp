@@ -107,6 +107,13 @@ int check_desc(const char* who, const obte_block_desc* d) {
 
 #define TRY(x) do { int rc_ = (x); if (rc_ != OBTE_OK) return rc_; } while (0)
 
+// rows form with the attention projection on the wanted rows only (see obte_block_fwd); OBTE_ROWS_PROJ=0 keeps the projection on
+// every row (A/B timing, tests)
+bool rows_proj(const obte_block_desc* d) {
+    static const bool off = [] { const char* e = getenv("OBTE_ROWS_PROJ"); return e && e[0] == '0'; }();
+    return d->out_rows != nullptr && d->dropout_p == 0.f && !off;
+}
+
 }  // namespace
 
 extern "C" int64_t obte_block_act_bytes(int64_t B, int64_t T, int32_t n_embd, int32_t n_head) {
@@ -154,14 +161,26 @@ extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte
     }
     af.ranges_exact = d->ranges_exact;
     TRY(obte_attn_fwd(&af, s));
-    TRY(gemm(yat, d->proj_w, x1, M, C, C, C, C, 1, 1, OBTE_EPI_ADD, x, nullptr, s, nullptr, 0, d->dropout_p, d->dropout_seed, SITE_RESID));
-    // the MLP half: on every position, or (rows form) on the n wanted positions only — per-position arithmetic, same results there
+    // the attention projection and the MLP half: on every position, or (rows form) on the n wanted positions only — per-position
+    // arithmetic, same results there.  Rows form without dropout: the projection too runs on the wanted rows (the attention output
+    // and the block input gathered; x1 = x + y W_proj^T formed for those rows alone; the region of the full x1 keeps the gathered
+    // attention output for the backward).  With dropout the projection's mask is defined on whole activations: all rows, then gather.
     int64_t Mm = M;
     const obte_bf16* x1m = x1;
-    if (d->out_rows) {
+    if (rows_proj(d)) {
         obte_bf16* x1r = (obte_bf16*)(A + L.x1r);
-        TRY(obte_rows_gather_bf16(x1, d->out_rows, x1r, d->n_out_rows, M, C, s));
+        obte_bf16* yr = x1;
         Mm = d->n_out_rows; x1m = x1r;
+        TRY(obte_rows_gather_bf16(x, d->out_rows, x1r, Mm, M, C, s));
+        TRY(obte_rows_gather_bf16(yat, d->out_rows, yr, Mm, M, C, s));
+        TRY(gemm(yr, d->proj_w, x1r, Mm, C, C, C, C, 1, 1, OBTE_EPI_ADD, x1r, nullptr, s, (void*)(A + L.hpre), M * 4 * C * 2));   // (split-K workspace: the MLP's regions are not written yet)
+    } else {
+        TRY(gemm(yat, d->proj_w, x1, M, C, C, C, C, 1, 1, OBTE_EPI_ADD, x, nullptr, s, nullptr, 0, d->dropout_p, d->dropout_seed, SITE_RESID));
+        if (d->out_rows) {
+            obte_bf16* x1r = (obte_bf16*)(A + L.x1r);
+            TRY(obte_rows_gather_bf16(x1, d->out_rows, x1r, d->n_out_rows, M, C, s));
+            Mm = d->n_out_rows; x1m = x1r;
+        }
     }
     TRY(obte_layernorm_fwd(x1m, d->ln2_w, h2, mean2, rstd2, Mm, C, 1e-5f, s));
     TRY(gemm(h2, d->fc_w, hpre, Mm, 4 * C, C, C, C, 1, 1, OBTE_EPI_GELU, nullptr, hact, s));
@@ -222,10 +241,11 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     // their own split-K launches with the tuned plans.  OBTE_GROUPED_LAST=1 restores the grouped form (A/B timing).
     static const bool grouped_last = [] { const char* e = getenv("OBTE_GROUPED_LAST"); return e && e[0] == '1'; }();
     const bool grouped_ok = use_grouped_wgrad(C, M);
-    const bool grouped = grouped_ok && (d->out_rows == nullptr || grouped_last);
+    const bool grouped = grouped_ok && (d->out_rows == nullptr || (grouped_last && !rows_proj(d)));   // (the projection on the wanted rows is its own pair of launches)
     // rows form: the MLP half ran on Mm = n_out_rows positions (dy is [Mm, C]); its two weight gradients contract over those rows
     // and go out as their own launches, the grouped launch keeps the attention half's
     const bool rows_form = d->out_rows != nullptr;
+    const bool rows_p = rows_proj(d);   // (implies rows_form, no dropout, and — below — the ungrouped form of the attention half)
     const int64_t Mm = rows_form ? d->n_out_rows : M;
     const obte_bf16* x1m = rows_form ? (const obte_bf16*)(A + L.x1r) : x1;
     const bool grouped_mlp = grouped && !rows_form;
@@ -273,13 +293,20 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
             TRY(obte_dropout_bf16(dx1, dym2, M * C, C, d->dropout_p, d->dropout_seed, SITE_RESID, s));
             dx1_proj = dym2;
         }
+        if (rows_p) {   // the projection ran on the wanted rows: its two gradients contract over / are formed for those rows only
+            const obte_bf16* yr = x1;                                   // the gathered attention output (forward)
+            obte_bf16* dyr = dym;                                       // d(attention output) at the wanted rows (dym is free without dropout)
+            TRY(gemm(dx1r, d->proj_w, dyr, Mm, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s, gws, W.gemmws_bytes));
+            TRY(gemm(dx1r, yr, dproj_w, C, C, Mm, C, C, 0, 0, wepi, accumulate_matrices ? dproj_w : nullptr, nullptr, s, gws, W.gemmws_bytes));   // dW_proj = dx1^T y over the wanted rows
+            TRY(obte_rows_scatter_bf16(dyr, d->out_rows, dyattn, Mm, M, C, s));   // (dx1r, staged in dyattn, has been read by both products)
+        }
     } else if (lnp) {
         TRY(obte_layernorm_bwd_partial(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, d->ln2_partials, M, C, lnp, s));
     } else {
         TRY(obte_layernorm_bwd_acc(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, lnws, M, C, acc_ln, s));
     }
-    TRY(gemm(dx1_proj, d->proj_w, dyattn, M, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dy_attn = dx1 W_proj
-    if (!grouped) TRY(gemm(dx1_proj, yat, dproj_w, C, C, M, C, C, 0, 0, wepi, accumulate_matrices ? dproj_w : nullptr, nullptr, s, gws, W.gemmws_bytes));                       // dW_proj = dx1^T y
+    if (!rows_p) TRY(gemm(dx1_proj, d->proj_w, dyattn, M, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dy_attn = dx1 W_proj
+    if (!grouped && !rows_p) TRY(gemm(dx1_proj, yat, dproj_w, C, C, M, C, C, 0, 0, wepi, accumulate_matrices ? dproj_w : nullptr, nullptr, s, gws, W.gemmws_bytes));                       // dW_proj = dx1^T y
     obte_attn_bwd_args ab = {};
     ab.qkv = qkv; ab.o = yat; ab.d_o = dyattn; ab.lse = lse; ab.delta = delta; ab.dqkv = dqkv;
     ab.rope_cos = d->rope_cos; ab.rope_sin = d->rope_sin;

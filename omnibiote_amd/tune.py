@@ -154,6 +154,8 @@ def model_gemm_shapes(rows: int, n_embd: int, vocab: int):
         (Mm, 4 * C, C, True, True, E.EPI_GELU), (Mm, C, 4 * C, True, True, E.EPI_ADD),
         (Mm, 4 * C, C, True, False, E.EPI_GELU_BWD), (Mm, C, 4 * C, True, False, E.EPI_NONE),
         (C, 4 * C, Mm, False, False, E.EPI_NONE), (4 * C, C, Mm, False, False, E.EPI_NONE),
+        # and its attention projection on those positions (rows form without dropout: csrc/block.cpp rows_proj)
+        (Mm, C, C, True, True, E.EPI_ADD), (Mm, C, C, True, False, E.EPI_NONE), (C, C, Mm, False, False, E.EPI_NONE),
     ]
 
 
