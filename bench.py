@@ -7,8 +7,8 @@ A *step* is one optimizer step of the reference's training loop (training/train_
 k in {1, 2, 4} chosen by measurement at start-up and named in ``config``: masks and loss normalisation stay per micro-batch) through the drop-in
 ``OmniBioTA`` (small: 8L/1024d/8h, bf16, dropout 0), the 65 536-way readout and masked-LM cross entropy evaluated on the
 MLM-masked positions only (``--readout masked``, the default since round 3: the loss multiplies every other position by
-zero, train_encoder.py:304, so loss and gradients are the reference's; the last block's MLP half and ln_f run on those
-positions too — ``model.forward(rows=...)``; ``--readout dense`` / ``dense_full`` compute every position's logits as
+zero, train_encoder.py:304, so loss and gradients are the reference's; the last block's MLP half, its attention's queries with
+the attention projection (round 5; keys and values of every position) and ln_f run on those positions too — ``model.forward(rows=...)``; ``--readout dense`` / ``dense_full`` compute every position's logits as
 rounds 1-2 did and are reported as variants), backward, global-norm clip, MuAdamW-grouped AdamW, LinearLR — BASELINE.json
 configs[1] at N=1 and configs[2] (batch_size 1024 over 8 ranks) at N=8.  At N=1 the line also carries ``other_configs``:
 driver-timed steps of BASELINE configs 4 (small, ctx 4096) and 5 (large 24L/2048d/16h, its single-GPU leg).  Per-rank work is fixed as N grows (weak scaling).  Inputs are resident in
@@ -42,8 +42,8 @@ METRIC = "MLM train tokens/sec, small (8L/1024d) ctx=1024 at 1/2/4/8 MI355X"
 READOUT_TEXT = {"dense": "full 65536-way logits for every position in the forward, readout backward over the MLM-masked rows (the other rows of d(logits) are exact zeros)",
                 "dense_full": "full 65536-way logits and dense d(logits)",
                 "masked": "65536-way readout + CE on the MLM-masked positions only (SURVEY §8f rank 1: the loss multiplies every other position by zero, "
-                          "train_encoder.py:304 — same loss, same gradients); the positions are handed to model.forward(rows=...), so the last block's MLP half "
-                          "and ln_f run on them alone as well"}
+                          "train_encoder.py:304 — same loss, same gradients); the positions are handed to model.forward(rows=...), so the last block's MLP half, "
+                          "its attention's queries (keys and values of every position) with the attention projection, and ln_f run on them alone as well"}
 # leads config.workload (the driver keeps the first 128 characters of it): which readout ran
 READOUT_LEAD = {"masked": "masked-positions readout+CE, rows-form last block", "masked_full": "masked-positions readout+CE, full last block",
                 "dense": "every-position logits fwd, masked-rows readout bwd", "dense_full": "reference-literal dense logits + dense dlogits"}
@@ -112,6 +112,7 @@ KIND_NAMES = {12: "gemm_fwd(NT)", 13: "gemm_fwd(NT)+gelu", 14: "gemm_fwd(NT)+res
               17: "gemm_fwd(NT)+rope", 8: "gemm_dgrad(NN)", 11: "gemm_dgrad(NN)+gelu_bwd", 0: "gemm_wgrad(TN)",
               2: "gemm_wgrad(TN)+accumulate", 32: "gemm_grouped(wgrads)", 34: "gemm_grouped(wgrads)+accumulate",
               33: "gemm_grouped(wgrads+dgrad)", 35: "gemm_grouped(wgrads+dgrad)+accumulate", 100: "attn_fwd", 101: "attn_bwd",
+              102: "attn_fwd(rows: last block)", 103: "attn_bwd(rows: last block)",
               110: "ln_fwd", 111: "ln_bwd", 112: "masked_ce_rows", 113: "adamw"}
 HBM_KINDS = {110: lambda d0, d1, d2: 4.0 * d0 * d1, 111: lambda d0, d1, d2: (6.0 + 2.0 * d2) * d0 * d1,
              112: lambda d0, d1, d2: 4.0 * d0 * d1, 113: lambda d0, d1, d2: 14.0 * d0}   # algorithmic bytes per launch
@@ -133,6 +134,8 @@ def rocprof_name(k: int) -> str:
 def launch_flops(code: int, d0, d1, d2) -> float:
     if code in (100, 101):   # attention: fwd 4*T*T*D per (b,h); bwd 2.5x (five products) — algorithmic, recompute not counted
         return 4.0 * d0 * d1 * d1 * d2 * (1.0 if code == 100 else 2.5)
+    if code in (102, 103):   # queries at listed rows only (the last block): d0 = queries x heads, d1 = keys
+        return 4.0 * d0 * d1 * d2 * (1.0 if code == 102 else 2.5)
     if code in HBM_KINDS:
         return 0.0
     return 2.0 * d0 * d1 * d2
@@ -356,7 +359,8 @@ def measure_other_config(name: str, rows: int, a, dev, steps: int = 2, warmup: i
     el = time.perf_counter() - t0
     value = rows * T * steps / el
     fpt = TE.flops_per_token(n_params, cfg["n_layer"], cfg["n_embd"], T)
-    fpt_exec = TE.flops_per_token_executed(n_params, cfg["n_layer"], cfg["n_embd"], T, a.readout, not a.full_last_block)
+    fpt_exec = TE.flops_per_token_executed(n_params, cfg["n_layer"], cfg["n_embd"], T, a.readout, not a.full_last_block,
+                                           rows_attention=(not a.full_last_block) and a.dropout == 0.0 and not a.dense_mask)
     out = {"workload": f"{READOUT_LEAD['masked_full' if (a.readout == 'masked' and a.full_last_block) else a.readout]}; OmniBioTA {name} "
                        f"({cfg['n_layer']}L/{cfg['n_embd']}d/{cfg['n_head']}h) ctx={T}, {rows} rows = {rows // a.mini_batch_size} micro-batches of "
                        f"{a.mini_batch_size}, dropout {a.dropout:g}, single-document rows, one GPU",
@@ -598,7 +602,8 @@ def main():
     value = tokens_per_step * a.steps / elapsed
     fpt = TE.flops_per_token(n_params, cfg["n_layer"], cfg["n_embd"], T)
     # 15 % of the positions are MLM-masked (train_encoder.py:271); their share of the readout products (and of the last block's MLP half) remains
-    fpt_exec = TE.flops_per_token_executed(n_params, cfg["n_layer"], cfg["n_embd"], T, a.readout, not a.full_last_block)
+    fpt_exec = TE.flops_per_token_executed(n_params, cfg["n_layer"], cfg["n_embd"], T, a.readout, not a.full_last_block,
+                                           rows_attention=(not a.full_last_block) and a.dropout == 0.0 and not a.dense_mask)
 
     log(f"timed region done: {value:,.0f} tokens/s")
     tail_guard = Watchdog(900.0, "profiled step + variants (they contain collectives at N > 1)")
@@ -747,7 +752,8 @@ def main():
             work = attention_work_fraction(md_host[0], a.mini_batch_size)
             v = timed_variant(bs=md)
             fpt_md = TE.flops_per_token_executed(n_params, cfg["n_layer"], cfg["n_embd"], T, a.readout, not a.full_last_block,
-                                                 attention_fraction=work["tile_fraction"])
+                                                 attention_fraction=work["tile_fraction"],
+                                                 rows_attention=(not a.full_last_block) and a.dropout == 0.0 and not a.dense_mask)
             variants["multi_document"] = {"value": v, "unit": "tokens/s", "steps": 10,
                                           "attention_work": work, "flops_per_token_executed": fpt_md,
                                           "mfma_fraction_whole_step_executed": round(v * fpt_md / (PEAK_BF16_TFLOPS * 1e12 * world), 4),

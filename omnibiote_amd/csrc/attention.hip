@@ -42,24 +42,28 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    const BlockId bid_ = block_id((int)((p.T + 32 * NW - 1) / (32 * NW)), p.H);
+    const BlockId bid_ = p.q_blk_off ? block_id_rows(p) : block_id((int)((p.T + 32 * NW - 1) / (32 * NW)), p.H);
+    if (bid_.blk < 0) return;
     const int hd = bid_.hd;
     const int64_t b = bid_.b;
     const int T = (int)p.T;
     const int C = p.H * D;
     const int64_t ld = 3 * (int64_t)C;
+    const QSide qsd = q_side(p, b, hd);          // the queries of this batch element (attn_common.h): all T rows, or a gathered set
+    const int Tq = qsd.n;
+    if (bid_.blk * (32 * NW) >= Tq) return;      // (a gathered set shorter than the grid allows for: nothing to do, before any barrier)
     const int q_row = bid_.blk * (32 * NW) + wave * 32 + (lane & 31);
-    const bool q_ok = q_row < T;
-    const int q_c = q_ok ? q_row : T - 1;
+    const bool q_ok = q_row < Tq;
+    const int q_c = q_ok ? q_row : Tq - 1;
 
     // the key range of this query FIRST: the tile range (and with it the first LDS-DMA) depends on it, and vmcnt retires in
     // issue order — loaded behind the Q fragments, it made the K/V stream wait for all of them
     int r_lo = 0, r_hi = T;
     if (MODE == MASK_RANGES || (MODE == MASK_DENSE && p.key_ranges)) {
-        r_lo = p.key_ranges[(b * T + q_c) * 2];
-        r_hi = p.key_ranges[(b * T + q_c) * 2 + 1];
+        r_lo = p.key_ranges[(qsd.row0 + q_c) * 2];
+        r_hi = p.key_ranges[(qsd.row0 + q_c) * 2 + 1];
     }
-    const bf16* qptr = p.qkv + (b * T + q_c) * ld + hd * D;
+    const bf16* qptr = p.q_src + (qsd.row0 + q_c) * p.q_ld + hd * D;
     bf16x8 qf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qptr + 16 * s + 8 * h);
@@ -283,7 +287,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem) {
         // the backward then gives the row exactly zero weight.  (The reference's own mask builder never produces such a
         // row; torch's fused SDPA backends return NaN for it.)
         const bool degenerate = m < -1.0e8f;
-        if (h == 0) p.lse[(b * p.H + hd) * T + q_row] = (l_tot > 0.f && !degenerate) ? (m + __log2f(l_tot)) * LN2 : INFINITY;
+        if (h == 0) p.lse[qsd.stat0 + q_row] = (l_tot > 0.f && !degenerate) ? (m + __log2f(l_tot)) * LN2 : INFINITY;
     }
     {   // every tile has been read (the loop ends on a barrier): the stage memory carries the output rows out (wave_rows_out)
         bf16x4 ob[ND * 4];
@@ -294,7 +298,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ob[4 * dt + i][j] = f2bf(o[dt][4 * i + j] * inv);
         const int64_t row0 = (int64_t)q_row - (lane & 31);   // the wave's first query
-        wave_rows_out<D>(smem + wave * (32 * 2 * D), ob, p.o + (b * T + row0) * C + hd * D, C, (int)min((int64_t)32, (int64_t)T - row0), lane);
+        wave_rows_out<D>(smem + wave * (32 * 2 * D), ob, p.o + (qsd.row0 + row0) * C + hd * D, C, (int)min((int64_t)32, (int64_t)Tq - row0), lane);
     }
 }
 
@@ -312,32 +316,36 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
-    const BlockId bid_ = block_id((int)((p.T + 32 * NW - 1) / (32 * NW)), p.H);
+    const BlockId bid_ = p.q_blk_off ? block_id_rows(p) : block_id((int)((p.T + 32 * NW - 1) / (32 * NW)), p.H);
+    if (bid_.blk < 0) return;
     const int hd = bid_.hd;
     const int64_t b = bid_.b;
     const int T = (int)p.T;
     const int C = p.H * D;
     const int64_t ld = 3 * (int64_t)C;
+    const QSide qsd = q_side(p, b, hd);          // (see the forward)
+    const int Tq = qsd.n;
+    if (bid_.blk * (32 * NW) >= Tq) return;
     const int q_row = bid_.blk * (32 * NW) + wave * 32 + (lane & 31);
-    const bool q_ok = q_row < T;
-    const int q_c = q_ok ? q_row : T - 1;
+    const bool q_ok = q_row < Tq;
+    const int q_c = q_ok ? q_row : Tq - 1;
 
     int r_lo = 0, r_hi = T;   // the key range first (see the forward)
     if (MODE == MASK_RANGES || (MODE == MASK_DENSE && p.key_ranges)) {
-        r_lo = p.key_ranges[(b * T + q_c) * 2];
-        r_hi = p.key_ranges[(b * T + q_c) * 2 + 1];
+        r_lo = p.key_ranges[(qsd.row0 + q_c) * 2];
+        r_hi = p.key_ranges[(qsd.row0 + q_c) * 2 + 1];
     }
-    const bf16* qptr = p.qkv + (b * T + q_c) * ld + hd * D;
-    const bf16* doptr = p.d_o + (b * T + q_c) * C + hd * D;
+    const bf16* qptr = p.q_src + (qsd.row0 + q_c) * p.q_ld + hd * D;
+    const bf16* doptr = p.d_o + (qsd.row0 + q_c) * C + hd * D;
     bf16x8 qf[NS], dof[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         qf[s] = *reinterpret_cast<const bf16x8*>(qptr + 16 * s + 8 * h);
         dof[s] = *reinterpret_cast<const bf16x8*>(doptr + 16 * s + 8 * h);
     }
-    const float lse2 = p.lse_in[(b * p.H + hd) * T + q_c] * LOG2E;
+    const float lse2 = p.lse_in[qsd.stat0 + q_c] * LOG2E;
     const uint32_t drop_rk = DROP ? drop_rowkey(((uint64_t)b * p.H + hd) * (uint64_t)T + (uint64_t)q_c, p.drop) : 0u;
-    const bf16* optr = p.o_in + (b * T + q_c) * C + hd * D;
+    const bf16* optr = p.o_in + (qsd.row0 + q_c) * C + hd * D;
     bf16x8 of[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) of[s] = *reinterpret_cast<const bf16x8*>(optr + 16 * s + 8 * h);
@@ -386,7 +394,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
 #pragma unroll
             for (int j = 0; j < 8; ++j) dl += bf2f(of[s][j]) * bf2f(dof[s][j]);
         dl += __shfl_xor(dl, 32, 64);
-        if (h == 0 && q_ok) p.delta[(b * p.H + hd) * T + q_row] = dl;
+        if (h == 0 && q_ok) p.delta[qsd.stat0 + q_row] = dl;
     }
 
     f32x16 dq[ND];
@@ -464,7 +472,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
     OBTE_STAMP(p, 2);
     {   // rotation table of the row first (one latency, nothing stored yet), then the rows leave through the stage memory
         RopeRow<D> rr;
-        rr.load(p.rope_cos, p.rope_sin, q_c, h);
+        rr.load(p.rope_cos, p.rope_sin, p.q_pos ? p.q_pos[qsd.row0 + q_c] : q_c, h);   // (a gathered query rotates back at its own position)
         bf16x4 gb[ND * 4];
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt)
@@ -478,7 +486,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
                 for (int j = 0; j < 4; ++j) gb[4 * dt + i][j] = f2bf(g[j]);
             }
         const int64_t row0 = (int64_t)q_row - (lane & 31);   // the wave's first query
-        wave_rows_out<D>(smem + wave * (32 * 2 * D), gb, p.dqkv + (b * T + row0) * ld + hd * D, ld, (int)min((int64_t)32, (int64_t)T - row0), lane);
+        wave_rows_out<D>(smem + wave * (32 * 2 * D), gb, p.dq_dst + (qsd.row0 + row0) * p.dq_ld + hd * D, p.dq_ld, (int)min((int64_t)32, (int64_t)Tq - row0), lane);
     }
 #ifdef OBTE_DEBUG_HOOKS
     OBTE_STAMP(p, 3);
@@ -522,8 +530,10 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
     const int key = bid_.blk * (32 * NW) + wave * 32 + (lane & 31);
     const bool k_ok = key < T;
     const int key_c = k_ok ? key : T - 1;
+    const QSide qsd = q_side(p, b, hd);   // the queries of this batch element: all T rows, or a gathered set (attn_common.h); query ranges
+    const int Tq = qsd.n;                 // of the keys (query_bounds — required with a gathered set and a range mask) are in its indices
 
-    int r_lo = 0, r_hi = T;   // the query range of this key first (see the forward)
+    int r_lo = 0, r_hi = Tq;   // the query range of this key first (see the forward)
     if (MODE == MASK_RANGES) {
         const int32_t* src = p.query_bounds ? p.query_bounds : p.key_ranges;   // no per-key table: symmetric mask
         r_lo = src[(b * T + key_c) * 2];
@@ -544,13 +554,13 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
         dmv.issue(p.qkv + (b * T + row0) * ld + 2 * C + hd * D, (((int64_t)T - row0) * ld - (2 * C + hd * D)) * 2, Vblk, wave);
     }
     // by symmetry of the mask, the queries that see this key are the keys this position sees as a query
-    int qs = 0, qe = T;
+    int qs = 0, qe = Tq;
     if (MODE == MASK_RANGES) {
         qs = max(r_lo, 0);
-        qe = min(r_hi, T);
+        qe = min(r_hi, Tq);
     }
     if (!k_ok) { qs = 0; qe = 0; }
-    int lo = k_ok ? qs : T, hi = k_ok ? qe : 0;
+    int lo = k_ok ? qs : Tq, hi = k_ok ? qe : 0;
     if (MODE == MASK_RANGES) {
         block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 2 * STAGE + VB), wave, lane);
     } else if (MODE == MASK_DENSE && p.query_bounds) {
@@ -560,16 +570,17 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
         }
         block_minmax<NW>(lo, hi, reinterpret_cast<int*>(smem + 2 * STAGE + VB), wave, lane);
     } else {
-        lo = 0; hi = T;
+        lo = 0; hi = Tq;
     }
     const int t_begin = lo / 32;
     int t_end = hi > lo ? (hi + 31) / 32 : t_begin;
     if (p.max_tiles) t_end = min(t_end, t_begin + p.max_tiles - 1);
 
-    const bf16* qbase = p.qkv + b * T * ld + hd * D;
-    const bf16* dobase = p.d_o + b * T * C + hd * D;
-    const float* lse_b = p.lse_in + (b * p.H + hd) * T;
-    const float* del_b = p.delta + (b * p.H + hd) * T;
+    const int64_t qld = p.q_ld;
+    const bf16* qbase = p.q_src + qsd.row0 * qld + hd * D;
+    const bf16* dobase = p.d_o + qsd.row0 * C + hd * D;
+    const float* lse_b = p.lse_in + qsd.stat0;
+    const float* del_b = p.delta + qsd.stat0;
     const bf16* mcol = nullptr;
     if (MODE == MASK_DENSE) mcol = p.mask + b * p.mask_sb + hd * p.mask_sh + key_c;
 
@@ -581,20 +592,20 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
     const float scale2 = p.scale * LOG2E;
 
     TileDma<D, 32, NW> dmq, dmd;
-    dmq.init(wave, lane, ld);
+    dmq.init(wave, lane, qld);
     dmd.init(wave, lane, C);
     auto issue_qd = [&](int t, char* stage) {
         const int64_t row0 = (int64_t)t * 32;
-        dmq.issue(qbase + row0 * ld, (((int64_t)T - row0) * ld - hd * D) * 2, stage, wave);
-        dmd.issue(dobase + row0 * C, (((int64_t)T - row0) * C - hd * D) * 2, stage + QB, wave);
+        dmq.issue(qbase + row0 * qld, (((int64_t)Tq - row0) * qld - hd * D) * 2, stage, wave);
+        dmd.issue(dobase + row0 * C, (((int64_t)Tq - row0) * C - hd * D) * 2, stage + QB, wave);
     };
     float st_l = 0.f;  // threads 0..31: lse2 of row tid ; 32..63: delta of row tid-32 ; 64..95 (dropout): row key of row tid-64
     auto load_stats = [&](int q0) {
         if (tid < 64) {
             const int q = q0 + (tid & 31);
             float v = 0.f;
-            if (q < T) v = tid < 32 ? lse_b[q] * LOG2E : del_b[q];
-            else if (tid < 32) v = INFINITY;   // rows past T: p = exp2(x - inf) = 0
+            if (q < Tq) v = tid < 32 ? lse_b[q] * LOG2E : del_b[q];
+            else if (tid < 32) v = INFINITY;   // rows past the last query: p = exp2(x - inf) = 0
             st_l = v;
         } else if (DROP && tid < 96) {
             const int q = min(q0 + (tid & 31), T - 1);
@@ -823,7 +834,8 @@ template <int D>
 int launch_fwd(const AttnParams& p, int mode, hipStream_t st) {
     const int smem = 2 * FwdShape<false>::STAGES * 64 * 2 * D + 64;   // >= the dropout variant's two stages
     const dim3 grid_d((unsigned)(cdiv64(p.T, 32 * FwdShape<true>::NW) * p.H * p.B)), block_d(64 * FwdShape<true>::NW);
-    const dim3 grid((unsigned)(cdiv64(p.T, 32 * FwdShape<false>::NW) * p.H * p.B)), block(64 * FwdShape<false>::NW);
+    // (a gathered query set: only blocks that can hold queries — at most ceil(n / 256) + B of them — in a compact grid: block_id_rows)
+    const dim3 grid((unsigned)((p.q_blk_off ? cdiv64(p.stat_hs, 32 * FwdShape<false>::NW) + p.B : cdiv64(p.T, 32 * FwdShape<false>::NW) * p.B) * p.H)), block(64 * FwdShape<false>::NW);
 #define GO(M)                                                                                 \
     do {                                                                                      \
         if (p.drop.thresh16) {                                                                \
@@ -879,7 +891,7 @@ int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
     {
         const int smem = 4 * 64 * 2 * D + 64;
         const dim3 grid_d((unsigned)(cdiv64(p.T, 32 * FwdShape<true>::NW) * p.H * p.B)), block_d(64 * FwdShape<true>::NW);
-        const dim3 grid((unsigned)(cdiv64(p.T, 32 * FwdShape<false>::NW) * p.H * p.B)), block(64 * FwdShape<false>::NW);
+        const dim3 grid((unsigned)((p.q_blk_off ? cdiv64(p.stat_hs, 32 * FwdShape<false>::NW) + p.B : cdiv64(p.T, 32 * FwdShape<false>::NW) * p.B) * p.H)), block(64 * FwdShape<false>::NW);
 #define GO(M)                                                                                    \
     do {                                                                                         \
         if (p.drop.thresh16) {                                                                   \
@@ -1057,6 +1069,7 @@ extern "C" int obte_attn_fwd(const obte_attn_fwd_args* a, obte_stream s) {
     p.qkv = (const bf16*)a->qkv; p.o = (bf16*)a->o; p.lse = a->lse;
     p.key_ranges = a->key_ranges; p.mask = (const bf16*)a->mask; p.mask_sb = a->mask_sb; p.mask_sh = a->mask_sh; p.mask_sq = a->mask_sq;
     p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
+    p.q_src = p.qkv; p.q_ld = 3 * (int64_t)a->n_head * a->head_dim; p.stat_hs = a->T;   // the queries are the rows of qkv
     OBTE_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "obte_attn_fwd: dropout p must be in [0,1)");
     p.drop = make_drop(a->dropout_p, a->dropout_seed, OBTE_SITE_ATTN);
     p.max_tiles = debug_max_tiles(); p.no_wait = debug_no_wait();
@@ -1096,6 +1109,7 @@ extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
     p.dqkv = (bf16*)a->dqkv; p.rope_cos = a->rope_cos; p.rope_sin = a->rope_sin; p.query_bounds = a->mask ? a->query_bounds : nullptr;
     p.key_ranges = a->key_ranges; p.mask = (const bf16*)a->mask; p.mask_sb = a->mask_sb; p.mask_sh = a->mask_sh; p.mask_sq = a->mask_sq;
     p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
+    p.q_src = p.qkv; p.q_ld = 3 * (int64_t)a->n_head * a->head_dim; p.dq_dst = p.dqkv; p.dq_ld = p.q_ld; p.stat_hs = a->T;   // the queries are the rows of qkv
     OBTE_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "obte_attn_bwd: dropout p must be in [0,1)");
     p.drop = make_drop(a->dropout_p, a->dropout_seed, OBTE_SITE_ATTN);
     p.max_tiles = debug_max_tiles(); p.no_wait = debug_no_wait(); p.dbg_skip = debug_skip();
@@ -1215,4 +1229,139 @@ extern "C" int obte_mask_bounds(const obte_bf16* mask, int64_t mask_sb, int64_t 
         OBTE_CHECK_LAUNCH("obte_mask_bounds(column check)");
     }
     return OBTE_OK;
+}
+
+// ---- queries at listed rows only (common.h: obte_attn_rows) ------------------------------------------------------------------------------
+namespace {
+// first index i in [0, n) with rows[i] >= v (n if none)
+__device__ __forceinline__ int64_t rows_lower_bound(const int64_t* rows, int64_t n, int64_t v) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (rows[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// thread i < B + 1: q_off; thread j < n: position and key range of gathered row j; thread m < B T: inverse index and, with a mask, the
+// gathered rows that see key m (the positions of the key's own range: symmetric masks)
+__global__ __launch_bounds__(256) void attn_rows_prep_kernel(const int64_t* rows, int64_t n, int64_t B, int64_t T, const int32_t* kr_full,
+                                                              int32_t* q_off, int32_t* q_blk_off, int32_t* q_pos, int32_t* kr_rows, int32_t* qb_rows, int32_t* inv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i <= B) {
+        q_off[i] = (int32_t)rows_lower_bound(rows, n, i * T);
+        int64_t blocks = 0, prev = 0;   // 256-query blocks of the batch elements before i (the compact grid of the query-major kernels)
+        for (int64_t b = 0; b < i; ++b) {
+            const int64_t next = rows_lower_bound(rows, n, (b + 1) * T);
+            blocks += (next - prev + 255) / 256;
+            prev = next;
+        }
+        q_blk_off[i] = (int32_t)blocks;
+    }
+    if (i < n) {
+        const int64_t r = rows[i];
+        q_pos[i] = (int32_t)(r % T);
+        if (kr_full) { kr_rows[2 * i] = kr_full[2 * r]; kr_rows[2 * i + 1] = kr_full[2 * r + 1]; }
+    }
+    if (i < B * T) {
+        const int64_t at = rows_lower_bound(rows, n, i);
+        inv[i] = (at < n && rows[at] == i) ? (int32_t)at : -1;
+        if (kr_full) {
+            const int64_t b = i / T, base = rows_lower_bound(rows, n, b * T);
+            const int64_t qs = max((int64_t)kr_full[2 * i], (int64_t)0), qe = min((int64_t)kr_full[2 * i + 1], T);
+            qb_rows[2 * i] = (int32_t)(rows_lower_bound(rows, n, b * T + qs) - base);
+            qb_rows[2 * i + 1] = qe > qs ? (int32_t)(rows_lower_bound(rows, n, b * T + qe) - base) : qb_rows[2 * i];
+        }
+    }
+}
+// one wave per row, 16 B per lane per step
+__global__ __launch_bounds__(256) void rows_fill_strided_kernel(const bf16* src, const int32_t* inv, bf16* dst, int64_t total_rows, int64_t ld, int cols) {
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= total_rows) return;
+    const int lane = threadIdx.x & 63;
+    const int32_t j = inv[m];
+    for (int c = lane * 8; c < cols; c += 512) {
+        bf16x8 v = {};
+        if (j >= 0) v = *reinterpret_cast<const bf16x8*>(src + (int64_t)j * cols + c);
+        *reinterpret_cast<bf16x8*>(dst + m * ld + c) = v;
+    }
+}
+__global__ __launch_bounds__(256) void rows_gather_strided_kernel(const bf16* src, int64_t ld, const int64_t* rows, bf16* dst, int64_t n_rows, int cols) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = rows[i];
+    for (int c = lane * 8; c < cols; c += 512) *reinterpret_cast<bf16x8*>(dst + i * cols + c) = *reinterpret_cast<const bf16x8*>(src + r * ld + c);
+}
+}  // namespace
+
+int obte_attn_rows_prep(const int64_t* rows, int64_t n, int64_t B, int64_t T, const int32_t* key_ranges_full, int32_t* q_off, int32_t* q_blk_off,
+                        int32_t* q_pos, int32_t* key_ranges_rows, int32_t* query_bounds_rows, int32_t* inv, obte_stream s) {
+    OBTE_REQUIRE(rows && n > 0 && n <= B * T && q_off && q_blk_off && q_pos && inv, "obte_attn_rows_prep: bad arguments");
+    OBTE_REQUIRE(!key_ranges_full || (key_ranges_rows && query_bounds_rows), "obte_attn_rows_prep: a mask needs both output tables");
+    hipLaunchKernelGGL(attn_rows_prep_kernel, dim3((unsigned)cdiv64(B * T + 1, 256)), dim3(256), 0, (hipStream_t)s, rows, n, B, T, key_ranges_full,
+                       q_off, q_blk_off, q_pos, key_ranges_rows, query_bounds_rows, inv);
+    OBTE_CHECK_LAUNCH("obte_attn_rows_prep");
+    return OBTE_OK;
+}
+int obte_rows_fill_strided_bf16(const obte_bf16* src, const int32_t* inv, obte_bf16* dst, int64_t total_rows, int64_t ld, int32_t cols, obte_stream s) {
+    OBTE_REQUIRE(src && inv && dst && total_rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0 && ld >= cols, "obte_rows_fill_strided_bf16: bad arguments");
+    hipLaunchKernelGGL(rows_fill_strided_kernel, dim3((unsigned)cdiv64(total_rows, 4)), dim3(256), 0, (hipStream_t)s, (const bf16*)src, inv, (bf16*)dst, total_rows, ld, (int)cols);
+    OBTE_CHECK_LAUNCH("obte_rows_fill_strided_bf16");
+    return OBTE_OK;
+}
+int obte_rows_gather_strided_bf16(const obte_bf16* src, int64_t ld, const int64_t* rows, obte_bf16* dst, int64_t n_rows, int32_t cols, obte_stream s) {
+    OBTE_REQUIRE(src && rows && dst && n_rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0 && ld >= cols, "obte_rows_gather_strided_bf16: bad arguments");
+    hipLaunchKernelGGL(rows_gather_strided_kernel, dim3((unsigned)cdiv64(n_rows, 4)), dim3(256), 0, (hipStream_t)s, (const bf16*)src, ld, rows, (bf16*)dst, n_rows, (int)cols);
+    OBTE_CHECK_LAUNCH("obte_rows_gather_strided_bf16");
+    return OBTE_OK;
+}
+
+static int rows_common(const char* who, const obte_attn_rows* r, const void* q, int64_t B, int64_t T, const obte_bf16* mask, float dropout_p) {
+    OBTE_REQUIRE(r && q && r->q_off && r->q_blk_off && r->q_pos && r->n > 0 && r->n <= B * T, "%s: bad row set", who);
+    OBTE_REQUIRE(!mask && dropout_p == 0.f, "%s: the rows form takes key ranges or no mask, no dropout", who);
+    OBTE_REQUIRE((r->key_ranges == nullptr) == (r->query_bounds == nullptr), "%s: a range mask needs both the rows' key ranges and the keys' row bounds", who);
+    return OBTE_OK;
+}
+int obte_attn_fwd_rows(const obte_attn_fwd_args* a, const obte_attn_rows* r, const obte_bf16* q, obte_stream s) {
+    OBTE_REQUIRE(a, "obte_attn_fwd_rows: null args");
+    int rc = check_common("obte_attn_fwd_rows", a->qkv, a->B, a->T, a->n_head, a->head_dim, nullptr, nullptr);
+    if (rc) return rc;
+    rc = rows_common("obte_attn_fwd_rows", r, q, a->B, a->T, a->mask, a->dropout_p);
+    if (rc) return rc;
+    OBTE_REQUIRE(a->o && a->lse, "obte_attn_fwd_rows: null output");
+    AttnParams p = {};
+    p.qkv = (const bf16*)a->qkv; p.o = (bf16*)a->o; p.lse = a->lse;
+    p.key_ranges = r->key_ranges;
+    p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
+    p.q_off = r->q_off; p.q_blk_off = r->q_blk_off; p.q_src = (const bf16*)q; p.q_ld = (int64_t)a->n_head * a->head_dim; p.q_pos = r->q_pos; p.stat_hs = r->n;
+    p.drop = make_drop(0.f, 0, OBTE_SITE_ATTN);
+    p.max_tiles = debug_max_tiles(); p.no_wait = debug_no_wait();
+    const int mode = r->key_ranges ? MASK_RANGES : MASK_NONE;
+    const int prof = obte_prof_begin((hipStream_t)s, 102, a->n_head * r->n, a->T, a->head_dim);   // kind 102 / 103: (queries x heads, keys, head size)
+    rc = a->head_dim == 128 ? launch_fwd<128>(p, mode, (hipStream_t)s) : launch_fwd<64>(p, mode, (hipStream_t)s);
+    obte_prof_end(prof, (hipStream_t)s);
+    return rc;
+}
+int obte_attn_bwd_rows(const obte_attn_bwd_args* a, const obte_attn_rows* r, const obte_bf16* q, obte_bf16* dq, obte_stream s) {
+    OBTE_REQUIRE(a, "obte_attn_bwd_rows: null args");
+    int rc = check_common("obte_attn_bwd_rows", a->qkv, a->B, a->T, a->n_head, a->head_dim, nullptr, nullptr);
+    if (rc) return rc;
+    rc = rows_common("obte_attn_bwd_rows", r, q, a->B, a->T, a->mask, a->dropout_p);
+    if (rc) return rc;
+    OBTE_REQUIRE(a->o && a->d_o && a->lse && a->delta && a->dqkv && dq, "obte_attn_bwd_rows: null pointer");
+    OBTE_REQUIRE((a->rope_cos == nullptr) == (a->rope_sin == nullptr), "obte_attn_bwd_rows: pass both RoPE tables or neither");
+    AttnParams p = {};
+    p.qkv = (const bf16*)a->qkv; p.o_in = (const bf16*)a->o; p.d_o = (const bf16*)a->d_o; p.lse_in = a->lse; p.delta = a->delta;
+    p.dqkv = (bf16*)a->dqkv; p.rope_cos = a->rope_cos; p.rope_sin = a->rope_sin;
+    p.key_ranges = r->key_ranges; p.query_bounds = r->query_bounds;
+    p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
+    p.q_off = r->q_off; p.q_blk_off = r->q_blk_off; p.q_src = (const bf16*)q; p.q_ld = (int64_t)a->n_head * a->head_dim; p.dq_dst = (bf16*)dq; p.dq_ld = p.q_ld;
+    p.q_pos = r->q_pos; p.stat_hs = r->n;
+    p.drop = make_drop(0.f, 0, OBTE_SITE_ATTN);
+    p.max_tiles = debug_max_tiles(); p.no_wait = debug_no_wait(); p.dbg_skip = debug_skip();
+    const int mode = r->key_ranges ? MASK_RANGES : MASK_NONE;
+    const int prof = obte_prof_begin((hipStream_t)s, 103, a->n_head * r->n, a->T, a->head_dim);
+    rc = a->head_dim == 128 ? launch_bwd<128>(p, mode, (hipStream_t)s) : launch_bwd<64>(p, mode, (hipStream_t)s);
+    obte_prof_end(prof, (hipStream_t)s);
+    return rc;
 }

@@ -24,6 +24,18 @@ struct AttnParams {
                                    // the exact query range of every key in range mode (else the mask is taken to be symmetric)
     const int32_t* gate;           // the *_gated_kernel entry points: device flag (obte_mask_bounds' ranges_exact), 1 = run the range-mode body
     int64_t B, T; int H; float scale;
+    // The QUERY side (forward, dQ and dK/dV kernels of attention.hip; the one-kernel backward does not use these).  Normally the
+    // queries are the T rows of every batch element inside qkv.  With q_off they are a separate, gathered set of rows per batch
+    // element (the last block of a masked-LM step needs its attention output at the masked positions only: csrc/block.cpp):
+    // batch element b owns q-side rows q_off[b] .. q_off[b + 1] - 1 of q_src / o / o_in / d_o / dq_dst and of key_ranges; lse and
+    // delta hold entry (head, q-side row r) at head * stat_hs + r.  Keys and values are always the T rows of qkv.
+    const int32_t* q_off;            // [B + 1], or null
+    const int32_t* q_blk_off;        // with q_off, the query-major kernels: [B + 1] first 256-query block of every batch element in the compact
+                                     // grid (the grid holds only blocks that have queries: an early-exit workgroup per empty block cost 3x the kernel)
+    const bf16* q_src; int64_t q_ld; // Q rows (head h at column h * D): qkv, 3C without q_off
+    bf16* dq_dst; int64_t dq_ld;     // dQ rows: dqkv, 3C without q_off
+    const int32_t* q_pos;            // with q_off: the sequence position of every q-side row (inverse RoPE of dQ); null: the row's own index
+    int64_t stat_hs;                 // lse / delta stride between heads: T without q_off (entry ((b H + head) T + q)), the row count with it
     DropCfg drop;   // attention-probability dropout (site 1); thresh16 == 0: off
     uint32_t* drop_bits_out;         // forward, nullable: keep bits in key-major order, uint32 [B*H][ceil(T/32)][T] (bit i = query 32 t + i)
     const uint32_t* drop_bits_in;    // backward, nullable: the same buffer
@@ -33,6 +45,19 @@ struct AttnParams {
                     // 4: no phase-A MFMAs, 8: no per-tile barrier (results are wrong)
     unsigned long long* dbg_times;   // debug build (OBTE_ATTN_TIMES=1): per workgroup, s_memrealtime at entry / loop start / loop end / stores issued / stores done
 };
+// the query side of batch element b, head hd: first q-side row, number of queries, first lse / delta entry
+struct QSide { int64_t row0; int n; int64_t stat0; };
+__device__ __forceinline__ QSide q_side(const AttnParams& p, int64_t b, int hd) {
+    QSide q;
+    if (p.q_off) {
+        const int o = __builtin_amdgcn_readfirstlane(p.q_off[b]), e = __builtin_amdgcn_readfirstlane(p.q_off[b + 1]);
+        q.row0 = o; q.n = e - o; q.stat0 = (int64_t)hd * p.stat_hs + o;
+    } else {
+        q.row0 = b * p.T; q.n = (int)p.T; q.stat0 = (b * p.H + hd) * p.T;
+    }
+    return q;
+}
+
 #ifdef OBTE_DEBUG_HOOKS
 #define OBTE_STAMP(p, k) do { if ((p).dbg_times && threadIdx.x == 0) (p).dbg_times[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -163,6 +188,18 @@ __device__ __forceinline__ bool mask_vec_ok(const AttnParams& p) {
 // receives (block id % 8) cover a CONTIGUOUS range of work ids, with the row blocks of one (batch, head) adjacent: the
 // blocks that stream the same K/V (or Q/dO) through LDS then share one L2 instead of pulling it into up to four.
 struct BlockId { int blk, hd; int64_t b; };
+// the compact grid of a gathered query set: workgroup w -> head w % H, block index w / H located in q_blk_off; blk < 0: nothing to do
+__device__ __forceinline__ BlockId block_id_rows(const AttnParams& p) {
+    const int w = blockIdx.x, H = p.H;
+    const int idx = w / H;
+    int lo = 0, hi = (int)p.B;            // last b with q_blk_off[b] <= idx
+    if (idx >= p.q_blk_off[p.B]) return BlockId{-1, 0, 0};
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (p.q_blk_off[mid] <= idx) lo = mid; else hi = mid;
+    }
+    return BlockId{idx - p.q_blk_off[lo], w % H, (int64_t)lo};
+}
 __device__ __forceinline__ BlockId block_id(int nblk, int H) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;

@@ -11,7 +11,7 @@ namespace {
 inline int64_t align256(int64_t x) { return (x + 255) & ~int64_t(255); }
 
 struct ActLayout {
-    int64_t mean1, rstd1, h1, qkv, lse, y, x1, mean2, rstd2, h2, hpre, hact, x1r, dropbits, total;
+    int64_t mean1, rstd1, h1, qkv, lse, y, x1, mean2, rstd2, h2, hpre, hact, x1r, r_off, r_boff, r_pos, r_kr, r_qb, r_inv, dropbits, total;
     // with_bits: the attention dropout's keep bits (B H ceil(T/32) T words: 134 MB per block at B = 8, T = 4096) are part of the
     // buffer only when dropout is on; they are the LAST region, so every other offset is the same either way
     ActLayout(int64_t B, int64_t T, int C, int H, bool with_bits = true) {
@@ -29,6 +29,8 @@ struct ActLayout {
         hpre = take(M * 4 * C * 2);
         hact = take(M * 4 * C * 2);
         x1r = take(M * C * 2);      // rows form (obte_block_desc::out_rows): x1 at the wanted positions
+        // rows form with the attention's queries at the wanted positions only (rows_attn below): the tables of obte_attn_rows_prep
+        r_off = take((B + 1) * 4); r_boff = take((B + 1) * 4); r_pos = take(M * 4); r_kr = take(M * 8); r_qb = take(M * 8); r_inv = take(M * 4);
         dropbits = take(with_bits ? obte_attn_drop_bits_bytes(B, T, H) : 0);   // attention dropout: the forward's keep bits for the backward
         total = o;
     }
@@ -109,6 +111,13 @@ int check_desc(const char* who, const obte_block_desc* d) {
 
 // rows form with the attention projection on the wanted rows only (see obte_block_fwd); OBTE_ROWS_PROJ=0 keeps the projection on
 // every row (A/B timing, tests)
+// ... and the attention itself with its QUERIES at the wanted rows only (keys and values of every position; common.h obte_attn_rows):
+// the wanted rows' attention output is all the rest of the block reads.  Key ranges or no mask; OBTE_ROWS_ATTN=0 keeps the full attention.
+bool rows_proj(const obte_block_desc* d);
+bool rows_attn(const obte_block_desc* d) {
+    static const bool off = [] { const char* e = getenv("OBTE_ROWS_ATTN"); return e && e[0] == '0'; }();
+    return rows_proj(d) && d->mask == nullptr && !off;
+}
 bool rows_proj(const obte_block_desc* d) {
     static const bool off = [] { const char* e = getenv("OBTE_ROWS_PROJ"); return e && e[0] == '0'; }();
     return d->out_rows != nullptr && d->dropout_p == 0.f && !off;
@@ -147,6 +156,15 @@ extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte
         g.rope_cos = d->rope_cos; g.rope_sin = d->rope_sin; g.rope_T = d->T; g.rope_head_dim = hs;
         TRY(obte_gemm_bf16(&g, s));
     }
+    const bool r_attn = rows_attn(d);
+    obte_attn_rows ar = {};
+    if (r_attn) {   // tables of the row set (q_off, positions, the rows' key ranges, the keys' row bounds, inverse index): once per call
+        ar.q_off = (const int32_t*)(A + L.r_off); ar.q_blk_off = (const int32_t*)(A + L.r_boff); ar.q_pos = (const int32_t*)(A + L.r_pos); ar.n = d->n_out_rows;
+        ar.key_ranges = d->key_ranges ? (const int32_t*)(A + L.r_kr) : nullptr;
+        ar.query_bounds = d->key_ranges ? (const int32_t*)(A + L.r_qb) : nullptr;
+        TRY(obte_attn_rows_prep(d->out_rows, d->n_out_rows, d->B, d->T, d->key_ranges, (int32_t*)(A + L.r_off), (int32_t*)(A + L.r_boff), (int32_t*)(A + L.r_pos),
+                                (int32_t*)(A + L.r_kr), (int32_t*)(A + L.r_qb), (int32_t*)(A + L.r_inv), s));
+    }
     obte_attn_fwd_args af = {};
     af.qkv = qkv; af.o = yat; af.lse = lse; af.key_ranges = d->key_ranges; af.mask = d->mask;
     af.mask_sb = d->mask_sb; af.mask_sh = d->mask_sh; af.mask_sq = d->mask_sq;
@@ -160,7 +178,15 @@ extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte
         }
     }
     af.ranges_exact = d->ranges_exact;
-    TRY(obte_attn_fwd(&af, s));
+    if (r_attn) {   // Q of the wanted rows gathered into the region of the full attention output (not formed in this form); the rows'
+                    // attention output lands where the projection below expects its gathered input: the region of the full x1
+        obte_bf16* qr = yat;
+        TRY(obte_rows_gather_strided_bf16(qkv, 3 * (int64_t)C, d->out_rows, qr, d->n_out_rows, C, s));
+        af.o = x1;
+        TRY(obte_attn_fwd_rows(&af, &ar, qr, s));
+    } else {
+        TRY(obte_attn_fwd(&af, s));
+    }
     // the attention projection and the MLP half: on every position, or (rows form) on the n wanted positions only — per-position
     // arithmetic, same results there.  Rows form without dropout: the projection too runs on the wanted rows (the attention output
     // and the block input gathered; x1 = x + y W_proj^T formed for those rows alone; the region of the full x1 keeps the gathered
@@ -172,7 +198,7 @@ extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte
         obte_bf16* yr = x1;
         Mm = d->n_out_rows; x1m = x1r;
         TRY(obte_rows_gather_bf16(x, d->out_rows, x1r, Mm, M, C, s));
-        TRY(obte_rows_gather_bf16(yat, d->out_rows, yr, Mm, M, C, s));
+        if (!r_attn) TRY(obte_rows_gather_bf16(yat, d->out_rows, yr, Mm, M, C, s));   // (rows_attn: the attention wrote the wanted rows there itself)
         TRY(gemm(yr, d->proj_w, x1r, Mm, C, C, C, C, 1, 1, OBTE_EPI_ADD, x1r, nullptr, s, (void*)(A + L.hpre), M * 4 * C * 2));   // (split-K workspace: the MLP's regions are not written yet)
     } else {
         TRY(gemm(yat, d->proj_w, x1, M, C, C, C, C, 1, 1, OBTE_EPI_ADD, x, nullptr, s, nullptr, 0, d->dropout_p, d->dropout_seed, SITE_RESID));
@@ -246,6 +272,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     // and go out as their own launches, the grouped launch keeps the attention half's
     const bool rows_form = d->out_rows != nullptr;
     const bool rows_p = rows_proj(d);   // (implies rows_form, no dropout, and — below — the ungrouped form of the attention half)
+    const bool r_attn = rows_attn(d);   // (implies rows_p: the attention's queries were the wanted rows only)
     const int64_t Mm = rows_form ? d->n_out_rows : M;
     const obte_bf16* x1m = rows_form ? (const obte_bf16*)(A + L.x1r) : x1;
     const bool grouped_mlp = grouped && !rows_form;
@@ -298,7 +325,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
             obte_bf16* dyr = dym;                                       // d(attention output) at the wanted rows (dym is free without dropout)
             TRY(gemm(dx1r, d->proj_w, dyr, Mm, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s, gws, W.gemmws_bytes));
             TRY(gemm(dx1r, yr, dproj_w, C, C, Mm, C, C, 0, 0, wepi, accumulate_matrices ? dproj_w : nullptr, nullptr, s, gws, W.gemmws_bytes));   // dW_proj = dx1^T y over the wanted rows
-            TRY(obte_rows_scatter_bf16(dyr, d->out_rows, dyattn, Mm, M, C, s));   // (dx1r, staged in dyattn, has been read by both products)
+            if (!r_attn) TRY(obte_rows_scatter_bf16(dyr, d->out_rows, dyattn, Mm, M, C, s));   // (dx1r, staged in dyattn, has been read by both products; rows_attn: the attention backward takes the gathered rows as they are)
         }
     } else if (lnp) {
         TRY(obte_layernorm_bwd_partial(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, d->ln2_partials, M, C, lnp, s));
@@ -317,7 +344,19 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     ab.dropout_p = d->dropout_p; ab.dropout_seed = d->dropout_seed;
     ab.drop_bits = d->dropout_p > 0.f ? (const uint32_t*)(A + L.dropbits) : nullptr;
     if (W.attnws_bytes > 0) { ab.ws = (void*)(S + W.attnws); ab.ws_bytes = W.attnws_bytes; }
-    TRY(obte_attn_bwd(&ab, s));
+    if (r_attn) {   // queries at the wanted rows: everything on the query side is the gathered set (forward: Q rows in the region of the
+                    // full attention output, the rows' output in the region of the full x1; the tables of the row set in the buffer's tail)
+        obte_attn_rows ar = {};
+        ar.q_off = (const int32_t*)(A + L.r_off); ar.q_blk_off = (const int32_t*)(A + L.r_boff); ar.q_pos = (const int32_t*)(A + L.r_pos); ar.n = d->n_out_rows;
+        ar.key_ranges = d->key_ranges ? (const int32_t*)(A + L.r_kr) : nullptr;
+        ar.query_bounds = d->key_ranges ? (const int32_t*)(A + L.r_qb) : nullptr;
+        ab.o = x1; ab.d_o = dym;
+        obte_bf16* dqr = dym2;
+        TRY(obte_attn_bwd_rows(&ab, &ar, yat, dqr, s));
+        TRY(obte_rows_fill_strided_bf16(dqr, (const int32_t*)(A + L.r_inv), dqkv, M, 3 * (int64_t)C, C, s));   // dqkv's q third: the rows' dQ, zeros elsewhere
+    } else {
+        TRY(obte_attn_bwd(&ab, s));
+    }
     // OBTE_GROUPED_DGRAD=0 keeps dh1 = dqkv W_attn as its own launch (A/B timing)
     const char* gd = getenv("OBTE_GROUPED_DGRAD");
     const bool group_dgrad = grouped && !(gd && gd[0] == '0');

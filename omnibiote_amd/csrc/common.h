@@ -37,6 +37,29 @@ void obte_set_error(const char* fmt, ...);
         }                                                                                 \
     } while (0)
 
+// ---- attention with the queries at listed rows only (library-internal: csrc/block.cpp's rows form calls it; attention.hip) -----------
+// The last block of a masked-LM step needs its attention output at the masked positions alone: the queries are a gathered set of
+// rows per batch element (ascending positions), keys and values stay the T rows of qkv.  Everything on the query side is
+// indexed by the gathered rows, n in all: q [n, C] (gathered rows of qkv's q third), o / d_o / dq [n, C], lse / delta [H][n].
+struct obte_attn_rows {
+    const int32_t* q_off;        // [B + 1]: batch element b owns gathered rows q_off[b] .. q_off[b + 1] - 1
+    const int32_t* q_blk_off;    // [B + 1]: its first 256-row block in the compact grid of the query-major kernels
+    const int32_t* q_pos;        // [n]: sequence position of every gathered row
+    const int32_t* key_ranges;   // [n][2] key range of every gathered row, or null (no mask)
+    const int32_t* query_bounds; // [B T][2]: for every key the gathered rows (indices within its batch element) that see it; null with no mask
+    int64_t n;
+};
+// obte_attn_rows_prep fills the five arrays from the ascending row list (global rows b T + position) and the full-size key ranges
+// (null: no mask; the masks are symmetric, SURVEY fact 5: a key's queries are the positions of its own range) and, for the
+// backward's scatter, inv [B T]: the gathered index of every row or -1.
+int obte_attn_rows_prep(const int64_t* rows, int64_t n, int64_t B, int64_t T, const int32_t* key_ranges_full, int32_t* q_off, int32_t* q_blk_off,
+                        int32_t* q_pos, int32_t* key_ranges_rows, int32_t* query_bounds_rows, int32_t* inv, obte_stream s);
+int obte_attn_fwd_rows(const obte_attn_fwd_args* a, const obte_attn_rows* r, const obte_bf16* q, obte_stream s);   // a->o, a->lse: gathered
+int obte_attn_bwd_rows(const obte_attn_bwd_args* a, const obte_attn_rows* r, const obte_bf16* q, obte_bf16* dq, obte_stream s);   // a->o, d_o, lse, delta: gathered; a->dqkv: dK, dV thirds
+// dst[m, 0:cols] (row stride ld) = src[inv[m]] (cols wide, dense) or zeros where inv[m] < 0; and the strided gather dst[i] = src[rows[i], 0:cols]
+int obte_rows_fill_strided_bf16(const obte_bf16* src, const int32_t* inv, obte_bf16* dst, int64_t total_rows, int64_t ld, int32_t cols, obte_stream s);
+int obte_rows_gather_strided_bf16(const obte_bf16* src, int64_t ld, const int64_t* rows, obte_bf16* dst, int64_t n_rows, int32_t cols, obte_stream s);
+
 // device status word (lib.cpp): pinned host memory kernels OR failure bits into; null if it could not be allocated
 int32_t* obte_status_word();
 int obte_fault_injection();   // the tests' fault-injection request (obte_fault_inject), 0 = none
