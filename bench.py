@@ -360,7 +360,7 @@ def measure_other_config(name: str, rows: int, a, dev, steps: int = 2, warmup: i
     value = rows * T * steps / el
     fpt = TE.flops_per_token(n_params, cfg["n_layer"], cfg["n_embd"], T)
     fpt_exec = TE.flops_per_token_executed(n_params, cfg["n_layer"], cfg["n_embd"], T, a.readout, not a.full_last_block,
-                                           rows_attention=(not a.full_last_block) and a.dropout == 0.0 and not a.dense_mask)
+                                           rows_attention=(not a.full_last_block) and not a.dense_mask)
     out = {"workload": f"{READOUT_LEAD['masked_full' if (a.readout == 'masked' and a.full_last_block) else a.readout]}; OmniBioTA {name} "
                        f"({cfg['n_layer']}L/{cfg['n_embd']}d/{cfg['n_head']}h) ctx={T}, {rows} rows = {rows // a.mini_batch_size} micro-batches of "
                        f"{a.mini_batch_size}, dropout {a.dropout:g}, single-document rows, one GPU",
@@ -603,7 +603,7 @@ def main():
     fpt = TE.flops_per_token(n_params, cfg["n_layer"], cfg["n_embd"], T)
     # 15 % of the positions are MLM-masked (train_encoder.py:271); their share of the readout products (and of the last block's MLP half) remains
     fpt_exec = TE.flops_per_token_executed(n_params, cfg["n_layer"], cfg["n_embd"], T, a.readout, not a.full_last_block,
-                                           rows_attention=(not a.full_last_block) and a.dropout == 0.0 and not a.dense_mask)
+                                           rows_attention=(not a.full_last_block) and not a.dense_mask)
 
     log(f"timed region done: {value:,.0f} tokens/s")
     tail_guard = Watchdog(900.0, "profiled step + variants (they contain collectives at N > 1)")
@@ -753,7 +753,7 @@ def main():
             v = timed_variant(bs=md)
             fpt_md = TE.flops_per_token_executed(n_params, cfg["n_layer"], cfg["n_embd"], T, a.readout, not a.full_last_block,
                                                  attention_fraction=work["tile_fraction"],
-                                                 rows_attention=(not a.full_last_block) and a.dropout == 0.0 and not a.dense_mask)
+                                                 rows_attention=(not a.full_last_block) and not a.dense_mask)
             variants["multi_document"] = {"value": v, "unit": "tokens/s", "steps": 10,
                                           "attention_work": work, "flops_per_token_executed": fpt_md,
                                           "mfma_fraction_whole_step_executed": round(v * fpt_md / (PEAK_BF16_TFLOPS * 1e12 * world), 4),

@@ -354,13 +354,14 @@ typedef struct {
      * loss multiplies every other position by zero (train_encoder.py:304) and nothing after the last block mixes positions.
      * out_rows: int64 [n_out_rows], ascending distinct rows of the [B*T, C] activation.  ln_1 and c_attn run on every position
      * (keys and values of all of them are needed); ln_2, c_fc + GELU and mlp.c_proj run on the listed rows only: y is
-     * [n_out_rows, C].  Without dropout and without a dense mask the attention itself runs with its QUERIES at the listed rows
-     * only (keys and values of every position; the rows' key ranges decide what each sees), and the attention projection on
-     * those rows.  Backward: dy is [n_out_rows, C]; every gradient of those products is contracted over / formed for the listed
-     * rows (the rows left out would contribute exact zeros); dK and dV of every position, dQ of the listed rows (zeros
-     * elsewhere) feed c_attn's backward as usual.  With dropout (or a dense mask) the attention half runs on every position as
-     * in the whole block and x1 is gathered; site 3 (the MLP projection) masks element (i, c) of the [n_out_rows, C] output,
-     * forward and backward alike; sites 1 and 2 are unchanged.  NULL / 0: the whole block on every position. */
+     * [n_out_rows, C].  Without a dense mask the attention itself runs with its QUERIES at the listed rows only (keys and values
+     * of every position; the rows' key ranges decide what each sees), and the attention projection on those rows.  Backward: dy
+     * is [n_out_rows, C]; every gradient of those products is contracted over / formed for the listed rows (the rows left out
+     * would contribute exact zeros); dK and dV of every position, dQ of the listed rows (zeros elsewhere) feed c_attn's backward
+     * as usual.  With a dense mask the attention runs on every position as in the whole block and its output is gathered.
+     * Dropout: sites 1 (attention probabilities) and 2 (attention projection) keep the masks they have in the whole block — a
+     * listed row's mask elements are those of its position; site 3 (the MLP projection) masks element (i, c) of the
+     * [n_out_rows, C] output, forward and backward alike.  NULL / 0: the whole block on every position. */
     const int64_t* out_rows; int64_t n_out_rows;
     /* backward only, optional, dropout only (p > 0): the hand-off of the masked gradient between consecutive blocks.  Block i's
      * MLP projection needs dy under ITS (seed, site 3) mask, and dy is the dx of block i + 1 — so block i + 1's last LayerNorm

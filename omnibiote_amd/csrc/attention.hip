@@ -68,7 +68,8 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qptr + 16 * s + 8 * h);
     // dropout row = (batch, head, query): its key is formed once per lane, not once per probability
-    const uint32_t drop_rk = DROP ? drop_rowkey(((uint64_t)b * p.H + hd) * (uint64_t)T + (uint64_t)q_c, p.drop) : 0u;
+    // (the mask's row is the query's POSITION in its sequence: a gathered query keeps the mask it has in the whole attention)
+    const uint32_t drop_rk = DROP ? drop_rowkey(((uint64_t)b * p.H + hd) * (uint64_t)T + (uint64_t)(p.q_pos ? p.q_pos[qsd.row0 + q_c] : q_c), p.drop) : 0u;
 
     int ks = 0, ke = T;
     if (MODE == MASK_RANGES) {
@@ -344,7 +345,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, char* smem
         dof[s] = *reinterpret_cast<const bf16x8*>(doptr + 16 * s + 8 * h);
     }
     const float lse2 = p.lse_in[qsd.stat0 + q_c] * LOG2E;
-    const uint32_t drop_rk = DROP ? drop_rowkey(((uint64_t)b * p.H + hd) * (uint64_t)T + (uint64_t)q_c, p.drop) : 0u;
+    // (the mask's row is the query's POSITION in its sequence: a gathered query keeps the mask it has in the whole attention)
+    const uint32_t drop_rk = DROP ? drop_rowkey(((uint64_t)b * p.H + hd) * (uint64_t)T + (uint64_t)(p.q_pos ? p.q_pos[qsd.row0 + q_c] : q_c), p.drop) : 0u;
     const bf16* optr = p.o_in + (qsd.row0 + q_c) * C + hd * D;
     bf16x8 of[NS];
 #pragma unroll
@@ -608,8 +610,8 @@ __device__ __forceinline__ void attn_bwd_dkdv_body(const AttnParams& p, char* sm
             else if (tid < 32) v = INFINITY;   // rows past the last query: p = exp2(x - inf) = 0
             st_l = v;
         } else if (DROP && tid < 96) {
-            const int q = min(q0 + (tid & 31), T - 1);
-            st_l = __uint_as_float(drop_rowkey(((uint64_t)b * p.H + hd) * (uint64_t)T + (uint64_t)q, p.drop));
+            const int q = min(q0 + (tid & 31), Tq - 1);
+            st_l = __uint_as_float(drop_rowkey(((uint64_t)b * p.H + hd) * (uint64_t)T + (uint64_t)(p.q_pos ? p.q_pos[qsd.row0 + q] : q), p.drop));
         }
     };
     auto store_stats = [&](char* stage) {
@@ -833,7 +835,7 @@ int mask_mode(const int32_t* ranges, const obte_bf16* mask) { return mask ? MASK
 template <int D>
 int launch_fwd(const AttnParams& p, int mode, hipStream_t st) {
     const int smem = 2 * FwdShape<false>::STAGES * 64 * 2 * D + 64;   // >= the dropout variant's two stages
-    const dim3 grid_d((unsigned)(cdiv64(p.T, 32 * FwdShape<true>::NW) * p.H * p.B)), block_d(64 * FwdShape<true>::NW);
+    const dim3 grid_d((unsigned)((p.q_blk_off ? cdiv64(p.stat_hs, 32 * FwdShape<true>::NW) + p.B : cdiv64(p.T, 32 * FwdShape<true>::NW) * p.B) * p.H)), block_d(64 * FwdShape<true>::NW);
     // (a gathered query set: only blocks that can hold queries — at most ceil(n / 256) + B of them — in a compact grid: block_id_rows)
     const dim3 grid((unsigned)((p.q_blk_off ? cdiv64(p.stat_hs, 32 * FwdShape<false>::NW) + p.B : cdiv64(p.T, 32 * FwdShape<false>::NW) * p.B) * p.H)), block(64 * FwdShape<false>::NW);
 #define GO(M)                                                                                 \
@@ -890,7 +892,7 @@ template <int D>
 int launch_bwd(const AttnParams& p, int mode, hipStream_t st) {
     {
         const int smem = 4 * 64 * 2 * D + 64;
-        const dim3 grid_d((unsigned)(cdiv64(p.T, 32 * FwdShape<true>::NW) * p.H * p.B)), block_d(64 * FwdShape<true>::NW);
+        const dim3 grid_d((unsigned)((p.q_blk_off ? cdiv64(p.stat_hs, 32 * FwdShape<true>::NW) + p.B : cdiv64(p.T, 32 * FwdShape<true>::NW) * p.B) * p.H)), block_d(64 * FwdShape<true>::NW);
         const dim3 grid((unsigned)((p.q_blk_off ? cdiv64(p.stat_hs, 32 * FwdShape<false>::NW) + p.B : cdiv64(p.T, 32 * FwdShape<false>::NW) * p.B) * p.H)), block(64 * FwdShape<false>::NW);
 #define GO(M)                                                                                    \
     do {                                                                                         \
@@ -1318,7 +1320,7 @@ int obte_rows_gather_strided_bf16(const obte_bf16* src, int64_t ld, const int64_
 
 static int rows_common(const char* who, const obte_attn_rows* r, const void* q, int64_t B, int64_t T, const obte_bf16* mask, float dropout_p) {
     OBTE_REQUIRE(r && q && r->q_off && r->q_blk_off && r->q_pos && r->n > 0 && r->n <= B * T, "%s: bad row set", who);
-    OBTE_REQUIRE(!mask && dropout_p == 0.f, "%s: the rows form takes key ranges or no mask, no dropout", who);
+    OBTE_REQUIRE(!mask && dropout_p >= 0.f && dropout_p < 1.f, "%s: the rows form takes key ranges or no mask; dropout p in [0,1)", who);
     OBTE_REQUIRE((r->key_ranges == nullptr) == (r->query_bounds == nullptr), "%s: a range mask needs both the rows' key ranges and the keys' row bounds", who);
     return OBTE_OK;
 }
@@ -1334,7 +1336,7 @@ int obte_attn_fwd_rows(const obte_attn_fwd_args* a, const obte_attn_rows* r, con
     p.key_ranges = r->key_ranges;
     p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
     p.q_off = r->q_off; p.q_blk_off = r->q_blk_off; p.q_src = (const bf16*)q; p.q_ld = (int64_t)a->n_head * a->head_dim; p.q_pos = r->q_pos; p.stat_hs = r->n;
-    p.drop = make_drop(0.f, 0, OBTE_SITE_ATTN);
+    p.drop = make_drop(a->dropout_p, a->dropout_seed, OBTE_SITE_ATTN);   // (hashed in both passes: no keep bits for a gathered query set)
     p.max_tiles = debug_max_tiles(); p.no_wait = debug_no_wait();
     const int mode = r->key_ranges ? MASK_RANGES : MASK_NONE;
     const int prof = obte_prof_begin((hipStream_t)s, 102, a->n_head * r->n, a->T, a->head_dim);   // kind 102 / 103: (queries x heads, keys, head size)
@@ -1357,7 +1359,7 @@ int obte_attn_bwd_rows(const obte_attn_bwd_args* a, const obte_attn_rows* r, con
     p.B = a->B; p.T = a->T; p.H = a->n_head; p.scale = a->scale;
     p.q_off = r->q_off; p.q_blk_off = r->q_blk_off; p.q_src = (const bf16*)q; p.q_ld = (int64_t)a->n_head * a->head_dim; p.dq_dst = (bf16*)dq; p.dq_ld = p.q_ld;
     p.q_pos = r->q_pos; p.stat_hs = r->n;
-    p.drop = make_drop(0.f, 0, OBTE_SITE_ATTN);
+    p.drop = make_drop(a->dropout_p, a->dropout_seed, OBTE_SITE_ATTN);
     p.max_tiles = debug_max_tiles(); p.no_wait = debug_no_wait(); p.dbg_skip = debug_skip();
     const int mode = r->key_ranges ? MASK_RANGES : MASK_NONE;
     const int prof = obte_prof_begin((hipStream_t)s, 103, a->n_head * r->n, a->T, a->head_dim);

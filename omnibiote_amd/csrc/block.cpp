@@ -120,7 +120,7 @@ bool rows_attn(const obte_block_desc* d) {
 }
 bool rows_proj(const obte_block_desc* d) {
     static const bool off = [] { const char* e = getenv("OBTE_ROWS_PROJ"); return e && e[0] == '0'; }();
-    return d->out_rows != nullptr && d->dropout_p == 0.f && !off;
+    return d->out_rows != nullptr && !off;
 }
 
 }  // namespace
@@ -170,7 +170,7 @@ extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte
     af.mask_sb = d->mask_sb; af.mask_sh = d->mask_sh; af.mask_sq = d->mask_sq;
     af.B = d->B; af.T = d->T; af.n_head = H; af.head_dim = hs; af.scale = 8.0f / (float)C;  // model.py:119
     af.dropout_p = d->dropout_p; af.dropout_seed = d->dropout_seed;
-    af.drop_bits = d->dropout_p > 0.f ? (uint32_t*)(A + L.dropbits) : nullptr;
+    af.drop_bits = (d->dropout_p > 0.f && !r_attn) ? (uint32_t*)(A + L.dropbits) : nullptr;   // (a gathered query set hashes in both passes)
     if (af.drop_bits) {   // words of key tiles the forward skips (pairs the mask excludes) stay defined whoever reads them
         if (hipMemsetAsync(af.drop_bits, 0, (size_t)obte_attn_drop_bits_bytes(d->B, d->T, H), (hipStream_t)s) != hipSuccess) {
             obte_set_error("obte_block_fwd: memset of the dropout keep bits failed");
@@ -199,7 +199,13 @@ extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte
         Mm = d->n_out_rows; x1m = x1r;
         TRY(obte_rows_gather_bf16(x, d->out_rows, x1r, Mm, M, C, s));
         if (!r_attn) TRY(obte_rows_gather_bf16(yat, d->out_rows, yr, Mm, M, C, s));   // (rows_attn: the attention wrote the wanted rows there itself)
-        TRY(gemm(yr, d->proj_w, x1r, Mm, C, C, C, C, 1, 1, OBTE_EPI_ADD, x1r, nullptr, s, (void*)(A + L.hpre), M * 4 * C * 2));   // (split-K workspace: the MLP's regions are not written yet)
+        if (d->dropout_p > 0.f) {   // the projection's dropout mask (site 2) is defined on the whole activation: element (rows[i], c) for gathered row i
+            obte_bf16* pr = (obte_bf16*)(A + L.h2);   // (ln_2's output region: written below)
+            TRY(gemm(yr, d->proj_w, pr, Mm, C, C, C, C, 1, 1, OBTE_EPI_NONE, nullptr, nullptr, s, (void*)(A + L.hpre), M * 4 * C * 2));
+            TRY(obte_dropout_rows_bf16(pr, x1r, x1r, d->out_rows, Mm, C, d->dropout_p, d->dropout_seed, SITE_RESID, s));
+        } else {
+            TRY(gemm(yr, d->proj_w, x1r, Mm, C, C, C, C, 1, 1, OBTE_EPI_ADD, x1r, nullptr, s, (void*)(A + L.hpre), M * 4 * C * 2));   // (split-K workspace: the MLP's regions are not written yet)
+        }
     } else {
         TRY(gemm(yat, d->proj_w, x1, M, C, C, C, C, 1, 1, OBTE_EPI_ADD, x, nullptr, s, nullptr, 0, d->dropout_p, d->dropout_seed, SITE_RESID));
         if (d->out_rows) {
@@ -316,15 +322,20 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
         if (lnp) TRY(obte_layernorm_bwd_partial(dh, x1m, d->ln2_w, mean2, rstd2, dy, dx1r, dln2_w, d->ln2_partials, Mm, C, lnp, s));
         else TRY(obte_layernorm_bwd_acc(dh, x1m, d->ln2_w, mean2, rstd2, dy, dx1r, dln2_w, lnws, Mm, C, acc_ln, s));
         TRY(obte_rows_scatter_bf16(dx1r, d->out_rows, dx1, Mm, M, C, s));
-        if (drop) {   // the attention projection sees d x1 under the (seed, site 2) mask, which is defined on whole activations
+        if (drop && !rows_p) {   // the attention projection sees d x1 under the (seed, site 2) mask, which is defined on whole activations
             TRY(obte_dropout_bf16(dx1, dym2, M * C, C, d->dropout_p, d->dropout_seed, SITE_RESID, s));
             dx1_proj = dym2;
         }
         if (rows_p) {   // the projection ran on the wanted rows: its two gradients contract over / are formed for those rows only
             const obte_bf16* yr = x1;                                   // the gathered attention output (forward)
-            obte_bf16* dyr = dym;                                       // d(attention output) at the wanted rows (dym is free without dropout)
-            TRY(gemm(dx1r, d->proj_w, dyr, Mm, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s, gws, W.gemmws_bytes));
-            TRY(gemm(dx1r, yr, dproj_w, C, C, Mm, C, C, 0, 0, wepi, accumulate_matrices ? dproj_w : nullptr, nullptr, s, gws, W.gemmws_bytes));   // dW_proj = dx1^T y over the wanted rows
+            obte_bf16* dyr = dym;                                       // d(attention output) at the wanted rows (dym: the MLP half's products above were its last readers)
+            const obte_bf16* dxp = dx1r;
+            if (drop) {   // d x1 of the wanted rows under the projection's mask (element (rows[i], c)), staged in dym2 (free: dq below is written after)
+                TRY(obte_dropout_rows_bf16(dx1r, nullptr, dym2, d->out_rows, Mm, C, d->dropout_p, d->dropout_seed, SITE_RESID, s));
+                dxp = dym2;
+            }
+            TRY(gemm(dxp, d->proj_w, dyr, Mm, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s, gws, W.gemmws_bytes));
+            TRY(gemm(dxp, yr, dproj_w, C, C, Mm, C, C, 0, 0, wepi, accumulate_matrices ? dproj_w : nullptr, nullptr, s, gws, W.gemmws_bytes));   // dW_proj = dx1^T y over the wanted rows
             if (!r_attn) TRY(obte_rows_scatter_bf16(dyr, d->out_rows, dyattn, Mm, M, C, s));   // (dx1r, staged in dyattn, has been read by both products; rows_attn: the attention backward takes the gathered rows as they are)
         }
     } else if (lnp) {
@@ -342,7 +353,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     ab.ranges_exact = d->ranges_exact;
     ab.B = d->B; ab.T = d->T; ab.n_head = H; ab.head_dim = hs; ab.scale = 8.0f / (float)C;
     ab.dropout_p = d->dropout_p; ab.dropout_seed = d->dropout_seed;
-    ab.drop_bits = d->dropout_p > 0.f ? (const uint32_t*)(A + L.dropbits) : nullptr;
+    ab.drop_bits = (d->dropout_p > 0.f && !r_attn) ? (const uint32_t*)(A + L.dropbits) : nullptr;
     if (W.attnws_bytes > 0) { ab.ws = (void*)(S + W.attnws); ab.ws_bytes = W.attnws_bytes; }
     if (r_attn) {   // queries at the wanted rows: everything on the query side is the gathered set (forward: Q rows in the region of the
                     // full attention output, the rows' output in the region of the full x1; the tables of the row set in the buffer's tail)

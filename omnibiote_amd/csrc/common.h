@@ -58,6 +58,9 @@ int obte_attn_fwd_rows(const obte_attn_fwd_args* a, const obte_attn_rows* r, con
 int obte_attn_bwd_rows(const obte_attn_bwd_args* a, const obte_attn_rows* r, const obte_bf16* q, obte_bf16* dq, obte_stream s);   // a->o, d_o, lse, delta: gathered; a->dqkv: dK, dV thirds
 // dst[m, 0:cols] (row stride ld) = src[inv[m]] (cols wide, dense) or zeros where inv[m] < 0; and the strided gather dst[i] = src[rows[i], 0:cols]
 int obte_rows_fill_strided_bf16(const obte_bf16* src, const int32_t* inv, obte_bf16* dst, int64_t total_rows, int64_t ld, int32_t cols, obte_stream s);
+// out[i] = (aux ? aux[i] : 0) + dropout(in[i]) on gathered rows: the mask element of (i, c) is (rows[i], c) of the whole activation
+int obte_dropout_rows_bf16(const obte_bf16* in, const obte_bf16* aux, obte_bf16* out, const int64_t* rows, int64_t n_rows, int32_t cols, float p,
+                           uint64_t seed, int32_t site, obte_stream s);
 int obte_rows_gather_strided_bf16(const obte_bf16* src, int64_t ld, const int64_t* rows, obte_bf16* dst, int64_t n_rows, int32_t cols, obte_stream s);
 
 // device status word (lib.cpp): pinned host memory kernels OR failure bits into; null if it could not be allocated

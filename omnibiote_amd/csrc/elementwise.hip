@@ -644,6 +644,32 @@ extern "C" int obte_embedding_fwd(const int64_t* idx, const obte_bf16* wte, obte
     return obte_embedding_fwd_dropout(idx, wte, out, rows, cols, vocab, 0.f, 0, s);
 }
 
+// the same on GATHERED rows: row i of in / out / aux is row rows[i] of the whole activation the mask is defined on (the rows form of
+// the block: csrc/block.cpp), out = (aux ? aux : 0) + dropout(in)
+__global__ __launch_bounds__(256) void dropout_rows_kernel(const bf16* __restrict__ in, const bf16* __restrict__ aux, bf16* __restrict__ out,
+                                                           const int64_t* __restrict__ rows, int64_t n_rows, int cols, DropCfg cfg) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t rk = drop_rowkey((uint64_t)rows[i], cfg);
+    for (int c = lane * 8; c < cols; c += 512) {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(in + i * cols + c);
+        bf16x8 a = {};
+        if (aux) a = *reinterpret_cast<const bf16x8*>(aux + i * cols + c);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const uint32_t bits = drop_pair_bits(rk, ((uint32_t)c >> 1) + jj);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int j = 2 * jj + e;
+                const float t = drop_keep_bits(bits, (uint32_t)e, cfg) ? bf2f(f2bf(bf2f(v[j]) * cfg.scale)) : 0.f;
+                v[j] = aux ? f2bf(bf2f(a[j]) + t) : f2bf(t);
+            }
+        }
+        *reinterpret_cast<bf16x8*>(out + i * cols + c) = v;
+    }
+}
+
 extern "C" int obte_dropout_bf16(const obte_bf16* in, obte_bf16* out, int64_t n, int64_t cols, float p, uint64_t seed, int32_t site,
                                  obte_stream s) {
     OBTE_REQUIRE(in && out && n > 0 && n % 8 == 0, "obte_dropout_bf16: null pointer or n not a positive multiple of 8");
@@ -868,5 +894,15 @@ extern "C" int obte_sumsq_multi_bf16_each(const obte_mt_args* a, float* out, obt
     if (blocks < 0) return blocks;
     hipLaunchKernelGGL(sumsq_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, t, out, 1);
     OBTE_CHECK_LAUNCH("obte_sumsq_multi_bf16_each");
+    return OBTE_OK;
+}
+
+int obte_dropout_rows_bf16(const obte_bf16* in, const obte_bf16* aux, obte_bf16* out, const int64_t* rows, int64_t n_rows, int32_t cols, float p,
+                           uint64_t seed, int32_t site, obte_stream s) {
+    OBTE_REQUIRE(in && out && rows && n_rows > 0 && cols > 0 && cols % 8 == 0, "obte_dropout_rows_bf16: bad arguments");
+    OBTE_REQUIRE(p > 0.f && p < 1.f, "obte_dropout_rows_bf16: p must be in (0,1)");
+    hipLaunchKernelGGL(dropout_rows_kernel, dim3((unsigned)cdiv64(n_rows, 4)), dim3(256), 0, (hipStream_t)s, (const bf16*)in, (const bf16*)aux, (bf16*)out,
+                       rows, n_rows, (int)cols, make_drop(p, seed, site));
+    OBTE_CHECK_LAUNCH("obte_dropout_rows_bf16");
     return OBTE_OK;
 }

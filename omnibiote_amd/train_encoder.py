@@ -618,8 +618,7 @@ def flops_per_token_executed(num_model_params: int, n_layer: int, n_embd: int, c
     """FLOP per token the step actually EXECUTES: the reference's 6N + 12LCT minus the products the readout form leaves out on
     the (1 - masked_fraction) of the positions the loss multiplies by zero (train_encoder.py:304) — "dense": the two backward
     products of the readout; "masked": all three, and with rows_forward the last block's MLP half (8 C^2 parameters) as well;
-    rows_attention (default: as rows_forward; the library takes this form at dropout 0 without a dense mask, csrc/block.cpp
-    rows_attn): also the last block's attention projection (C^2 parameters) and its attention for the queries at those
+    rows_attention (default: as rows_forward; the library takes this form without a dense mask, csrc/block.cpp rows_attn): also the last block's attention projection (C^2 parameters) and its attention for the queries at those
     positions — keys and values of every position are still formed, so c_attn stays whole."""
     skip = 1.0 - masked_fraction
     skipped = {"dense": 4.0 * n_embd * vocab * skip, "dense_full": 0.0, "masked": 6.0 * n_embd * vocab * skip}[lm_head_impl]
@@ -896,7 +895,7 @@ def run(args):
     fpt = flops_per_token(n_params, args.n_layer, args.n_embd, args.ctx_len)   # the reference's MFU formula (:360)
     # what this step executes: its default readout runs on the ~15 % MLM-masked positions only (fewer FLOP, same gradients)
     fpt_exec = flops_per_token_executed(n_params, args.n_layer, args.n_embd, args.ctx_len, step.lm_head_impl, step.rows_forward,
-                                        rows_attention=step.rows_forward and args.dropout == 0.0 and step.mask_impl == "ranges")
+                                        rows_attention=step.rows_forward and step.mask_impl == "ranges")
     n_steps = total_iters if args.max_steps <= 0 else min(total_iters, start + args.max_steps)
 
     def save(tag):
