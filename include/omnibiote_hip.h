@@ -352,8 +352,9 @@ typedef struct {
     const int32_t* ranges_exact;              /* nullable: obte_mask_bounds' flag for a dense mask (see obte_mask_bounds) */
     /* optional (the LAST block of a masked-LM step): only these positions of the block's output are wanted — the
      * loss multiplies every other position by zero (train_encoder.py:304) and nothing after the last block mixes positions.
-     * out_rows: int64 [n_out_rows], ascending distinct rows of the [B*T, C] activation.  ln_1 and c_attn run on every position
-     * (keys and values of all of them are needed); ln_2, c_fc + GELU and mlp.c_proj run on the listed rows only: y is
+     * out_rows: int64 [n_out_rows], ascending distinct rows of the [B*T, C] activation.  ln_1 and the k and v thirds of c_attn run
+     * on every position (keys and values of all of them are needed; without a dense mask the q third is formed for the listed
+     * rows only); ln_2, c_fc + GELU and mlp.c_proj run on the listed rows only: y is
      * [n_out_rows, C].  Without a dense mask the attention itself runs with its QUERIES at the listed rows only (keys and values
      * of every position; the rows' key ranges decide what each sees), and the attention projection on those rows.  Backward: dy
      * is [n_out_rows, C]; every gradient of those products is contracted over / formed for the listed rows (the rows left out

@@ -66,10 +66,10 @@ struct WsLayout {
 
 int gemm(const obte_bf16* a, const obte_bf16* b, obte_bf16* d, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
          int ak, int bk, int epi, const obte_bf16* aux, obte_bf16* d2, obte_stream s, void* ws = nullptr, int64_t ws_bytes = 0,
-         float drop_p = 0.f, uint64_t drop_seed = 0, int drop_site = 0) {
+         float drop_p = 0.f, uint64_t drop_seed = 0, int drop_site = 0, int64_t ldd = 0) {
     obte_gemm_args g = {};
     g.a = a; g.b = b; g.d = d; g.aux = aux; g.d2 = d2;
-    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldd = N;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldd = ldd > 0 ? ldd : N;
     g.a_kmajor = ak; g.b_kmajor = bk; g.epilogue = epi; g.alpha = 1.0f;
     if (epi == OBTE_EPI_ADD && drop_p > 0.f) {   // residual add with dropout on the projection output
         g.epilogue = OBTE_EPI_ADD_DROPOUT; g.dropout_p = drop_p; g.dropout_seed = drop_seed; g.dropout_site = drop_site;
@@ -113,6 +113,14 @@ int check_desc(const char* who, const obte_block_desc* d) {
 // every row (A/B timing, tests)
 // ... and the attention itself with its QUERIES at the wanted rows only (keys and values of every position; common.h obte_attn_rows):
 // the wanted rows' attention output is all the rest of the block reads.  Key ranges or no mask; OBTE_ROWS_ATTN=0 keeps the full attention.
+// ... and c_attn split by its output thirds: keys and values for every position, queries for the wanted rows only (the same products:
+// W_attn's rows 0 .. C-1 make q, C .. 3C-1 make k and v); RoPE then runs as its own small passes (on the k third by position = row % T,
+// on the gathered q rows by their positions) with the arithmetic of the fused epilogue.  OBTE_ROWS_QSPLIT=0 keeps the whole c_attn.
+bool rows_attn(const obte_block_desc* d);
+bool rows_qsplit(const obte_block_desc* d) {
+    static const bool off = [] { const char* e = getenv("OBTE_ROWS_QSPLIT"); return e && e[0] == '0'; }();
+    return rows_attn(d) && !off;
+}
 bool rows_proj(const obte_block_desc* d);
 bool rows_attn(const obte_block_desc* d) {
     static const bool off = [] { const char* e = getenv("OBTE_ROWS_ATTN"); return e && e[0] == '0'; }();
@@ -148,6 +156,11 @@ extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte
     float* lse = (float*)(A + L.lse);
 
     TRY(obte_layernorm_fwd(x, d->ln1_w, h1, mean1, rstd1, M, C, 1e-5f, s));
+    const bool q_split = rows_qsplit(d);
+    if (q_split) {   // keys and values of every position (the k third rotated in place); the queries follow below, for the wanted rows only
+        TRY(gemm(h1, d->attn_w + (int64_t)C * C, qkv + C, M, 2 * C, C, C, C, 1, 1, OBTE_EPI_NONE, nullptr, nullptr, s, nullptr, 0, 0.f, 0, 0, 3 * (int64_t)C));
+        TRY(obte_rope_cols_bf16(qkv + C, 3 * (int64_t)C, C, d->rope_cos, d->rope_sin, M, d->T, nullptr, hs, s));
+    } else
     {   // c_attn with RoPE on its q and k thirds fused in the epilogue (model.py:102-108)
         obte_gemm_args g = {};
         g.a = h1; g.b = d->attn_w; g.d = qkv;
@@ -181,7 +194,14 @@ extern "C" int obte_block_fwd(const obte_block_desc* d, const obte_bf16* x, obte
     if (r_attn) {   // Q of the wanted rows gathered into the region of the full attention output (not formed in this form); the rows'
                     // attention output lands where the projection below expects its gathered input: the region of the full x1
         obte_bf16* qr = yat;
-        TRY(obte_rows_gather_strided_bf16(qkv, 3 * (int64_t)C, d->out_rows, qr, d->n_out_rows, C, s));
+        if (q_split) {   // q = ln_1(x) W_q^T for the wanted rows, rotated at their positions (ln_1's rows gathered into the region x1r fills later)
+            obte_bf16* h1r = (obte_bf16*)(A + L.x1r);
+            TRY(obte_rows_gather_bf16(h1, d->out_rows, h1r, d->n_out_rows, M, C, s));
+            TRY(gemm(h1r, d->attn_w, qr, d->n_out_rows, C, C, C, C, 1, 1, OBTE_EPI_NONE, nullptr, nullptr, s, (void*)(A + L.hpre), M * 4 * C * 2));
+            TRY(obte_rope_cols_bf16(qr, C, C, d->rope_cos, d->rope_sin, d->n_out_rows, d->T, (const int32_t*)(A + L.r_pos), hs, s));
+        } else {
+            TRY(obte_rows_gather_strided_bf16(qkv, 3 * (int64_t)C, d->out_rows, qr, d->n_out_rows, C, s));
+        }
         af.o = x1;
         TRY(obte_attn_fwd_rows(&af, &ar, qr, s));
     } else {
@@ -279,6 +299,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     const bool rows_form = d->out_rows != nullptr;
     const bool rows_p = rows_proj(d);   // (implies rows_form, no dropout, and — below — the ungrouped form of the attention half)
     const bool r_attn = rows_attn(d);   // (implies rows_p: the attention's queries were the wanted rows only)
+    const bool q_split = rows_qsplit(d);   // (implies r_attn: c_attn ran by its output thirds)
     const int64_t Mm = rows_form ? d->n_out_rows : M;
     const obte_bf16* x1m = rows_form ? (const obte_bf16*)(A + L.x1r) : x1;
     const bool grouped_mlp = grouped && !rows_form;
@@ -364,15 +385,29 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
         ab.o = x1; ab.d_o = dym;
         obte_bf16* dqr = dym2;
         TRY(obte_attn_bwd_rows(&ab, &ar, yat, dqr, s));
-        TRY(obte_rows_fill_strided_bf16(dqr, (const int32_t*)(A + L.r_inv), dqkv, M, 3 * (int64_t)C, C, s));   // dqkv's q third: the rows' dQ, zeros elsewhere
+        if (q_split) {   // c_attn's backward by thirds: dK / dV of every position against W's k and v rows, dQ of the wanted rows against its q rows
+            const obte_bf16* dkv = dqkv + C;
+            const obte_bf16* w_kv = d->attn_w + (int64_t)C * C;
+            obte_bf16* tmp = dym;        // (d(attention output) of the wanted rows has been read by the attention backward)
+            obte_bf16* h1r = dyattn;     // (d x1 of the wanted rows has been read by the projection's products)
+            TRY(gemm(dkv, w_kv, dh, M, C, 2 * C, 3 * (int64_t)C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));                                   // dh1 = [dK dV] W_kv
+            TRY(gemm(dqr, d->attn_w, tmp, Mm, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s, gws, W.gemmws_bytes));                         //       + dQ W_q at the wanted rows
+            TRY(obte_rows_add_bf16(tmp, d->out_rows, dh, Mm, C, s));
+            TRY(obte_rows_gather_bf16(h1, d->out_rows, h1r, Mm, M, C, s));
+            obte_bf16* dw_kv = dattn_w + (int64_t)C * C;
+            TRY(gemm(dkv, h1, dw_kv, 2 * C, C, M, 3 * (int64_t)C, C, 0, 0, wepi, accumulate_matrices ? dw_kv : nullptr, nullptr, s, gws, W.gemmws_bytes));   // dW_kv = [dK dV]^T ln_1(x)
+            TRY(gemm(dqr, h1r, dattn_w, C, C, Mm, C, C, 0, 0, wepi, accumulate_matrices ? dattn_w : nullptr, nullptr, s, gws, W.gemmws_bytes));             // dW_q = dQ^T ln_1(x) over the wanted rows
+        } else {
+            TRY(obte_rows_fill_strided_bf16(dqr, (const int32_t*)(A + L.r_inv), dqkv, M, 3 * (int64_t)C, C, s));   // dqkv's q third: the rows' dQ, zeros elsewhere
+        }
     } else {
         TRY(obte_attn_bwd(&ab, s));
     }
     // OBTE_GROUPED_DGRAD=0 keeps dh1 = dqkv W_attn as its own launch (A/B timing)
     const char* gd = getenv("OBTE_GROUPED_DGRAD");
     const bool group_dgrad = grouped && !(gd && gd[0] == '0');
-    if (!group_dgrad) TRY(gemm(dqkv, d->attn_w, dh, M, C, 3 * C, 3 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh1 = dqkv W_attn
-    if (!grouped) TRY(gemm(dqkv, h1, dattn_w, 3 * C, C, M, 3 * C, C, 0, 0, wepi, accumulate_matrices ? dattn_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_attn = dqkv^T h1
+    if (!group_dgrad && !q_split) TRY(gemm(dqkv, d->attn_w, dh, M, C, 3 * C, 3 * C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dh1 = dqkv W_attn
+    if (!grouped && !q_split) TRY(gemm(dqkv, h1, dattn_w, 3 * C, C, M, 3 * C, C, 0, 0, wepi, accumulate_matrices ? dattn_w : nullptr, nullptr, s, gws, W.gemmws_bytes));               // dW_attn = dqkv^T h1
     if (grouped) {
         // One grid: dW_fc = dhpre^T h2, dW_mlp = dy^T hact, dW_attn = dqkv^T h1, dW_proj = dx1^T y (K = tokens, full K
         // per tile) and, on the CUs those tiles leave idle, dh1 = dqkv W_attn (K = 3C).

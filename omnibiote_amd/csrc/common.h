@@ -61,6 +61,10 @@ int obte_rows_fill_strided_bf16(const obte_bf16* src, const int32_t* inv, obte_b
 // out[i] = (aux ? aux[i] : 0) + dropout(in[i]) on gathered rows: the mask element of (i, c) is (rows[i], c) of the whole activation
 int obte_dropout_rows_bf16(const obte_bf16* in, const obte_bf16* aux, obte_bf16* out, const int64_t* rows, int64_t n_rows, int32_t cols, float p,
                            uint64_t seed, int32_t site, obte_stream s);
+// RoPE in place on columns [0, ncols) of x (row stride ld; head boundaries aligned), the row's position pos[row] or row % T; dst[rows[i]] += src[i]
+int obte_rope_cols_bf16(obte_bf16* x, int64_t ld, int32_t ncols, const float* cos_t, const float* sin_t, int64_t rows, int64_t T, const int32_t* pos,
+                        int32_t head_dim, obte_stream s);
+int obte_rows_add_bf16(const obte_bf16* src, const int64_t* rows, obte_bf16* dst, int64_t n_rows, int32_t cols, obte_stream s);
 int obte_rows_gather_strided_bf16(const obte_bf16* src, int64_t ld, const int64_t* rows, obte_bf16* dst, int64_t n_rows, int32_t cols, obte_stream s);
 
 // device status word (lib.cpp): pinned host memory kernels OR failure bits into; null if it could not be allocated

@@ -906,3 +906,56 @@ int obte_dropout_rows_bf16(const obte_bf16* in, const obte_bf16* aux, obte_bf16*
     OBTE_CHECK_LAUNCH("obte_dropout_rows_bf16");
     return OBTE_OK;
 }
+
+// ---- the rows form of the block's c_attn (csrc/block.cpp): RoPE on ONE column block of a row-strided activation, the row's position taken
+// from a list (gathered rows) or as row % T; and dst[rows[i]] += src[i] ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_cols_kernel(bf16* __restrict__ x, int64_t ld, int ncols, const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                        int64_t rows, int64_t T, const int32_t* __restrict__ pos, int hs) {
+    const int cpr = ncols / 8;
+    const int64_t total = rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cpr;
+        const int col = (int)(i % cpr) * 8;
+        const int d = col % hs;
+        const int64_t t = pos ? (int64_t)pos[row] : row % T;
+        bf16* ptr = x + row * ld + col;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(ptr);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(cos_t + t * (hs / 2) + d / 2);
+        const f32x4 sn = *reinterpret_cast<const f32x4*>(sin_t + t * (hs / 2) + d / 2);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // (the arithmetic of the GEMM epilogue OBTE_EPI_ROPE_QK and of rope_kernel)
+            const float xe = bf2f(v[2 * j]), xo = bf2f(v[2 * j + 1]);
+            o[2 * j] = f2bf(xe * c[j] - xo * sn[j]);
+            o[2 * j + 1] = f2bf(xe * sn[j] + xo * c[j]);
+        }
+        *reinterpret_cast<bf16x8*>(ptr) = o;
+    }
+}
+__global__ __launch_bounds__(256) void rows_add_kernel(const bf16* __restrict__ src, const int64_t* __restrict__ rows, bf16* __restrict__ dst, int64_t n_rows, int cols) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = rows[i];
+    for (int c = lane * 8; c < cols; c += 512) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(src + i * cols + c);
+        bf16x8 b = *reinterpret_cast<const bf16x8*>(dst + r * cols + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = f2bf(bf2f(a[j]) + bf2f(b[j]));
+        *reinterpret_cast<bf16x8*>(dst + r * cols + c) = b;
+    }
+}
+int obte_rope_cols_bf16(obte_bf16* x, int64_t ld, int32_t ncols, const float* cos_t, const float* sin_t, int64_t rows, int64_t T, const int32_t* pos,
+                        int32_t head_dim, obte_stream s) {
+    OBTE_REQUIRE(x && cos_t && sin_t && rows > 0 && ncols > 0 && ncols % 8 == 0 && ld % 8 == 0 && ld >= ncols && head_dim % 8 == 0 && ncols % head_dim == 0 && (pos || T > 0),
+                 "obte_rope_cols_bf16: bad arguments");
+    hipLaunchKernelGGL(rope_cols_kernel, dim3(stream_grid(rows * (ncols / 8), 256)), dim3(256), 0, (hipStream_t)s, (bf16*)x, ld, (int)ncols, cos_t, sin_t, rows, T, pos, (int)head_dim);
+    OBTE_CHECK_LAUNCH("obte_rope_cols_bf16");
+    return OBTE_OK;
+}
+int obte_rows_add_bf16(const obte_bf16* src, const int64_t* rows, obte_bf16* dst, int64_t n_rows, int32_t cols, obte_stream s) {
+    OBTE_REQUIRE(src && rows && dst && n_rows > 0 && cols > 0 && cols % 8 == 0, "obte_rows_add_bf16: bad arguments");
+    hipLaunchKernelGGL(rows_add_kernel, dim3((unsigned)cdiv64(n_rows, 4)), dim3(256), 0, (hipStream_t)s, (const bf16*)src, rows, (bf16*)dst, n_rows, (int)cols);
+    OBTE_CHECK_LAUNCH("obte_rows_add_bf16");
+    return OBTE_OK;
+}

@@ -618,14 +618,15 @@ def flops_per_token_executed(num_model_params: int, n_layer: int, n_embd: int, c
     """FLOP per token the step actually EXECUTES: the reference's 6N + 12LCT minus the products the readout form leaves out on
     the (1 - masked_fraction) of the positions the loss multiplies by zero (train_encoder.py:304) — "dense": the two backward
     products of the readout; "masked": all three, and with rows_forward the last block's MLP half (8 C^2 parameters) as well;
-    rows_attention (default: as rows_forward; the library takes this form without a dense mask, csrc/block.cpp rows_attn): also the last block's attention projection (C^2 parameters) and its attention for the queries at those
-    positions — keys and values of every position are still formed, so c_attn stays whole."""
+    rows_attention (default: as rows_forward; the library takes this form without a dense mask, csrc/block.cpp rows_attn): also the
+    last block's attention projection and the q third of its c_attn (C^2 parameters each) and its attention for the queries at
+    those positions — keys and values of every position are still formed."""
     skip = 1.0 - masked_fraction
     skipped = {"dense": 4.0 * n_embd * vocab * skip, "dense_full": 0.0, "masked": 6.0 * n_embd * vocab * skip}[lm_head_impl]
     if lm_head_impl == "masked" and rows_forward:
         skipped += 6.0 * 8.0 * n_embd ** 2 * skip
         if rows_attention is None or rows_attention:
-            skipped += (6.0 * n_embd ** 2 + 12.0 * n_embd * ctx_len * attention_fraction) * skip
+            skipped += (2 * 6.0 * n_embd ** 2 + 12.0 * n_embd * ctx_len * attention_fraction) * skip   # c_proj and c_attn's q third: C^2 parameters each
     # attention_fraction < 1 (rows that pack several documents): the share of the 12 L C T attention term the kernels visit
     skipped += 12.0 * n_layer * n_embd * ctx_len * (1.0 - attention_fraction)
     return flops_per_token(num_model_params, n_layer, n_embd, ctx_len) - skipped

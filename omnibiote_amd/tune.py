@@ -156,6 +156,9 @@ def model_gemm_shapes(rows: int, n_embd: int, vocab: int):
         (C, 4 * C, Mm, False, False, E.EPI_NONE), (4 * C, C, Mm, False, False, E.EPI_NONE),
         # and its attention projection on those positions (rows form without dropout: csrc/block.cpp rows_proj)
         (Mm, C, C, True, True, E.EPI_ADD), (Mm, C, C, True, False, E.EPI_NONE), (C, C, Mm, False, False, E.EPI_NONE),
+        # its c_attn by output thirds (rows_qsplit): k and v of every position, q of those positions; and the three backward products
+        (M, 2 * C, C, True, True, E.EPI_NONE), (Mm, C, C, True, True, E.EPI_NONE), (M, C, 2 * C, True, False, E.EPI_NONE),
+        (2 * C, C, M, False, False, E.EPI_NONE),
     ]
 
 

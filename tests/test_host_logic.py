@@ -256,7 +256,8 @@ def test_tuner_ranking_breaks_ties_towards_the_deeper_ring_and_lists_the_masked_
         (1232, 1024, 65536, True, False), (65536, 1024, 1232, False, False), (1232, 65536, 1024, True, True),      # the readout
         (1232, 4096, 1024, True, True), (1232, 1024, 4096, True, True), (1232, 4096, 1024, True, False), (1232, 1024, 4096, True, False),
         (1024, 4096, 1232, False, False), (4096, 1024, 1232, False, False),                                          # the last block's MLP half
-        (1232, 1024, 1024, True, True), (1232, 1024, 1024, True, False), (1024, 1024, 1232, False, False)])          # and its attention projection
+        (1232, 1024, 1024, True, True), (1232, 1024, 1024, True, False), (1024, 1024, 1232, False, False),           # and its attention projection
+        (1232, 1024, 1024, True, True)])                                                                             # and its q rows (epilogue NONE)
 
 
 def test_tuner_lists_the_192_wide_and_the_persistent_structure_only_where_they_apply():
