@@ -1249,16 +1249,7 @@ __device__ __forceinline__ int64_t rows_lower_bound(const int64_t* rows, int64_t
 __global__ __launch_bounds__(256) void attn_rows_prep_kernel(const int64_t* rows, int64_t n, int64_t B, int64_t T, const int32_t* kr_full,
                                                               int32_t* q_off, int32_t* q_blk_off, int32_t* q_pos, int32_t* kr_rows, int32_t* qb_rows, int32_t* inv) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i <= B) {
-        q_off[i] = (int32_t)rows_lower_bound(rows, n, i * T);
-        int64_t blocks = 0, prev = 0;   // 256-query blocks of the batch elements before i (the compact grid of the query-major kernels)
-        for (int64_t b = 0; b < i; ++b) {
-            const int64_t next = rows_lower_bound(rows, n, (b + 1) * T);
-            blocks += (next - prev + 255) / 256;
-            prev = next;
-        }
-        q_blk_off[i] = (int32_t)blocks;
-    }
+    if (i <= B) q_off[i] = (int32_t)rows_lower_bound(rows, n, i * T);   // (q_blk_off: attn_rows_blocks_kernel, once q_off is complete)
     if (i < n) {
         const int64_t r = rows[i];
         q_pos[i] = (int32_t)(r % T);
@@ -1274,6 +1265,32 @@ __global__ __launch_bounds__(256) void attn_rows_prep_kernel(const int64_t* rows
             qb_rows[2 * i + 1] = qe > qs ? (int32_t)(rows_lower_bound(rows, n, b * T + qe) - base) : qb_rows[2 * i];
         }
     }
+}
+// q_blk_off[b] = number of 256-query blocks of the batch elements before b (the compact grid of the query-major kernels): one
+// workgroup, a running sum over chunks of 256 batch elements (as part of the kernel above it was one thread's chain of B binary
+// searches: 40 of that launch's 50 us)
+__global__ __launch_bounds__(256) void attn_rows_blocks_kernel(const int32_t* q_off, int32_t* q_blk_off, int64_t B) {
+    __shared__ int32_t part[256];
+    __shared__ int32_t carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < B; b0 += 256) {
+        const int64_t b = b0 + tid;
+        part[tid] = b < B ? (q_off[b + 1] - q_off[b] + 255) / 256 : 0;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {   // inclusive scan
+            const int32_t v = tid >= o ? part[tid - o] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        if (b < B) q_blk_off[b + 1] = carry + part[tid];
+        __syncthreads();
+        if (tid == 255) carry += part[255];
+        __syncthreads();
+    }
+    if (tid == 0) q_blk_off[0] = 0;
 }
 // one wave per row, 16 B per lane per step
 __global__ __launch_bounds__(256) void rows_fill_strided_kernel(const bf16* src, const int32_t* inv, bf16* dst, int64_t total_rows, int64_t ld, int cols) {
@@ -1303,6 +1320,8 @@ int obte_attn_rows_prep(const int64_t* rows, int64_t n, int64_t B, int64_t T, co
     hipLaunchKernelGGL(attn_rows_prep_kernel, dim3((unsigned)cdiv64(B * T + 1, 256)), dim3(256), 0, (hipStream_t)s, rows, n, B, T, key_ranges_full,
                        q_off, q_blk_off, q_pos, key_ranges_rows, query_bounds_rows, inv);
     OBTE_CHECK_LAUNCH("obte_attn_rows_prep");
+    hipLaunchKernelGGL(attn_rows_blocks_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, q_off, q_blk_off, B);
+    OBTE_CHECK_LAUNCH("obte_attn_rows_prep(blocks)");
     return OBTE_OK;
 }
 int obte_rows_fill_strided_bf16(const obte_bf16* src, const int32_t* inv, obte_bf16* dst, int64_t total_rows, int64_t ld, int32_t cols, obte_stream s) {
