@@ -1100,7 +1100,11 @@ extern "C" int64_t obte_attn_bwd_ws_bytes(int64_t B, int64_t T, int32_t n_head, 
     return fused_bwd_ws_bytes(B, T, n_head);
 }
 
-extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
+static int attn_bwd_impl(const obte_attn_bwd_args* a, int delta_ready, obte_stream s);
+extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) { return attn_bwd_impl(a, 0, s); }
+// common.h: the same with a->delta already holding rowsum(dO o O)
+int obte_attn_bwd_delta_ready(const obte_attn_bwd_args* a, obte_stream s) { return attn_bwd_impl(a, 1, s); }
+static int attn_bwd_impl(const obte_attn_bwd_args* a, int delta_ready, obte_stream s) {
     OBTE_REQUIRE(a, "obte_attn_bwd: null args");
     int rc = check_common("obte_attn_bwd", a->qkv, a->B, a->T, a->n_head, a->head_dim, a->key_ranges, a->mask);
     if (rc) return rc;
@@ -1115,6 +1119,7 @@ extern "C" int obte_attn_bwd(const obte_attn_bwd_args* a, obte_stream s) {
     OBTE_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "obte_attn_bwd: dropout p must be in [0,1)");
     p.drop = make_drop(a->dropout_p, a->dropout_seed, OBTE_SITE_ATTN);
     p.max_tiles = debug_max_tiles(); p.no_wait = debug_no_wait(); p.dbg_skip = debug_skip();
+    p.delta_ready = delta_ready;
     p.dbg_times = debug_times_buffer(a->B * a->n_head * ((a->T + 127) / 128));
     const int mode = mask_mode(a->key_ranges, a->mask);
     p.drop_bits_in = (p.drop.thresh16 != 0 && a->head_dim == 128 && mode != MASK_DENSE) ? a->drop_bits : nullptr;

@@ -990,7 +990,9 @@ int launch_bwd_fused(const AttnParams& p, int mode, void* ws, hipStream_t st) {
     const bool inject = obte_fault_injection() == 1;
     fp.spin_limit = inject ? (1 << 10) : (1 << 20);
     fp.no_signal_slice = inject ? 0 : -1;
-    const int nb_delta = (int)cdiv64(p.B * p.T, 4), nb_flags = (int)cdiv64(p.B * p.H * nsl, 256);
+    // (delta already formed by the producer of dO — the row-dot epilogue of the projection's input gradient, csrc/block.cpp: the prep launch
+    //  then only zeroes the counters and derives the slice ranges)
+    const int nb_delta = p.delta_ready ? 0 : (int)cdiv64(p.B * p.T, 4), nb_flags = (int)cdiv64(p.B * p.H * nsl, 256);
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)(nb_delta + nb_flags + p.B * nkb)), dim3(256), 0, st, fp, mode, nb_delta, nb_flags);
     OBTE_CHECK_LAUNCH("obte_attn_bwd(prep)");
     const int smem = FusedShape<128>::SMEM;

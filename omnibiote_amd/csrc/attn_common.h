@@ -39,6 +39,7 @@ struct AttnParams {
     DropCfg drop;   // attention-probability dropout (site 1); thresh16 == 0: off
     uint32_t* drop_bits_out;         // forward, nullable: keep bits in key-major order, uint32 [B*H][ceil(T/32)][T] (bit i = query 32 t + i)
     const uint32_t* drop_bits_in;    // backward, nullable: the same buffer
+    int delta_ready;   // backward: p.delta already holds rowsum(dO o O) (the one-kernel form's prep launch skips it; the kernel pair forms its own)
     int no_wait;    // timing-only diagnostic (OBTE_ATTN_DEBUG=nowait): the tile loops do not wait for their LDS-DMA (results are wrong)
     int max_tiles;  // timing-only diagnostic (OBTE_ATTN_DEBUG=tiles:N): every workgroup stops after N tiles (results are wrong; 0 = off)
     int dbg_skip;   // timing-only diagnostic, debug build (OBTE_ATTN_SKIP=bits): dK/dV kernel — 1: no softmax arithmetic, 2: no phase-C MFMAs,

@@ -364,7 +364,17 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
     } else {
         TRY(obte_layernorm_bwd_acc(dh, x1, d->ln2_w, mean2, rstd2, dy, dx1, dln2_w, lnws, M, C, acc_ln, s));
     }
-    if (!rows_p) TRY(gemm(dx1_proj, d->proj_w, dyattn, M, C, C, C, C, 1, 0, OBTE_EPI_NONE, nullptr, nullptr, s));             // dy_attn = dx1 W_proj
+    bool delta_ready = false;
+    if (!rows_p) {   // dy_attn = dx1 W_proj — where structure 7 takes the shape, with the softmax backward's delta = rowsum(dy_attn o y) formed in
+                     // its epilogue (the attention backward's prep launch would otherwise read both tensors again to form it)
+        obte_gemm_args g = {};
+        g.a = dx1_proj; g.b = d->proj_w; g.d = dyattn; g.M = M; g.N = C; g.K = C; g.lda = C; g.ldb = C; g.ldd = C;
+        g.a_kmajor = 1; g.b_kmajor = 0; g.epilogue = OBTE_EPI_NONE; g.alpha = 1.0f;
+        const int rcd = obte_gemm_rowdot_bf16(&g, yat, delta, d->T, hs, s);
+        if (rcd == OBTE_OK) delta_ready = true;
+        else if (rcd == 1) TRY(obte_gemm_bf16(&g, s));
+        else return rcd;
+    }
     if (!grouped && !rows_p) TRY(gemm(dx1_proj, yat, dproj_w, C, C, M, C, C, 0, 0, wepi, accumulate_matrices ? dproj_w : nullptr, nullptr, s, gws, W.gemmws_bytes));                       // dW_proj = dx1^T y
     obte_attn_bwd_args ab = {};
     ab.qkv = qkv; ab.o = yat; ab.d_o = dyattn; ab.lse = lse; ab.delta = delta; ab.dqkv = dqkv;
@@ -401,7 +411,7 @@ extern "C" int obte_block_bwd_acc(const obte_block_desc* d, const obte_bf16* x, 
             TRY(obte_rows_fill_strided_bf16(dqr, (const int32_t*)(A + L.r_inv), dqkv, M, 3 * (int64_t)C, C, s));   // dqkv's q third: the rows' dQ, zeros elsewhere
         }
     } else {
-        TRY(obte_attn_bwd(&ab, s));
+        TRY(delta_ready ? obte_attn_bwd_delta_ready(&ab, s) : obte_attn_bwd(&ab, s));
     }
     // OBTE_GROUPED_DGRAD=0 keeps dh1 = dqkv W_attn as its own launch (A/B timing)
     const char* gd = getenv("OBTE_GROUPED_DGRAD");

@@ -37,6 +37,16 @@ void obte_set_error(const char* fmt, ...);
         }                                                                                 \
     } while (0)
 
+// ---- GEMM with a row-dot epilogue (library-internal: the block backward's d(attention output) = dx1 W_proj, structure 7 only) -----------
+// D = A B as OBTE_EPI_NONE (dy W layout: A k-contiguous, B not), and for every row m = b T + t and every head h (head_dim 128 columns):
+// rowdot[(b H + h) T + t] = sum over the head's columns of D[m, c] * other[m, c] (both as stored, bf16; fp32 sums) — the softmax
+// backward's delta = rowsum(dO o O), which the attention backward's prep launch otherwise forms by reading both tensors again.
+// Returns OBTE_OK, an error, or 1: this shape does not take structure 7 (nothing was launched: run the plain product instead).
+#define OBTE_EPI_ROWDOT 7
+extern "C" int obte_gemm_rowdot_bf16(const obte_gemm_args* g, const obte_bf16* other, float* rowdot, int64_t T, int32_t head_dim, obte_stream s);   // (C linkage: tests/ call it directly)
+
+int obte_attn_bwd_delta_ready(const obte_attn_bwd_args* a, obte_stream s);   // obte_attn_bwd with a->delta = rowsum(dO o O) already formed (the row-dot epilogue above)
+
 // ---- attention with the queries at listed rows only (library-internal: csrc/block.cpp's rows form calls it; attention.hip) -----------
 // The last block of a masked-LM step needs its attention output at the masked positions alone: the queries are a gathered set of
 // rows per batch element (ascending positions), keys and values stay the T rows of qkv.  Everything on the query side is

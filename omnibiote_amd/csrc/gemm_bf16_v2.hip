@@ -1219,6 +1219,34 @@ extern "C" int obte_gemm_bf16_ws(const obte_gemm_args* g, void* workspace, int64
 
 extern "C" int obte_gemm_bf16(const obte_gemm_args* g, obte_stream s) { return obte_gemm_bf16_ws(g, nullptr, 0, s); }
 
+// common.h: the plain dy W product with the row-dot epilogue, on structure 7 or not at all (1)
+extern "C" int obte_gemm_rowdot_bf16(const obte_gemm_args* g, const obte_bf16* other, float* rowdot, int64_t T, int32_t head_dim, obte_stream s) {
+    { const int vrc = validate_args(g); if (vrc != OBTE_OK) return vrc; }
+    OBTE_REQUIRE(other && rowdot && T > 0, "obte_gemm_rowdot_bf16: null pointer");
+    OBTE_REQUIRE(g->epilogue == OBTE_EPI_NONE && g->a_kmajor && !g->b_kmajor && g->alpha == 1.0f, "obte_gemm_rowdot_bf16: the plain dy W product only");
+    static const bool off = [] { const char* e = getenv("OBTE_GEMM_ROWDOT"); return e && e[0] == '0'; }();   // (A/B timing: the prep launch forms delta instead)
+    obte_gemm_args g2 = *g;
+    g2.epilogue = OBTE_EPI_ROWDOT;
+    if (off || head_dim != 128 || g->N % 128 != 0 || g->M % T != 0 || T >= (1ll << 31) || g->M >= (1ll << 31) || !obte_gemm_v7_eligible(&g2)) return 1;
+    hipStream_t st = (hipStream_t)s;
+    GemmParams p;
+    fill_params(g, nullptr, p);
+    p.aux = (const bf16*)other;
+    p.slab = rowdot;                      // (no split-K here: the slot carries the row-dot output)
+    p.tiles_m = (int)(g->M / BM); p.tiles_n = (int)(g->N / 256);
+    p.k_per_split = (int)cdiv64(g->K, BKT); p.splits = 1;
+    p.alpha = 1.0f;
+    p.rope_cos = nullptr; p.rope_sin = nullptr; p.rope_T = T; p.rope_hs = head_dim;
+    p.drop = make_drop(0.f, 0, 0);
+#ifdef OBTE_DEBUG_HOOKS
+    p.dbg_times = nullptr;
+#endif
+    const int prof = obte_prof_begin(st, 8 + OBTE_EPI_NONE + 7000, g->M, g->N, g->K);   // (recorded as the dy W product it is)
+    const int rc = obte_gemm_v7_launch(p, true, false, OBTE_EPI_ROWDOT, st);
+    obte_prof_end(prof, st);
+    return rc;
+}
+
 // Grouped launch (see gemm_v3_group_kernel).  Each problem: any layout, epilogue NONE or ADD, K >= 128.
 extern "C" int obte_gemm_grouped_bf16(const obte_gemm_args* gs, int count, obte_stream s) {
     OBTE_REQUIRE(gs && count >= 1 && count <= GROUP_MAX, "obte_gemm_grouped_bf16: count must be 1..%d", GROUP_MAX);

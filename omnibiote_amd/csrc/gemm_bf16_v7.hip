@@ -47,7 +47,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v7_kernel(GemmParams p) {
     constexpr int NJ = 8;
     constexpr int S_ST = EPI == OBTE_EPI_GELU ? 32 : 16;                            // stores of one epilogue per wave
     constexpr int WAIT_LAX = (((8 + S_ST) >> 4) << 14) | 0x0070 | ((8 + S_ST) & 15);   // s_waitcnt vmcnt(8 + S) lgkmcnt(0)
-    constexpr bool READS = EPI == OBTE_EPI_ADD || EPI == OBTE_EPI_GELU_BWD || EPI == OBTE_EPI_ADD_DROPOUT;
+    constexpr bool READS = EPI == OBTE_EPI_ADD || EPI == OBTE_EPI_GELU_BWD || EPI == OBTE_EPI_ADD_DROPOUT || EPI == OBTE_EPI_ROWDOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -190,6 +190,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_v7_kernel(GemmParams p) {
                 } else if (EPI == OBTE_EPI_ADD) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(raux[mi][it][j]) + bf2f(v[j]));
+                } else if (EPI == OBTE_EPI_ROWDOT) {
+                    // the wave tile's 128 columns are ONE head: the 16 lanes of a row piece hold the row's 128 values of it (common.h
+                    // obte_gemm_rowdot_bf16: p.slab = the output, p.rope_T = T, heads of 128 columns)
+                    float sdot = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sdot += bf2f(v[j]) * bf2f(raux[mi][it][j]);
+#pragma unroll
+                    for (int o_ = 1; o_ < 16; o_ <<= 1) sdot += __shfl_xor(sdot, o_, 64);
+                    if (em == 0) {
+                        const uint32_t mu = row_of(mi, it), T32 = (uint32_t)p.rope_T;
+                        const uint32_t bq = (T32 & (T32 - 1)) == 0 ? mu >> (31 - __builtin_clz(T32)) : mu / T32;   // batch element
+                        const uint32_t tq = mu - bq * T32, Hn = (uint32_t)(p.N >> 7), head = ((uint32_t)n0 + (uint32_t)wn * 128u) >> 7;
+                        p.slab[((int64_t)bq * Hn + head) * T32 + tq] = sdot;
+                    }
                 } else if (EPI == OBTE_EPI_GELU_BWD) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * bf2f(raux[mi][it][j]));
@@ -329,7 +343,7 @@ bool obte_gemm_v7_has(bool a_kmajor, bool b_kmajor, int epilogue) {
     if (a_kmajor && b_kmajor)
         return epilogue == OBTE_EPI_NONE || epilogue == OBTE_EPI_GELU || epilogue == OBTE_EPI_ADD || epilogue == OBTE_EPI_ADD_DROPOUT ||
                epilogue == OBTE_EPI_ROPE_QK;
-    if (a_kmajor && !b_kmajor) return epilogue == OBTE_EPI_NONE || epilogue == OBTE_EPI_GELU_BWD;
+    if (a_kmajor && !b_kmajor) return epilogue == OBTE_EPI_NONE || epilogue == OBTE_EPI_GELU_BWD || epilogue == OBTE_EPI_ROWDOT;
     return false;
 }
 
@@ -376,6 +390,7 @@ int obte_gemm_v7_launch(const GemmParams& p, bool ak, bool bk, int epi, hipStrea
         switch (epi) {
             case OBTE_EPI_NONE: return launch7<true, false, OBTE_EPI_NONE>(p, st);
             case OBTE_EPI_GELU_BWD: return launch7<true, false, OBTE_EPI_GELU_BWD>(p, st);
+            case OBTE_EPI_ROWDOT: return launch7<true, false, OBTE_EPI_ROWDOT>(p, st);
         }
     }
     obte_set_error("obte_gemm_bf16: structure 7 has no form for this layout / epilogue (%d %d %d)", (int)ak, (int)bk, epi);

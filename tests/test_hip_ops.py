@@ -889,6 +889,43 @@ def test_gemm_both_tile_widths(monkeypatch, bn):
     close(o.linear_fwd(x.to(DEV), w.to(DEV), alpha=1 / 42.0), acc / 42.0, atol=2e-3, what="alpha")
 
 
+def test_gemm_row_dot_epilogue_forms_the_softmax_backward_delta():
+    """The block backward's d(attention output) = dx1 W_proj with the row-dot epilogue of structure 7 (csrc/common.h
+    obte_gemm_rowdot_bf16): the product itself bit for bit the plain launch's, and rowdot[(b H + h) T + t] = sum over head h's 128
+    columns of D[b T + t, c] * other[b T + t, c] — the softmax backward's delta, which the attention backward's prep launch otherwise
+    forms by reading both tensors again; shapes structure 7 does not take answer 1 and launch nothing."""
+    import ctypes as C
+    o, Lm = ops(), L()
+    lib = Lm.lib()
+    lib.obte_gemm_rowdot_bf16.restype = C.c_int
+    lib.obte_gemm_rowdot_bf16.argtypes = [C.POINTER(Lm.GemmArgs), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+    for (B, T, Cc) in [(16, 1024, 1024), (64, 256, 2048)]:
+        M, H = B * T, Cc // 128
+        dx1, w, y = rnd(M, Cc, seed=3, scale=0.5), rnd(Cc, Cc, seed=4, scale=0.05), rnd(M, Cc, seed=5)
+        dx1d, wd, yd = dx1.to(DEV), w.to(DEV), y.to(DEV)
+        plain = o.gemm(dx1d, wd, M, Cc, Cc, True, False, Lm.EPI_NONE, None)
+        out = torch.empty(M * Cc, dtype=BF, device=DEV)
+        dot = torch.full((B * H * T,), float("nan"), dtype=torch.float32, device=DEV)
+        g = Lm.GemmArgs()
+        g.a, g.b, g.d = dx1d.data_ptr(), wd.data_ptr(), out.data_ptr()
+        g.M, g.N, g.K, g.lda, g.ldb, g.ldd = M, Cc, Cc, Cc, Cc, Cc
+        g.a_kmajor, g.b_kmajor, g.epilogue, g.alpha = 1, 0, Lm.EPI_NONE, 1.0
+        rc = lib.obte_gemm_rowdot_bf16(C.byref(g), yd.data_ptr(), dot.data_ptr(), T, 128, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, (rc, Lm.last_error() if hasattr(Lm, "last_error") else "")
+        assert torch.equal(out.reshape(M, Cc), plain.reshape(M, Cc)), "the product itself"
+        want = (out.reshape(B, T, H, 128).float() * yd.reshape(B, T, H, 128).float()).sum(-1).permute(0, 2, 1).reshape(-1)
+        close(dot, want.cpu(), atol=2e-3 * math.sqrt(128), rtol=1e-4, what=f"row dot B={B} T={T} C={Cc}")
+    # fewer than 256 tiles: not structure 7's shape
+    M, Cc = 2048, 1024
+    g = Lm.GemmArgs()
+    a_, b_, d_ = rnd(M, Cc, seed=1).to(DEV), rnd(Cc, Cc, seed=2).to(DEV), torch.empty(M * Cc, dtype=BF, device=DEV)
+    g.a, g.b, g.d = a_.data_ptr(), b_.data_ptr(), d_.data_ptr()
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldd = M, Cc, Cc, Cc, Cc, Cc
+    g.a_kmajor, g.b_kmajor, g.epilogue, g.alpha = 1, 0, Lm.EPI_NONE, 1.0
+    dot = torch.zeros(2 * 8 * 1024, dtype=torch.float32, device=DEV)
+    assert lib.obte_gemm_rowdot_bf16(C.byref(g), a_.data_ptr(), dot.data_ptr(), 1024, 128, torch.cuda.current_stream().cuda_stream) == 1
+
+
 def test_gemm_persistent_continuous_ring_structure():
     """Structure 7 (csrc/gemm_bf16_v7.hip: the 256 x 256 half-tile ring as a persistent kernel — the LDS-DMA stream runs on across
     tiles, each wave's epilogue goes through 4 KiB of staging of its own, stores drain under the next tile's loop): every layout and
